@@ -1,0 +1,126 @@
+/*
+ * fastsparse_hip.h -- C-ABI of libfastsparse_hip.so (MI355X / gfx950).
+ *
+ * Two layers, both plain C (no C++/torch types cross this boundary):
+ *
+ *  (1) the reference's own entry points -- A_mul_B, At_mul_B, csr_A_mul_B, bcsr_*,
+ *      bsbm_*, sdm_*, bsdm_*, cbcsr_* and the format constructors -- declared in
+ *      include/sparse.h, dsparse.h, csr.h, cbcsr.h with the reference's struct layouts
+ *      and signatures.  They accept host OR device pointers for x / y and keep a
+ *      device copy of each matrix in a side table keyed by the host struct
+ *      (fs_invalidate / fs_release below manage that table).
+ *
+ *  (2) the device-resident layer declared here: opaque matrix handles living in HBM,
+ *      products on device pointers and an explicit HIP stream.  This is what a
+ *      device-resident caller (CG loop, multi-GPU driver, bench.py) binds, and what
+ *      layer (1) is implemented on.
+ *
+ * Every function that can fail returns 0 on success and a negative fs_status
+ * otherwise; fs_last_error() gives the message for the calling thread.  There is no
+ * CPU fallback anywhere: without a usable HIP device the calls fail.
+ *
+ * Reference interfaces replaced (all in /root/reference):
+ *   csr_A_mul_B csr.h:425, csr_A_mul_Bn csr.h:441, bcsr_A_mul_B csr.h:149,
+ *   bcsr_A_mul_B2/_B4/_B8/_B8_auto/_Bn/_B32n csr.h:164-302, bcsr_AA_mul_B csr.h:305,
+ *   parallel_bcsr_AA_mul_B csr.h:323, A_mul_B sparse.h:58, At_mul_B sparse.h:68,
+ *   bsbm_A_mul_B/_B2/_B4/_Bn sparse.h:259-336, sdm_A_mul_B dsparse.h:43,
+ *   sdm_At_mul_B dsparse.h:54, bsdm_A_mul_B dsparse.h:176, cbcsr_A_mul_B cbcsr.h:76.
+ */
+#ifndef FASTSPARSE_HIP_H
+#define FASTSPARSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_matrix_s *fs_matrix_t;   /* device-resident sparse matrix (CSR, valued or pattern-only) */
+typedef struct fs_cbcsr_s  *fs_cbcsr_t;    /* device-resident column-blocked binary CSR (cbcsr.h:5-14)   */
+typedef void *fs_stream_t;                 /* a hipStream_t; NULL = the legacy default stream            */
+
+enum fs_status {
+  FS_OK = 0,
+  FS_ERR_HIP = -1,        /* a HIP runtime call failed (message has the HIP error string) */
+  FS_ERR_ARG = -2,        /* bad argument (NULL handle, negative size, k < 1, ...)          */
+  FS_ERR_NO_DEVICE = -3,  /* no gfx950 device visible                                        */
+  FS_ERR_NO_TRANSPOSE = -4 /* transposed product asked for before fs_matrix_build_transpose  */
+};
+
+enum fs_memspace { FS_HOST = 0, FS_DEVICE = 1 };
+
+/* ---- runtime ---------------------------------------------------------------------- */
+const char *fs_version(void);
+const char *fs_last_error(void);
+int  fs_device_count(void);
+int  fs_set_device(int device);
+/* option names: "strict_order" (0/1: thread-per-row sequential sums, bit-identical to the
+ * strict-IEEE CPU order for arbitrary x), "spmv_kernel" (0 = auto) */
+int  fs_set_option(const char *name, int value);
+int  fs_get_option(const char *name);
+
+/* ---- matrices in HBM ---------------------------------------------------------------- */
+/* CSR arrays -> handle.  vals == NULL makes a pattern-only (BinaryCSR) matrix.
+ * space says where row_ptr/cols/vals live.  With space == FS_DEVICE and borrow != 0 the
+ * handle uses the caller's device arrays in place (they must outlive the handle and be
+ * 16-byte aligned); otherwise the arrays are copied.  replaces: struct CSR csr.h:358-366,
+ * struct BinaryCSR csr.h:15-22 as device-side containers. */
+fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols,
+                          const double *vals, int space, int borrow);
+/* COO arrays -> handle; entries are stably ordered by row on the device, so every row keeps
+ * the caller's entry order (what new_csr csr.h:375-422 / new_bcsr csr.h:30-67 produce and
+ * what the serial COO loops sparse.h:58-65 / dsparse.h:43-51 sum in). */
+fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, const int *cols,
+                          const double *vals, int space);
+void fs_matrix_destroy(fs_matrix_t A);
+/* builds and caches the stably column-ordered CSR of A' (needed by *_t products) */
+int  fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream);
+int  fs_matrix_has_transpose(fs_matrix_t A);
+int  fs_matrix_nrow(fs_matrix_t A);
+int  fs_matrix_ncol(fs_matrix_t A);
+int64_t fs_matrix_nnz(fs_matrix_t A);
+/* HBM bytes one product has to move at least (SURVEY.md 8d formula):
+ * (12 or 4)*nnz + 4*(nrow+1) + 8*k*nrow + 8*k*ncol */
+int64_t fs_matrix_algorithmic_bytes(fs_matrix_t A, int k);
+/* copy the device CSR back (any pointer may be NULL); used by tests */
+int  fs_matrix_download(fs_matrix_t A, int transposed, int *row_ptr, int *cols, double *vals);
+
+/* ---- products on device pointers ---------------------------------------------------- */
+/* y[nrow] = A x[ncol]           (csr_A_mul_B / bcsr_A_mul_B / A_mul_B / sdm_A_mul_B / bsbm / bsdm) */
+int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
+/* y[ncol] = A' x[nrow]          (At_mul_B / sdm_At_mul_B; CSR At_mul_B of BASELINE config 2) */
+int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
+/* Y[nrow,k] = A X[ncol,k], X and Y row-major  (csr_A_mul_Bn, bcsr_A_mul_B2..._B32n, bsbm_A_mul_B2/_B4/_Bn) */
+int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
+int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
+/* y[ncol] = A'A x[ncol]; tmp is caller scratch of nrow doubles in HBM   (bcsr_AA_mul_B, parallel_bcsr_AA_mul_B) */
+int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream);
+
+/* ---- column-blocked binary CSR (cbcsr.h) -------------------------------------------- */
+fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, const int *row_ptr,
+                           const int *cols, int space);
+void fs_cbcsr_destroy(fs_cbcsr_t A);
+/* y[nrow] = A x: per column block the x tile is staged in LDS, cell sums are added block by block */
+int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream);
+
+/* ---- side table of layer (1) ---------------------------------------------------------- */
+/* forget the device copy made for a host struct (call after mutating its arrays in place) */
+void fs_invalidate(const void *host_struct);
+/* drop every cached device copy */
+void fs_release_all(void);
+
+/* ---- synthetic inputs for bench/tests (counter-based, identical to oracle/fs_synth.c) -- */
+/* exactly per_row entries per row, columns uniform on [0,ncol), vals uniform(-1,1) (vals may be NULL) */
+int fs_synth_uniform(int nrow, int ncol, int per_row, uint64_t seed, int64_t row_offset,
+                     int *row_ptr_dev, int *cols_dev, double *vals_dev, fs_stream_t stream);
+/* power-law row lengths (P(len >= L) ~ scale/L, clipped to [1,max_len]) for rows [row_offset, row_offset+nrow) */
+int fs_synth_powerlaw_lengths(int nrow, double scale, int max_len, uint64_t seed, int64_t row_offset,
+                              int *len_dev, fs_stream_t stream);
+/* fill cols/vals for a given row_ptr (uniform columns) */
+int fs_synth_fill(int nrow, int ncol, uint64_t seed, int64_t row_offset, const int *row_ptr_dev,
+                  int *cols_dev, double *vals_dev, fs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTSPARSE_HIP_H */

@@ -1,0 +1,235 @@
+"""ctypes binding of libfastsparse_hip.so (include/fastsparse_hip.h + the reference-named entry points).
+
+Loading fails loudly if the library has not been built (run `python -c "import __graft_entry__ as g; g.build()"`
+or `python libfastsparse_amd/_build.py`); nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfastsparse_hip.so")
+
+FS_HOST, FS_DEVICE = 0, 1
+
+vp = C.c_void_p
+_lib = None
+
+# every symbol declared in include/*.h (tests check that the library exports all of them)
+DEVICE_API = [
+    "fs_version", "fs_last_error", "fs_device_count", "fs_set_device", "fs_set_option", "fs_get_option",
+    "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose",
+    "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
+    "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul",
+    "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all",
+    "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill",
+]
+REFERENCE_API = [
+    # sparse.h
+    "new_sbm", "free_sbm", "new_transpose", "transpose", "read_sbm", "new_bsbm", "read_long",
+    "A_mul_B", "At_mul_B", "bsbm_A_mul_B", "bsbm_A_mul_B2", "bsbm_A_mul_B4", "bsbm_A_mul_Bn",
+    # dsparse.h
+    "new_sdm", "sdm_transpose", "read_sdm", "new_bsdm", "sdm_A_mul_B", "sdm_At_mul_B", "bsdm_A_mul_B",
+    # csr.h
+    "new_bcsr", "bcsr_from_sbm", "free_bcsr", "new_csr", "free_csr",
+    "bcsr_A_mul_B", "bcsr_A_mul_B2", "bcsr_A_mul_B4", "bcsr_A_mul_B8", "bcsr_A_mul_B8_auto", "bcsr_A_mul_Bn",
+    "bcsr_A_mul_B32n", "bcsr_AA_mul_B", "parallel_bcsr_AA_mul_B", "csr_A_mul_B", "csr_A_mul_Bn",
+    "csr_At_mul_B", "bcsr_At_mul_B",
+    # cbcsr.h
+    "new_cbcsr", "cbcsr_from_sbm", "cbcsr_A_mul_B",
+]
+
+
+class FastsparseError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Import torch first when device tensors are shared with it, so that
+    both use the same HIP runtime (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FastsparseError(f"{LIB_PATH} is missing: build it first (libfastsparse_amd._build.build()); "
+                              "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.fs_version.restype = C.c_char_p
+    L.fs_last_error.restype = C.c_char_p
+    L.fs_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.fs_get_option.argtypes = [C.c_char_p]
+    L.fs_csr_create.restype = vp
+    L.fs_csr_create.argtypes = [C.c_int, C.c_int, C.c_int64, vp, vp, vp, C.c_int, C.c_int]
+    L.fs_coo_create.restype = vp
+    L.fs_coo_create.argtypes = [C.c_int, C.c_int, C.c_int64, vp, vp, vp, C.c_int]
+    L.fs_matrix_destroy.argtypes = [vp]
+    L.fs_matrix_destroy.restype = None
+    L.fs_matrix_build_transpose.argtypes = [vp, vp]
+    L.fs_matrix_has_transpose.argtypes = [vp]
+    L.fs_matrix_nrow.argtypes = [vp]
+    L.fs_matrix_ncol.argtypes = [vp]
+    L.fs_matrix_nnz.argtypes = [vp]
+    L.fs_matrix_nnz.restype = C.c_int64
+    L.fs_matrix_algorithmic_bytes.argtypes = [vp, C.c_int]
+    L.fs_matrix_algorithmic_bytes.restype = C.c_int64
+    L.fs_matrix_download.argtypes = [vp, C.c_int, vp, vp, vp]
+    for f in ("fs_spmv", "fs_spmv_t"):
+        getattr(L, f).argtypes = [vp, vp, vp, vp]
+    for f in ("fs_spmm", "fs_spmm_t"):
+        getattr(L, f).argtypes = [vp, vp, vp, C.c_int, vp]
+    L.fs_ata_mul.argtypes = [vp, vp, vp, vp, vp]
+    L.fs_cbcsr_create.restype = vp
+    L.fs_cbcsr_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.fs_cbcsr_destroy.argtypes = [vp]
+    L.fs_cbcsr_destroy.restype = None
+    L.fs_cbcsr_spmv.argtypes = [vp, vp, vp, vp]
+    L.fs_invalidate.argtypes = [vp]
+    L.fs_invalidate.restype = None
+    L.fs_release_all.restype = None
+    L.fs_synth_uniform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, vp, vp, vp, vp]
+    L.fs_synth_powerlaw_lengths.argtypes = [C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int64, vp, vp]
+    L.fs_synth_fill.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what="call"):
+    if rc != 0:
+        raise FastsparseError(f"{what} failed ({rc}): {lib().fs_last_error().decode()}")
+
+
+def _ptr(t):
+    """device/host address of a torch tensor, numpy array, or None"""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        assert t.is_contiguous()
+        return t.data_ptr()
+    assert t.flags.c_contiguous
+    return t.ctypes.data
+
+
+def _space(t):
+    return FS_DEVICE if hasattr(t, "is_cuda") and t.is_cuda else FS_HOST
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Matrix:
+    """Device-resident CSR (valued or pattern-only) behind an fs_matrix_t handle."""
+
+    def __init__(self, handle, keep=()):
+        if not handle:
+            raise FastsparseError("matrix creation failed: " + lib().fs_last_error().decode())
+        self.h = handle
+        self._keep = keep  # borrowed device arrays must outlive the handle
+
+    @classmethod
+    def from_csr(cls, nrow, ncol, row_ptr, cols, vals=None, borrow=False):
+        nnz = int(cols.numel() if hasattr(cols, "numel") else cols.size)
+        h = lib().fs_csr_create(nrow, ncol, nnz, _ptr(row_ptr), _ptr(cols), _ptr(vals), _space(cols), int(borrow))
+        return cls(h, (row_ptr, cols, vals) if borrow else ())
+
+    @classmethod
+    def from_coo(cls, nrow, ncol, rows, cols, vals=None):
+        nnz = int(cols.numel() if hasattr(cols, "numel") else cols.size)
+        return cls(lib().fs_coo_create(nrow, ncol, nnz, _ptr(rows), _ptr(cols), _ptr(vals), _space(cols)))
+
+    nrow = property(lambda s: lib().fs_matrix_nrow(s.h))
+    ncol = property(lambda s: lib().fs_matrix_ncol(s.h))
+    nnz = property(lambda s: lib().fs_matrix_nnz(s.h))
+
+    def algorithmic_bytes(self, k=1):
+        return lib().fs_matrix_algorithmic_bytes(self.h, k)
+
+    def build_transpose(self, stream=None):
+        check(lib().fs_matrix_build_transpose(self.h, stream), "fs_matrix_build_transpose")
+
+    def download(self, transposed=False):
+        import numpy as np
+        nrow, ncol, nnz = (self.ncol, self.nrow, self.nnz) if transposed else (self.nrow, self.ncol, self.nnz)
+        rp = np.empty(nrow + 1, np.int32)
+        cc = np.empty(nnz, np.int32)
+        vv = np.full(nnz, np.nan)
+        check(lib().fs_matrix_download(self.h, int(transposed), rp.ctypes.data, cc.ctypes.data, vv.ctypes.data))
+        return rp, cc, vv
+
+    def spmv(self, y, x, stream=None, transposed=False):
+        f = lib().fs_spmv_t if transposed else lib().fs_spmv
+        check(f(self.h, _ptr(y), _ptr(x), stream), "fs_spmv")
+
+    def spmm(self, Y, X, k, stream=None, transposed=False):
+        f = lib().fs_spmm_t if transposed else lib().fs_spmm
+        check(f(self.h, _ptr(Y), _ptr(X), k, stream), "fs_spmm")
+
+    def ata(self, y, x, tmp, stream=None):
+        check(lib().fs_ata_mul(self.h, _ptr(y), _ptr(x), _ptr(tmp), stream), "fs_ata_mul")
+
+    def close(self):
+        if self.h:
+            lib().fs_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ColBlockMatrix:
+    """Device-resident column-blocked binary CSR (cbcsr.h)."""
+
+    def __init__(self, nrow, ncol, nblocks, colblocksize, row_ptr, cols):
+        self.h = lib().fs_cbcsr_create(nrow, ncol, nblocks, colblocksize, _ptr(row_ptr), _ptr(cols), _space(cols))
+        if not self.h:
+            raise FastsparseError("fs_cbcsr_create failed: " + lib().fs_last_error().decode())
+
+    def spmv(self, y, x, stream=None):
+        check(lib().fs_cbcsr_spmv(self.h, _ptr(y), _ptr(x), stream), "fs_cbcsr_spmv")
+
+    def close(self):
+        if self.h:
+            lib().fs_cbcsr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def set_option(name, value):
+    check(lib().fs_set_option(name.encode(), int(value)), "fs_set_option")
+
+
+def synth_uniform(nrow, ncol, per_row, seed, row_offset=0, valued=True, device="cuda"):
+    """Uniform synthetic CSR generated on the device (BASELINE configs 2-4)."""
+    import torch
+    nnz = nrow * per_row
+    row_ptr = torch.empty(nrow + 1, dtype=torch.int32, device=device)
+    cols = torch.empty(max(nnz, 1), dtype=torch.int32, device=device)[:nnz]
+    vals = torch.empty(max(nnz, 1), dtype=torch.float64, device=device)[:nnz] if valued else None
+    check(lib().fs_synth_uniform(nrow, ncol, per_row, seed, row_offset, _ptr(row_ptr), _ptr(cols), _ptr(vals),
+                                 current_stream()), "fs_synth_uniform")
+    return row_ptr, cols, vals
+
+
+def synth_powerlaw(nrow, ncol, scale, max_len, seed, row_offset=0, valued=True, device="cuda"):
+    """Power-law row lengths, uniform columns (BASELINE config 5 shards)."""
+    import torch
+    lens = torch.empty(nrow, dtype=torch.int32, device=device)
+    check(lib().fs_synth_powerlaw_lengths(nrow, float(scale), max_len, seed, row_offset, _ptr(lens), current_stream()))
+    row_ptr = torch.zeros(nrow + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=row_ptr[1:])
+    nnz = int(row_ptr[-1].item())
+    if nnz > 2**31 - 1:
+        raise FastsparseError("shard holds more than 2^31-1 non-zeros: int row_ptr cannot index it")
+    row_ptr = row_ptr.to(torch.int32)
+    cols = torch.empty(nnz, dtype=torch.int32, device=device)
+    vals = torch.empty(nnz, dtype=torch.float64, device=device) if valued else None
+    check(lib().fs_synth_fill(nrow, ncol, seed, row_offset, _ptr(row_ptr), _ptr(cols), _ptr(vals), current_stream()))
+    return row_ptr, cols, vals

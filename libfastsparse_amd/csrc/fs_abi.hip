@@ -1,0 +1,253 @@
+// fs_abi.hip -- the device-resident layer of the C-ABI (include/fastsparse_hip.h, part 2).
+#include <string.h>
+
+#include "fs_common.h"
+
+namespace fs {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string &msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
+  g_err = buf;
+  return FS_ERR_HIP;
+}
+
+Options &options()
+{
+  static Options o;
+  return o;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+static int to_device(T **dst, const T *src, size_t n, int space)
+{
+  FS_HIP(hipMalloc(dst, sizeof(T) * (n ? n : 1)));
+  if (n) FS_HIP(hipMemcpy(*dst, src, sizeof(T) * n, space == FS_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  return FS_OK;
+}
+
+}  // namespace fs
+
+using fs::set_error;
+
+extern "C" {
+
+const char *fs_version(void) { return "fastsparse-hip 0.1 (gfx950)"; }
+const char *fs_last_error(void) { return fs::g_err.c_str(); }
+
+int fs_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fs_set_device(int device)
+{
+  FS_HIP(hipSetDevice(device));
+  return FS_OK;
+}
+
+int fs_set_option(const char *name, int value)
+{
+  if (!name) { set_error("fs_set_option: NULL name"); return FS_ERR_ARG; }
+  if (!strcmp(name, "strict_order")) { fs::options().strict_order = value; return FS_OK; }
+  if (!strcmp(name, "spmv_kernel")) { fs::options().spmv_kernel = value; return FS_OK; }
+  set_error(std::string("fs_set_option: unknown option ") + name);
+  return FS_ERR_ARG;
+}
+
+int fs_get_option(const char *name)
+{
+  if (name && !strcmp(name, "strict_order")) return fs::options().strict_order;
+  if (name && !strcmp(name, "spmv_kernel")) return fs::options().spmv_kernel;
+  return FS_ERR_ARG;
+}
+
+fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols, const double *vals,
+                          int space, int borrow)
+{
+  if (nrow < 0 || ncol < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !cols)) {
+    set_error("fs_csr_create: bad argument");
+    return nullptr;
+  }
+  fs_matrix_t M = new fs_matrix_s();
+  if (hipGetDevice(&M->device) != hipSuccess) { set_error("fs_csr_create: no HIP device"); delete M; return nullptr; }
+  fs::DeviceCsr &A = M->a;
+  A.nrow = nrow; A.ncol = ncol; A.nnz = nnz;
+  int rc = FS_OK;
+  if (space == FS_DEVICE && borrow && fs::aligned16(cols) && (!vals || fs::aligned16(vals))) {
+    A.owns = false;
+    A.row_ptr = const_cast<int *>(row_ptr);
+    A.cols = const_cast<int *>(cols);
+    A.vals = const_cast<double *>(vals);
+  } else {
+    A.owns = true;
+    rc = fs::to_device(&A.row_ptr, row_ptr, (size_t)nrow + 1, space);
+    if (!rc) rc = fs::to_device(&A.cols, cols, (size_t)nnz, space);
+    if (!rc && vals) rc = fs::to_device(&A.vals, vals, (size_t)nnz, space);
+  }
+  if (!rc) rc = fs::build_schedule(A, nullptr);
+  if (rc) { fs::free_csr(A); delete M; return nullptr; }
+  return M;
+}
+
+fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, const int *cols, const double *vals,
+                          int space)
+{
+  if (nrow < 0 || ncol < 0 || nnz < 0 || (nnz > 0 && (!rows || !cols))) {
+    set_error("fs_coo_create: bad argument");
+    return nullptr;
+  }
+  fs_matrix_t M = new fs_matrix_s();
+  if (hipGetDevice(&M->device) != hipSuccess) { set_error("fs_coo_create: no HIP device"); delete M; return nullptr; }
+  int *r = nullptr, *c = nullptr;
+  double *v = nullptr;
+  int rc = FS_OK;
+  if (space == FS_DEVICE) {
+    r = const_cast<int *>(rows); c = const_cast<int *>(cols); v = const_cast<double *>(vals);
+  } else {
+    rc = fs::to_device(&r, rows, (size_t)nnz, FS_HOST);
+    if (!rc) rc = fs::to_device(&c, cols, (size_t)nnz, FS_HOST);
+    if (!rc && vals) rc = fs::to_device(&v, vals, (size_t)nnz, FS_HOST);
+  }
+  if (!rc) rc = fs::coo_to_csr_device(M->a, nrow, ncol, nnz, r, c, v, nullptr);
+  if (space != FS_DEVICE) {
+    if (r) (void)hipFree(r);
+    if (c) (void)hipFree(c);
+    if (v) (void)hipFree(v);
+  }
+  if (rc) { fs::free_csr(M->a); delete M; return nullptr; }
+  return M;
+}
+
+void fs_matrix_destroy(fs_matrix_t A)
+{
+  if (!A) return;
+  fs::free_csr(A->a);
+  if (A->has_t) fs::free_csr(A->at);
+  delete A;
+}
+
+int fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream)
+{
+  if (!A) { set_error("fs_matrix_build_transpose: NULL handle"); return FS_ERR_ARG; }
+  std::lock_guard<std::mutex> g(A->lock);
+  if (A->has_t) return FS_OK;
+  const int rc = fs::transpose_device(A->a, A->at, (hipStream_t)stream);
+  if (rc) { fs::free_csr(A->at); return rc; }
+  A->has_t = true;
+  return FS_OK;
+}
+
+int fs_matrix_has_transpose(fs_matrix_t A) { return A && A->has_t; }
+int fs_matrix_nrow(fs_matrix_t A) { return A ? A->a.nrow : FS_ERR_ARG; }
+int fs_matrix_ncol(fs_matrix_t A) { return A ? A->a.ncol : FS_ERR_ARG; }
+int64_t fs_matrix_nnz(fs_matrix_t A) { return A ? A->a.nnz : FS_ERR_ARG; }
+
+int64_t fs_matrix_algorithmic_bytes(fs_matrix_t A, int k)
+{
+  if (!A || k < 1) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = A->a;
+  return (a.vals ? 12 : 4) * a.nnz + 4 * ((int64_t)a.nrow + 1) + 8ll * k * a.nrow + 8ll * k * a.ncol;
+}
+
+int fs_matrix_download(fs_matrix_t A, int transposed, int *row_ptr, int *cols, double *vals)
+{
+  if (!A) { set_error("fs_matrix_download: NULL handle"); return FS_ERR_ARG; }
+  if (transposed && !A->has_t) { set_error("fs_matrix_download: transpose not built"); return FS_ERR_NO_TRANSPOSE; }
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (row_ptr) FS_HIP(hipMemcpy(row_ptr, a.row_ptr, sizeof(int) * ((size_t)a.nrow + 1), hipMemcpyDeviceToHost));
+  if (cols && a.nnz) FS_HIP(hipMemcpy(cols, a.cols, sizeof(int) * (size_t)a.nnz, hipMemcpyDeviceToHost));
+  if (vals && a.vals && a.nnz) FS_HIP(hipMemcpy(vals, a.vals, sizeof(double) * (size_t)a.nnz, hipMemcpyDeviceToHost));
+  return FS_OK;
+}
+
+static int check_mul(fs_matrix_t A, const void *y, const void *x, const char *who)
+{
+  if (!A || !y || !x) { set_error(std::string(who) + ": NULL argument"); return FS_ERR_ARG; }
+  return FS_OK;
+}
+
+int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
+{
+  if (int rc = check_mul(A, y, x, "fs_spmv")) return rc;
+  std::lock_guard<std::mutex> g(A->lock);
+  return fs::launch_spmv(A->a, y, x, (hipStream_t)stream);
+}
+
+int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
+{
+  if (int rc = check_mul(A, y, x, "fs_spmv_t")) return rc;
+  if (!A->has_t) { set_error("fs_spmv_t: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  return fs::launch_spmv(A->at, y, x, (hipStream_t)stream);
+}
+
+int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream)
+{
+  if (int rc = check_mul(A, Y, X, "fs_spmm")) return rc;
+  if (k < 1) { set_error("fs_spmm: k < 1"); return FS_ERR_ARG; }
+  if (k == 1) return fs_spmv(A, Y, X, stream);
+  return fs::launch_spmm(A->a, Y, X, k, (hipStream_t)stream);
+}
+
+int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream)
+{
+  if (int rc = check_mul(A, Y, X, "fs_spmm_t")) return rc;
+  if (k < 1) { set_error("fs_spmm_t: k < 1"); return FS_ERR_ARG; }
+  if (!A->has_t) { set_error("fs_spmm_t: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  if (k == 1) return fs_spmv_t(A, Y, X, stream);
+  return fs::launch_spmm(A->at, Y, X, k, (hipStream_t)stream);
+}
+
+int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream)
+{
+  if (int rc = check_mul(A, y, x, "fs_ata_mul")) return rc;
+  if (!tmp) { set_error("fs_ata_mul: NULL scratch"); return FS_ERR_ARG; }
+  if (int rc = fs_matrix_build_transpose(A, stream)) return rc;
+  if (int rc = fs_spmv(A, tmp, x, stream)) return rc;
+  return fs_spmv_t(A, y, tmp, stream);
+}
+
+fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, const int *row_ptr, const int *cols,
+                           int space)
+{
+  if (nrow < 0 || ncol < 0 || nblocks < 0 || colblocksize < 1 || !row_ptr) {
+    set_error("fs_cbcsr_create: bad argument");
+    return nullptr;
+  }
+  fs_cbcsr_t M = new fs_cbcsr_s();
+  M->nrow = nrow; M->ncol = ncol; M->nblocks = nblocks; M->colblocksize = colblocksize;
+  const size_t ncell = (size_t)nblocks * (size_t)nrow;
+  int rc = fs::to_device(&M->row_ptr, row_ptr, ncell + 1, space);
+  int last = 0;
+  if (!rc && hipMemcpy(&last, M->row_ptr + ncell, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = FS_ERR_HIP;
+  M->nnz = last;
+  if (!rc) rc = fs::to_device(&M->cols, cols, (size_t)M->nnz, space);
+  if (rc) { fs_cbcsr_destroy(M); return nullptr; }
+  return M;
+}
+
+void fs_cbcsr_destroy(fs_cbcsr_t A)
+{
+  if (!A) return;
+  if (A->row_ptr) (void)hipFree(A->row_ptr);
+  if (A->cols) (void)hipFree(A->cols);
+  delete A;
+}
+
+int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream)
+{
+  if (!A || !y || !x) { set_error("fs_cbcsr_spmv: NULL argument"); return FS_ERR_ARG; }
+  return fs::launch_cbcsr(*A, y, x, (hipStream_t)stream);
+}
+
+}  // extern "C"

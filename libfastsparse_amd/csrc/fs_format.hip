@@ -1,0 +1,288 @@
+// fs_format.hip -- one-time format work on the device: chunk schedule of the streaming
+// SpMV kernel, stable COO -> CSR, CSR -> CSR of the transpose, synthetic generators.
+//
+// The reference builds its CSRs on the host with a stable counting sort (new_csr csr.h:375-422,
+// new_bcsr csr.h:30-67).  Here the same result (entries of a row kept in input order) comes
+// from a stable LSD radix sort of (row key, entry index) pairs -- rocPRIM's device radix sort is
+// used for this one-time step; the products themselves run on the hand-written kernels of
+// fs_kernels.hip.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "fs_common.h"
+
+namespace fs {
+
+// ---- small helpers -------------------------------------------------------------------------
+void free_csr(DeviceCsr &A)
+{
+  if (A.owns) {
+    if (A.row_ptr) (void)hipFree(A.row_ptr);
+    if (A.cols) (void)hipFree(A.cols);
+    if (A.vals) (void)hipFree(A.vals);
+  }
+  if (A.first_row) (void)hipFree(A.first_row);
+  if (A.head) (void)hipFree(A.head);
+  if (A.tail) (void)hipFree(A.tail);
+  A = DeviceCsr();
+}
+
+// first index r in [0, n] with a[r] >= key (a non-decreasing)
+__device__ __forceinline__ int lower_bound_dev(const int *__restrict__ a, int n, int64_t key)
+{
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if ((int64_t)a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// first_row[c] = first row whose first non-zero index is >= c*kChunk; first_row[nchunks] = nrow
+__global__ void schedule_kernel(int nrow, int nchunks, const int *__restrict__ row_ptr, int *__restrict__ first_row)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nchunks) return;
+  first_row[c] = (c == nchunks) ? nrow : lower_bound_dev(row_ptr, nrow, (int64_t)c * kChunk);
+}
+
+__global__ void count_spanning_kernel(int nchunks, int64_t nnz, const int *__restrict__ row_ptr,
+                                      const int *__restrict__ first_row, int *__restrict__ count)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const int r0 = first_row[c], r1 = first_row[c + 1];
+  if (r1 <= r0) return;
+  int64_t e = (int64_t)(c + 1) * kChunk;
+  if (e > nnz) e = nnz;
+  if ((int64_t)row_ptr[r1] > e) atomicAdd(count, 1);
+}
+
+int build_schedule(DeviceCsr &A, hipStream_t s)
+{
+  A.nchunks = (int)((A.nnz + kChunk - 1) / kChunk);
+  if (A.nchunks < 1) A.nchunks = 1;
+  FS_HIP(hipMalloc(&A.first_row, sizeof(int) * ((size_t)A.nchunks + 1)));
+  FS_HIP(hipMalloc(&A.head, sizeof(double) * (size_t)A.nchunks));
+  FS_HIP(hipMalloc(&A.tail, sizeof(double) * (size_t)A.nchunks));
+  FS_HIP(hipMemsetAsync(A.head, 0, sizeof(double) * (size_t)A.nchunks, s));
+  FS_HIP(hipMemsetAsync(A.tail, 0, sizeof(double) * (size_t)A.nchunks, s));
+  const int n = A.nchunks + 1;
+  hipLaunchKernelGGL(schedule_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A.nrow, A.nchunks, A.row_ptr,
+                     A.first_row);
+  FS_HIP(hipGetLastError());
+  int *cnt = nullptr;
+  FS_HIP(hipMalloc(&cnt, sizeof(int)));
+  FS_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
+  hipLaunchKernelGGL(count_spanning_kernel, dim3((A.nchunks + 255) / 256), dim3(256), 0, s, A.nchunks, A.nnz,
+                     A.row_ptr, A.first_row, cnt);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  FS_HIP(hipFree(cnt));
+  return FS_OK;
+}
+
+// ---- stable COO -> CSR -----------------------------------------------------------------------
+__global__ void iota_kernel(int64_t n, unsigned *__restrict__ idx)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = (unsigned)i;
+}
+
+__global__ void permute_kernel(int64_t n, const unsigned *__restrict__ perm, const int *__restrict__ cols_in,
+                               const double *__restrict__ vals_in, int *__restrict__ cols_out,
+                               double *__restrict__ vals_out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned src = perm[i];
+  cols_out[i] = cols_in[src];
+  if (vals_in) vals_out[i] = vals_in[src];
+}
+
+// row_ptr[r] = first position in the sorted key array whose key is >= r
+__global__ void row_ptr_kernel(int nrow, int64_t nnz, const int *__restrict__ sorted_rows, int *__restrict__ row_ptr)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrow) return;
+  int64_t lo = 0, hi = nnz;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (sorted_rows[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  row_ptr[r] = (int)lo;
+}
+
+static unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
+
+int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev, const int *cols_dev,
+                      const double *vals_dev, hipStream_t s)
+{
+  out = DeviceCsr();
+  out.nrow = nrow; out.ncol = ncol; out.nnz = nnz; out.owns = true;
+  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+  FS_HIP(hipMalloc(&out.row_ptr, sizeof(int) * ((size_t)nrow + 1)));
+  FS_HIP(hipMalloc(&out.cols, sizeof(int) * n));
+  if (vals_dev) FS_HIP(hipMalloc(&out.vals, sizeof(double) * n));
+  int *keys_out = nullptr;
+  unsigned *idx_in = nullptr, *idx_out = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  FS_HIP(hipMalloc(&keys_out, sizeof(int) * n));
+  FS_HIP(hipMalloc(&idx_in, sizeof(unsigned) * n));
+  FS_HIP(hipMalloc(&idx_out, sizeof(unsigned) * n));
+  if (nnz > 0) {
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_in);
+    FS_HIP(hipGetLastError());
+    int bits = 1;
+    while (bits < 31 && (1ll << bits) < (long long)nrow) ++bits;
+    FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, rows_dev, keys_out, idx_in, idx_out, (size_t)nnz, 0, bits, s));
+    FS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+    FS_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, rows_dev, keys_out, idx_in, idx_out, (size_t)nnz, 0, bits, s));
+    hipLaunchKernelGGL(permute_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_out, cols_dev, vals_dev,
+                       out.cols, out.vals);
+    FS_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((int64_t)nrow + 1)), dim3(256), 0, s, nrow, nnz, keys_out,
+                     out.row_ptr);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipStreamSynchronize(s));
+  if (tmp) FS_HIP(hipFree(tmp));
+  FS_HIP(hipFree(keys_out));
+  FS_HIP(hipFree(idx_in));
+  FS_HIP(hipFree(idx_out));
+  return build_schedule(out, s);
+}
+
+// ---- CSR -> CSR of the transpose -------------------------------------------------------------------
+// row id of every stored entry (one thread per entry, binary search in row_ptr)
+__global__ void expand_rows_kernel(int nrow, int64_t nnz, const int *__restrict__ row_ptr, int *__restrict__ rows)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  int lo = 0, hi = nrow;  // last r with row_ptr[r] <= i
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    if ((int64_t)row_ptr[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  rows[i] = lo;
+}
+
+int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
+{
+  int *rows = nullptr;
+  const size_t n = (size_t)(A.nnz > 0 ? A.nnz : 1);
+  FS_HIP(hipMalloc(&rows, sizeof(int) * n));
+  if (A.nnz > 0) {
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, A.row_ptr, rows);
+    FS_HIP(hipGetLastError());
+  }
+  // A' in COO is (cols, rows, vals); stable sort by column keeps the row order inside each column,
+  // i.e. the order in which the serial loops of At_mul_B (sparse.h:72-74) visit a column's entries
+  // when the COO itself is row ordered.
+  const int rc = coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows, A.vals, s);
+  (void)hipFree(rows);
+  return rc;
+}
+
+// ---- synthetic inputs (same arithmetic as oracle/fs_synth.c) -------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void synth_entry(uint64_t seed, int64_t grow, int slot, int ncol, int *c, double *v)
+{
+  const uint64_t h = splitmix64(seed ^ ((uint64_t)grow * 0x100000001B3ull + (uint64_t)slot));
+  *c = (int)__umul64hi(h, (uint64_t)ncol);
+  const uint64_t h2 = splitmix64(h ^ 0xABCDEF0123456789ull);
+  *v = (double)(h2 >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+__global__ void synth_uniform_kernel(int nrow, int ncol, int per_row, uint64_t seed, int64_t row_offset,
+                                     int *__restrict__ row_ptr, int *__restrict__ cols, double *__restrict__ vals)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nnz = (int64_t)nrow * per_row;
+  if (i <= nrow && row_ptr) row_ptr[i] = (int)(i * per_row);
+  if (i >= nnz) return;
+  const int64_t r = i / per_row;
+  const int slot = (int)(i - r * per_row);
+  int c; double v;
+  synth_entry(seed, row_offset + r, slot, ncol, &c, &v);
+  cols[i] = c;
+  if (vals) vals[i] = v;
+}
+
+__global__ void synth_lengths_kernel(int nrow, double scale, int max_len, uint64_t seed, int64_t row_offset,
+                                     int *__restrict__ len)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrow) return;
+  const uint64_t h = splitmix64(seed ^ (0xC0FFEEull + (uint64_t)(row_offset + r) * 0x9E3779B97F4A7C15ull));
+  const double u = (double)((h >> 11) + 1) * (1.0 / 9007199254740992.0);  // (0, 1]
+  double L = scale / u;
+  if (L > (double)max_len) L = (double)max_len;
+  int n = (int)L;
+  len[r] = n < 1 ? 1 : n;
+}
+
+__global__ void synth_fill_kernel(int nrow, int ncol, uint64_t seed, int64_t row_offset,
+                                  const int *__restrict__ row_ptr, int *__restrict__ cols, double *__restrict__ vals)
+{
+  // one wave per row, lanes stride over the row's slots
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= nrow) return;
+  const int a = row_ptr[w], b = row_ptr[w + 1];
+  for (int i = a + lane; i < b; i += 64) {
+    int c; double v;
+    synth_entry(seed, row_offset + w, i - a, ncol, &c, &v);
+    cols[i] = c;
+    if (vals) vals[i] = v;
+  }
+}
+
+}  // namespace fs
+
+extern "C" {
+
+int fs_synth_uniform(int nrow, int ncol, int per_row, uint64_t seed, int64_t row_offset, int *row_ptr_dev,
+                     int *cols_dev, double *vals_dev, fs_stream_t stream)
+{
+  if (nrow < 0 || ncol < 1 || per_row < 0 || !cols_dev) { fs::set_error("fs_synth_uniform: bad argument"); return FS_ERR_ARG; }
+  int64_t n = (int64_t)nrow * per_row;
+  if (n < (int64_t)nrow + 1) n = (int64_t)nrow + 1;
+  hipLaunchKernelGGL(fs::synth_uniform_kernel, dim3(fs::grid_for(n)), dim3(256), 0, (hipStream_t)stream, nrow, ncol,
+                     per_row, seed, row_offset, row_ptr_dev, cols_dev, vals_dev);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int fs_synth_powerlaw_lengths(int nrow, double scale, int max_len, uint64_t seed, int64_t row_offset, int *len_dev,
+                              fs_stream_t stream)
+{
+  if (nrow < 0 || !len_dev || max_len < 1) { fs::set_error("fs_synth_powerlaw_lengths: bad argument"); return FS_ERR_ARG; }
+  hipLaunchKernelGGL(fs::synth_lengths_kernel, dim3(fs::grid_for(nrow)), dim3(256), 0, (hipStream_t)stream, nrow,
+                     scale, max_len, seed, row_offset, len_dev);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int fs_synth_fill(int nrow, int ncol, uint64_t seed, int64_t row_offset, const int *row_ptr_dev, int *cols_dev,
+                  double *vals_dev, fs_stream_t stream)
+{
+  if (nrow < 0 || ncol < 1 || !row_ptr_dev || !cols_dev) { fs::set_error("fs_synth_fill: bad argument"); return FS_ERR_ARG; }
+  hipLaunchKernelGGL(fs::synth_fill_kernel, dim3(fs::grid_for((int64_t)nrow * 64)), dim3(256), 0, (hipStream_t)stream,
+                     nrow, ncol, seed, row_offset, row_ptr_dev, cols_dev, vals_dev);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,380 @@
+// fs_kernels.hip -- hand-written gfx950 kernels of the A_mul_B / At_mul_B path.
+//
+// Compiled with -ffp-contract=off: a valued term is one rounded multiply followed by one
+// rounded add, exactly what the strict-IEEE reference loop `tmp += x[cols[i]] * vals[i]`
+// (csr.h:434, dsparse.h:49) computes, so that every kernel that adds a row's terms in
+// storage order is bit-identical to the CPU order.  All kernels are HBM/gather bound
+// (0.17 flop/B), the spare multiply issue slot costs nothing.
+//
+// Kernels
+//   spmv_stream_kernel   y = A x, CSR or pattern-only CSR.  One 256-thread workgroup streams a
+//                        fixed 2048-non-zero chunk of cols/vals with 16-byte loads, gathers x,
+//                        parks the products in LDS and reduces them per row.  Work per
+//                        workgroup is independent of the row-length distribution.
+//   spmv_fixup_kernel    adds up the partial sums of rows that cross chunk boundaries
+//   spmv_vector_kernel   classic G-lanes-per-row CSR kernel (A/B alternative, option spmv_kernel=2)
+//   spmm_kernel          Y = A X, k row-major right-hand sides, one lane per output column
+//   cbcsr_kernel         column-blocked binary CSR, x tile staged in LDS per column block
+#include "fs_common.h"
+
+namespace fs {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// LDS slot of the i-th product of a chunk: one pad slot per 16 products makes the stride
+// between consecutive 16-entry rows odd (17), so a thread-per-row sweep is conflict free.
+__device__ __forceinline__ int lds_slot(int i) { return i + (i >> 4); }
+constexpr int kLdsDoubles = kChunk + (kChunk >> 4) + 8;
+
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// ------------------------------------------------------------------------------------------
+// y = A x, chunk-streaming kernel.
+//   replaces csr_A_mul_B (csr.h:425-438), bcsr_A_mul_B (csr.h:149-161) and, through the
+//   device CSR built at upload, A_mul_B / At_mul_B (sparse.h:58-75), sdm_A_mul_B /
+//   sdm_At_mul_B (dsparse.h:43-62), bsbm_A_mul_B (sparse.h:259-273), bsdm_A_mul_B
+//   (dsparse.h:176-191).
+// Chunk c owns non-zeros [c*kChunk, min((c+1)*kChunk, nnz)) and finishes the rows whose first
+// non-zero is in that range, rows [first_row[c], first_row[c+1]).  Non-zeros in front of
+// row_ptr[first_row[c]] belong to a row that began in an earlier chunk: their sum goes to
+// head[c].  If the last row runs past the chunk its partial sum goes to tail[c]; the fix-up
+// kernel combines tail[c] + head[c+1] + ... left to right.
+// Row sums: with G == 1 (chosen when the chunk holds >= 64 rows, or always under
+// strict_order) one thread adds a row's products in storage order.  Chunks with few, long rows
+// use G = 2..64 lanes per row and a butterfly reduction.
+// ------------------------------------------------------------------------------------------
+// phase 1 of the streaming kernel for one thread: 8 non-zeros as two groups of 4 consecutive
+// entries.  FULL (every chunk but possibly the last) is straight-line code: six 16-byte
+// streaming loads, then eight independent 8-byte gathers of x, all in flight together.
+template <bool VALUED, bool NT, bool FULL>
+__device__ __forceinline__ void stream_products(double *__restrict__ prod, const int *__restrict__ cols,
+                                                const double *__restrict__ vals, const double *__restrict__ x,
+                                                int64_t s, int64_t e, int t)
+{
+  int ci[kPerThread];
+  double vv[kPerThread];
+#pragma unroll
+  for (int j = 0; j < kPerThread / 4; ++j) {
+    const int l = 4 * (j * kBlock + t);
+    const int64_t g = s + l;
+    if (FULL) {
+      const v4i cc = stream_load<NT>(reinterpret_cast<const v4i *>(cols + g));
+      ci[4 * j + 0] = cc.x; ci[4 * j + 1] = cc.y; ci[4 * j + 2] = cc.z; ci[4 * j + 3] = cc.w;
+      if (VALUED) {
+        const v2d a = stream_load<NT>(reinterpret_cast<const v2d *>(vals + g));
+        const v2d b = stream_load<NT>(reinterpret_cast<const v2d *>(vals + g + 2));
+        vv[4 * j + 0] = a.x; vv[4 * j + 1] = a.y; vv[4 * j + 2] = b.x; vv[4 * j + 3] = b.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool in = g + q < e;
+        ci[4 * j + q] = in ? cols[g + q] : -1;
+        if (VALUED) vv[4 * j + q] = in ? vals[g + q] : 0.0;
+      }
+    }
+  }
+  double p[kPerThread];
+#pragma unroll
+  for (int i = 0; i < kPerThread; ++i) p[i] = (FULL || ci[i] >= 0) ? x[ci[i]] : 0.0;
+#pragma unroll
+  for (int j = 0; j < kPerThread / 4; ++j) {
+    const int l = 4 * (j * kBlock + t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * j + q;
+      prod[lds_slot(l + q)] = VALUED ? p[i] * vv[i] : p[i];
+    }
+  }
+}
+
+template <bool VALUED, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+    int nrow, int64_t nnz, const int *__restrict__ row_ptr, const int *__restrict__ cols,
+    const double *__restrict__ vals, const int *__restrict__ first_row, const double *__restrict__ x,
+    double *__restrict__ y, double *__restrict__ head, double *__restrict__ tail, int strict)
+{
+  __shared__ double prod[kLdsDoubles];
+  const int t = threadIdx.x;
+  const int c = blockIdx.x;
+  const int64_t s = (int64_t)c * kChunk;
+  const bool full = s + kChunk <= nnz;
+  const int64_t e = full ? s + kChunk : nnz;
+
+  // row bookkeeping first: these loads do not depend on phase 1 and overlap with it.
+  // Virtual row vr: vr == 0 is the head (non-zeros [s, row_ptr[r_begin]) of a row that began
+  // earlier), vr >= 1 is row r_begin + vr - 1.  Its non-zeros are [A(vr), B(vr)) with
+  // A(0) = s, A(vr) = row_ptr[r_begin + vr - 1], B(vr) = row_ptr[r_begin + vr].
+  const int r_begin = first_row[c];
+  const int r_end = first_row[c + 1];
+  const int nv = r_end - r_begin + 1;
+  int lg = 0;  // log2(lanes per row)
+  if (!strict && nv < 64) {
+    lg = 31 - __clz(kBlock / nv);  // floor(log2(256 / nv)) in [2, 8]
+    if (lg > 6) lg = 6;
+  }
+  const int G = 1 << lg;
+  const int groups = kBlock >> lg;
+  const int gid = t >> lg;
+  const int gl = t & (G - 1);
+  const int s32 = (int)s, e32 = (int)e;  // nnz <= INT_MAX because row_ptr is int
+  // unconditional (index-clamped) loads: no branch, so no wait is forced in front of phase 1
+  const int vg = gid < nv ? gid : nv - 1;
+  const int la = row_ptr[r_begin + (vg > 0 ? vg - 1 : 0)];
+  int pb = row_ptr[r_begin + vg];
+  int pa = gid == 0 ? s32 : la;
+
+  // ---- phase 1: stream cols/vals, gather x, park the products in LDS ------------------------
+  if (full) stream_products<VALUED, NT, true>(prod, cols, vals, x, s, e, t);
+  else      stream_products<VALUED, NT, false>(prod, cols, vals, x, s, e, t);
+  __syncthreads();
+
+  // ---- phase 2: per-row sums out of LDS -----------------------------------------------------
+  for (int vr = gid; vr < nv; vr += groups) {
+    if (vr != gid) {
+      pa = row_ptr[r_begin + vr - 1];
+      pb = row_ptr[r_begin + vr];
+    }
+    const bool cont = pb > e32;
+    const int lo = pa - s32;
+    const int hi = (cont ? e32 : pb) - s32;
+    double acc = 0.0;
+    int i = lo + gl;
+    for (; i + 7 * G < hi; i += 8 * G) {
+      double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = prod[lds_slot(i + u * G)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += w[u];
+    }
+    for (; i < hi; i += G) acc += prod[lds_slot(i)];
+    for (int m = G >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (gl == 0) {
+      if (vr == 0) head[c] = acc;
+      else if (cont) tail[c] = acc;
+      else y[r_begin + vr - 1] = acc;
+    }
+  }
+}
+
+// rows that cross chunk boundaries: y[r] = tail[c] + head[c+1] + ... + head[last chunk of r]
+__global__ void spmv_fixup_kernel(int nchunks, int64_t nnz, const int *__restrict__ row_ptr,
+                                  const int *__restrict__ first_row, const double *__restrict__ head,
+                                  const double *__restrict__ tail, double *__restrict__ y)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const int r0 = first_row[c], r1 = first_row[c + 1];
+  if (r1 <= r0) return;
+  const int r = r1 - 1;
+  const int64_t b = row_ptr[r + 1];
+  int64_t e = (int64_t)(c + 1) * kChunk;
+  if (e > nnz) e = nnz;
+  if (b <= e) return;
+  double acc = tail[c];
+  const int last = (int)((b - 1) / kChunk);
+  for (int cc = c + 1; cc <= last; ++cc) acc += head[cc];
+  y[r] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// G-lanes-per-row CSR kernel (A/B alternative; also the simplest correct baseline).
+// ------------------------------------------------------------------------------------------
+template <bool VALUED>
+__global__ __launch_bounds__(kBlock) void spmv_vector_kernel(int nrow, int lg, const int *__restrict__ row_ptr,
+                                                            const int *__restrict__ cols,
+                                                            const double *__restrict__ vals,
+                                                            const double *__restrict__ x, double *__restrict__ y)
+{
+  const int G = 1 << lg;
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> lg;
+  const int gl = threadIdx.x & (G - 1);
+  if (row >= nrow) return;
+  const int a = row_ptr[row], b = row_ptr[row + 1];
+  double acc = 0.0;
+  for (int i = a + gl; i < b; i += G) {
+    const double xv = x[cols[i]];
+    acc += VALUED ? xv * vals[i] : xv;
+  }
+  for (int m = G >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+  if (gl == 0) y[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Y = A X with k row-major right-hand sides.
+//   replaces csr_A_mul_Bn (csr.h:441-465), bcsr_A_mul_B2/_B4/_B8/_B8_auto/_Bn/_B32n
+//   (csr.h:164-302), bsbm_A_mul_B2/_B4/_Bn (sparse.h:276-336).
+// A group of KP = 2^lg lanes (KP >= min(k,64)) owns one row; lane j owns output column j and
+// adds the row's terms in storage order (bit-identical to the CPU loops).  The group fetches
+// KP (col,val) pairs with one coalesced load and broadcasts them with shuffles; each term is a
+// contiguous 8k-byte read of X row cols[i] -- the whole group reads one X row per step.
+// ------------------------------------------------------------------------------------------
+template <bool VALUED>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(int nrow, int k, int lg, const int *__restrict__ row_ptr,
+                                                     const int *__restrict__ cols,
+                                                     const double *__restrict__ vals,
+                                                     const double *__restrict__ X, double *__restrict__ Y)
+{
+  const int KP = 1 << lg;
+  const int gpb = kBlock >> lg;
+  const int j = threadIdx.x & (KP - 1);
+  const int64_t row = (int64_t)blockIdx.x * gpb + (threadIdx.x >> lg);
+  if (row >= nrow) return;
+  const int a = row_ptr[row], b = row_ptr[row + 1];
+  for (int j0 = 0; j0 < k; j0 += KP) {
+    const int col = j0 + j;
+    const bool act = col < k;
+    double acc = 0.0;
+    for (int base = a; base < b; base += KP) {
+      int myc = 0;
+      double myv = 0.0;
+      if (base + j < b) {
+        myc = cols[base + j];
+        if (VALUED) myv = vals[base + j];
+      }
+      const int n = (b - base < KP) ? b - base : KP;
+      for (int i0 = 0; i0 < n; i0 += 8) {
+        double xv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u;
+          const int cc = __shfl(myc, i & (KP - 1), KP);
+          if (VALUED) wv[u] = __shfl(myv, i & (KP - 1), KP);
+          xv[u] = (act && i < n) ? X[(int64_t)cc * k + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < n) acc += VALUED ? xv[u] * wv[u] : xv[u];
+      }
+    }
+    if (act) Y[row * k + col] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Column-blocked binary CSR (cbcsr_A_mul_B, cbcsr.h:76-106): cell = block*nrow + row.
+// One thread per row; the workgroup walks the column blocks in order, so every row adds its
+// cell sums block by block (the order one CPU thread produces).  With STAGE the x tile of the
+// current column block is first copied to LDS (coalesced) and gathers hit LDS instead of L2.
+// ------------------------------------------------------------------------------------------
+constexpr int kCbTile = 8192;  // doubles of x staged per column block (64 KiB)
+
+template <bool STAGE>
+__global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int nblocks, int cbs,
+                                                      const int *__restrict__ row_ptr,
+                                                      const int *__restrict__ cols,
+                                                      const double *__restrict__ x, double *__restrict__ y)
+{
+  __shared__ double xt[STAGE ? kCbTile : 1];
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  double tot = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int c0 = b * cbs;
+    if (STAGE) {
+      const int w = (ncol - c0 < cbs) ? ncol - c0 : cbs;
+      __syncthreads();
+      for (int i = threadIdx.x; i < w; i += kBlock) xt[i] = x[c0 + i];
+      __syncthreads();
+    }
+    if (r < nrow) {
+      const int64_t cell = (int64_t)b * nrow + r;
+      const int lo = row_ptr[cell], hi = row_ptr[cell + 1];
+      double s = 0.0;
+      for (int i = lo; i < hi; ++i) s += STAGE ? xt[cols[i] - c0] : x[cols[i]];
+      tot += s;
+    }
+  }
+  if (r < nrow) y[r] = 0.0 + tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int ceil_log2(int v)
+{
+  int lg = 0;
+  while ((1 << lg) < v) ++lg;
+  return lg;
+}
+
+int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
+{
+  if (A.nrow == 0) return FS_OK;
+  const Options &o = options();
+  const bool valued = A.vals != nullptr;
+  if (o.spmv_kernel == 2) {
+    const double avg = A.nrow ? (double)A.nnz / A.nrow : 0.0;
+    int lg = o.strict_order ? 0 : ceil_log2((int)(avg < 1 ? 1 : (avg > 64 ? 64 : avg)));
+    if (lg > 6) lg = 6;
+    const int64_t threads = (int64_t)A.nrow << lg;
+    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
+    if (valued)
+      hipLaunchKernelGGL(spmv_vector_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, lg, A.row_ptr, A.cols,
+                         A.vals, x, y);
+    else
+      hipLaunchKernelGGL(spmv_vector_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, lg, A.row_ptr, A.cols,
+                         A.vals, x, y);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+  }
+  const bool nt = o.spmv_kernel != 3;  // 3 = streaming kernel with plain (cached) loads, for A/B runs
+  const dim3 grid(A.nchunks), block(kBlock);
+#define FS_LAUNCH_STREAM(V, N)                                                                              \
+  hipLaunchKernelGGL((spmv_stream_kernel<V, N>), grid, block, 0, s, A.nrow, A.nnz, A.row_ptr, A.cols, A.vals, \
+                     A.first_row, x, y, A.head, A.tail, o.strict_order)
+  if (valued) { if (nt) FS_LAUNCH_STREAM(true, true); else FS_LAUNCH_STREAM(true, false); }
+  else        { if (nt) FS_LAUNCH_STREAM(false, true); else FS_LAUNCH_STREAM(false, false); }
+#undef FS_LAUNCH_STREAM
+  FS_HIP(hipGetLastError());
+  if (A.spanning > 0) {
+    hipLaunchKernelGGL(spmv_fixup_kernel, dim3((A.nchunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, A.nchunks,
+                       A.nnz, A.row_ptr, A.first_row, A.head, A.tail, y);
+    FS_HIP(hipGetLastError());
+  }
+  return FS_OK;
+}
+
+int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
+{
+  if (A.nrow == 0) return FS_OK;
+  int lg = ceil_log2(k > 64 ? 64 : k);
+  const int gpb = kBlock >> lg;
+  const unsigned grid = (unsigned)(((int64_t)A.nrow + gpb - 1) / gpb);
+  if (A.vals)
+    hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, k, lg, A.row_ptr, A.cols, A.vals, X,
+                       Y);
+  else
+    hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, k, lg, A.row_ptr, A.cols, A.vals, X,
+                       Y);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
+{
+  if (A.nrow == 0) return FS_OK;
+  const unsigned grid = (unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock);
+  // stage the x tile in LDS when it fits and a workgroup's cells of one block hold enough
+  // entries to amortise the copy (one tile read per workgroup per block)
+  const double per_wg_block = A.nblocks ? (double)A.nnz / A.nblocks / grid : 0.0;
+  const int forced = options().spmv_kernel;  // 4 = always stage (if it fits), 5 = never
+  bool stage = A.colblocksize <= kCbTile && per_wg_block * 4 >= A.colblocksize;
+  if (forced == 4) stage = A.colblocksize <= kCbTile;
+  if (forced == 5) stage = false;
+  if (stage)
+    hipLaunchKernelGGL(cbcsr_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.ncol, A.nblocks, A.colblocksize,
+                       A.row_ptr, A.cols, x, y);
+  else
+    hipLaunchKernelGGL(cbcsr_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.ncol, A.nblocks, A.colblocksize,
+                       A.row_ptr, A.cols, x, y);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+}  // namespace fs

@@ -21,8 +21,8 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile liboracle.so with gcc (strict IEEE flags, see oracle/Makefile)."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "fs_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("fs_oracle.c", "fs_synth.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 

