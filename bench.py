@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 CSR SpMV (A_mul_B + At_mul_B) on BASELINE.json config 2, one rank per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload: per GPU a CSR shard of 10 000 000 rows x 16 non-zeros, columns uniform over
+the global column range, values uniform(-1,1), generated on the device by the counter-based generator
+(seed 0x5EED0002, identical on CPU).  N = 1 is exactly config 2 (10M x 10M).  N > 1 is the weak-scaling
+form of config 5's scheme: the global matrix is (N*10M) x (N*10M), rank r owns rows [r*10M, (r+1)*10M) of A
+and of A' (the latter built once by an all-to-all of the entries), x is replicated, and each product is a
+local SpMV followed by an RCCL all-gather of the y shards.
+
+One step = y = A x  then  z = A' u  (two launches of the streaming SpMV kernel per rank, plus the two
+all-gathers when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
+Algorithmic bytes per product: 12*nnz + 4*(nrow+1) + 8*nrow + 8*ncol.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = spmv_stream_kernel, HIP-event timed
+inside the timed region) and, at N = 1, `cpu_baseline` (the oracle's OpenMP restatement of csr_A_mul_B,
+built with the reference's flags, timed on this box's host cores on the same matrix).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+SEED = 0x5EED0002
+METRIC = "fp64 CSR SpMV effective GB/s (% HBM3E peak)"
+
+
+def cpu_baseline(rows, ncol, per_row, reps=10):
+    """csr_A_mul_B restated (oracle/fs_oracle.c: fso_csr_mul, omp parallel for schedule(dynamic,256) as csr.h:429),
+    built here with the reference's flags (-O3 -march=native -fopenmp -ffast-math), on the same config-2 matrix."""
+    import numpy as np
+    from oracle import pyoracle, pysynth
+    out = os.path.join("/tmp", "liboracle_fast_%d.so" % os.getpid())
+    fast = pyoracle.load(pyoracle.build_fast(out))
+    rp, cc, vv = pysynth.uniform(rows, ncol, per_row, SEED)
+    x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
+    y = np.empty(rows)
+    vp = vv.ctypes.data
+    fast.fso_csr_mul(y, rows, rp, cc, vp, x)          # warm-up (bench_a_mul_b.c does one untimed call)
+    t0 = time.time()
+    for _ in range(reps):
+        fast.fso_csr_mul(y, rows, rp, cc, vp, x)
+    dt = (time.time() - t0) / reps
+    nbytes = 12 * rows * per_row + 4 * (rows + 1) + 8 * rows + 8 * ncol
+    strict = pyoracle.load()
+    os.remove(out)
+    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": int(strict.fso_threads()), "kind": "port",
+            "ms_per_product": dt * 1e3,
+            "sample": "csr_A_mul_B on the full config-2 matrix (%d x %d, %d nnz/row), 1 warm-up + mean of %d "
+                      "repeats, OpenMP schedule(dynamic,256), gcc -O3 -march=native -ffast-math" % (rows, ncol, per_row, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (config 2: 10M)")
+    ap.add_argument("--per-row", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from libfastsparse_amd import capi
+    from libfastsparse_amd import dist as fsd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    capi.lib()
+
+    n_local, per = args.rows, args.per_row
+    n_global = n_local * world
+    lo = rank * n_local
+    st = capi.current_stream()
+
+    # ---- this rank's shard of A (rows lo .. lo+n_local, global columns) -----------------------------
+    rp, cc, vv = capi.synth_uniform(n_local, n_global, per, SEED, row_offset=lo)
+    A = capi.Matrix.from_csr(n_local, n_global, rp, cc, vv, borrow=True)
+    bounds = fsd.even_row_partition(n_global, world)
+    if world == 1:
+        A.build_transpose(st)
+        At = None
+        t_spmv = lambda y, x: A.spmv(y, x, capi.current_stream(), transposed=True)   # noqa: E731
+        bytes_t = A.algorithmic_bytes()
+    else:
+        rows_g = torch.arange(lo, lo + n_local, device=dev, dtype=torch.int32).repeat_interleave(per)
+        tr, tc, tv = fsd.exchange_transpose_entries(rows_g, cc, vv, bounds)
+        del rows_g
+        At = capi.Matrix.from_coo(n_local, n_global, tr.to(torch.int32), tc, tv)
+        del tr, tc, tv
+        t_spmv = fsd.hip_local_spmv(At)
+        bytes_t = At.algorithmic_bytes()
+    bytes_a = A.algorithmic_bytes()
+    op_a = fsd.ShardedOperator(fsd.hip_local_spmv(A), bounds)
+    op_t = fsd.ShardedOperator(t_spmv, bounds)
+
+    i = torch.arange(n_global, device=dev, dtype=torch.float64)
+    x = torch.sin(7.0 * i + 0.3)           # bench_a_mul_b.c:142
+    u = torch.sin(11.0 * i - 0.2)          # second column of X2col, bench_a_mul_b.c:145
+    del i
+    y = torch.empty(n_global, dtype=torch.float64, device=dev)
+    z = torch.empty(n_global, dtype=torch.float64, device=dev)
+
+    def step(events=None):
+        if events is not None:
+            events[0].record()
+        op_a.apply(y, x)
+        if events is not None:
+            events[1].record()
+        op_t.apply(z, u)
+        if events is not None:
+            events[2].record()
+
+    def local_only(events):
+        """kernel-only timing of the two local products (no collective), for the roofline object"""
+        yl, zl = y[:n_local], z[:n_local]
+        events[0].record()
+        op_a.apply_local(yl, x)
+        events[1].record()
+        op_t.apply_local(zl, u)
+        events[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch durations of the dominant kernel inside the timed region (HIP events on the launch stream).
+    # With N > 1 the interval e0->e1 also holds the all-gather, so the kernel-only figure is re-measured below.
+    ka = [e[0].elapsed_time(e[1]) for e in evs]
+    kt = [e[1].elapsed_time(e[2]) for e in evs]
+    if world > 1:
+        evs2 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        for k in range(args.steps):
+            local_only(evs2[k])
+        torch.cuda.synchronize()
+        ka = [e[0].elapsed_time(e[1]) for e in evs2]
+        kt = [e[1].elapsed_time(e[2]) for e in evs2]
+    launches = 2 * args.steps
+    avg_ms = (sum(ka) + sum(kt)) / launches
+    bytes_per_launch = (bytes_a + bytes_t) / 2.0
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+
+    total_bytes = float(world) * (bytes_a + bytes_t) * args.steps
+    value = total_bytes / elapsed / 1e9
+
+    if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_stream.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("rows") == n_local and tj.get("per_row") == per and world == 1:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B"
+                                   % (n_global, n_global, per) if world == 1 else
+                                   "config-2 shards, weak scaling: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
+                                   "(A_mul_B + all-gather y) + (At_mul_B + all-gather z)" % (n_global, n_global, n_local, per),
+                       "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
+                       "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
+                       "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt)},
+            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel<valued,nt>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                         "launches_timed": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                rec["cpu_baseline"] = cpu_baseline(n_local, n_global, per)
+            except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
+                rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -183,6 +183,32 @@ __global__ void spmv_fixup_kernel(int nchunks, int64_t nnz, const int *__restric
   y[r] = acc;
 }
 
+// strict_order variant: a row that crosses chunks must still be ONE left-to-right sum, so the
+// thread continues the running sum tail[c] with the remaining terms themselves (recomputed from
+// global memory) instead of adding the later chunks' partial sums.
+template <bool VALUED>
+__global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__restrict__ row_ptr,
+                                         const int *__restrict__ first_row, const int *__restrict__ cols,
+                                         const double *__restrict__ vals, const double *__restrict__ x,
+                                         const double *__restrict__ tail, double *__restrict__ y)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const int r0 = first_row[c], r1 = first_row[c + 1];
+  if (r1 <= r0) return;
+  const int r = r1 - 1;
+  const int64_t b = row_ptr[r + 1];
+  int64_t e = (int64_t)(c + 1) * kChunk;
+  if (e > nnz) e = nnz;
+  if (b <= e) return;
+  double acc = tail[c];
+  for (int64_t i = e; i < b; ++i) {
+    const double xv = x[cols[i]];
+    acc += VALUED ? xv * vals[i] : xv;
+  }
+  y[r] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // G-lanes-per-row CSR kernel (A/B alternative; also the simplest correct baseline).
 // ------------------------------------------------------------------------------------------
@@ -332,7 +358,16 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
   else        { if (nt) FS_LAUNCH_STREAM(false, true); else FS_LAUNCH_STREAM(false, false); }
 #undef FS_LAUNCH_STREAM
   FS_HIP(hipGetLastError());
-  if (A.spanning > 0) {
+  if (A.spanning > 0 && o.strict_order) {
+    const dim3 fg((A.nchunks + kBlock - 1) / kBlock), fb(kBlock);
+    if (valued)
+      hipLaunchKernelGGL(spmv_fixup_strict_kernel<true>, fg, fb, 0, s, A.nchunks, A.nnz, A.row_ptr, A.first_row,
+                         A.cols, A.vals, x, A.tail, y);
+    else
+      hipLaunchKernelGGL(spmv_fixup_strict_kernel<false>, fg, fb, 0, s, A.nchunks, A.nnz, A.row_ptr, A.first_row,
+                         A.cols, A.vals, x, A.tail, y);
+    FS_HIP(hipGetLastError());
+  } else if (A.spanning > 0) {
     hipLaunchKernelGGL(spmv_fixup_kernel, dim3((A.nchunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, A.nchunks,
                        A.nnz, A.row_ptr, A.first_row, A.head, A.tail, y);
     FS_HIP(hipGetLastError());

@@ -1,0 +1,134 @@
+"""Row-sharded products across the GPUs of one node: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The path shards by rows: y[r] depends on row r only, so each rank owns a contiguous
+row range of A as an ordinary CSR with local row_ptr and GLOBAL column ids, x is replicated, and the
+one real exchange step is the all-gather of the y shards.  The transposed product uses the same
+scheme on a row shard of A' (= the columns of A this rank owns), built once by an all-to-all of the
+entries (`exchange_transpose_entries`), so both directions are "local SpMV + all-gather".
+
+Nothing here computes: `local_spmv(y_local, x_full)` is injected -- the HIP C-ABI in the product
+(`hip_local_spmv`), the oracle in the gloo tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def even_row_partition(nrow, world):
+    """contiguous row ranges of (almost) equal size: bounds[r] .. bounds[r+1]"""
+    base, rem = divmod(nrow, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + base + (1 if r < rem else 0))
+    return bounds
+
+
+def nnz_balanced_partition(row_ptr, world):
+    """contiguous row ranges holding (almost) equal numbers of non-zeros -- what a power-law matrix
+    (BASELINE config 5) needs; row_ptr is the global CSR row pointer (any integer tensor / array)."""
+    rp = torch.as_tensor(row_ptr).to(torch.int64).cpu()
+    nrow = rp.numel() - 1
+    nnz = int(rp[-1])
+    targets = torch.tensor([nnz * r // world for r in range(1, world)], dtype=torch.int64)
+    cuts = torch.searchsorted(rp, targets, right=False).clamp_(0, nrow)
+    bounds = [0] + [int(c) for c in cuts] + [nrow]
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+class ShardedOperator:
+    """y = A x with rows [bounds[rank], bounds[rank+1]) of A on this rank.
+
+    apply(y_full, x_full): local product into this rank's slice, then all-gather of the slices.
+    Unequal shards are gathered through a padded buffer (RCCL's all-gather wants equal counts).
+    """
+
+    def __init__(self, local_spmv, bounds, group=None):
+        self.local_spmv = local_spmv
+        self.bounds = list(bounds)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(self.bounds) == self.world + 1
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        self.sizes = sizes
+        self.equal = len(set(sizes)) == 1
+        self.max_rows = max(sizes)
+        self._pad = None
+        self._y_local = None
+
+    @property
+    def nrow(self):
+        return self.bounds[-1]
+
+    def _buffers(self, like):
+        if self._y_local is None or self._y_local.device != like.device:
+            self._y_local = torch.empty(self.max_rows, dtype=like.dtype, device=like.device)
+            if not self.equal:
+                self._pad = torch.empty(self.max_rows * self.world, dtype=like.dtype, device=like.device)
+        return self._y_local
+
+    def apply_local(self, y_local, x_full):
+        self.local_spmv(y_local, x_full)
+
+    def apply(self, y_full, x_full):
+        n_local = self.hi - self.lo
+        if self.world == 1:
+            self.local_spmv(y_full, x_full)
+            return y_full
+        y_local = self._buffers(y_full)
+        self.local_spmv(y_local[:n_local], x_full)
+        if self.equal:
+            dist.all_gather_into_tensor(y_full, y_local[:n_local], group=self.group)
+        else:
+            dist.all_gather_into_tensor(self._pad, y_local, group=self.group)
+            for r in range(self.world):
+                y_full[self.bounds[r]:self.bounds[r + 1]] = \
+                    self._pad[r * self.max_rows: r * self.max_rows + self.sizes[r]]
+        return y_full
+
+
+def exchange_transpose_entries(rows_global, cols_global, vals, col_bounds, group=None):
+    """One-time build of this rank's row shard of A'.
+
+    Each rank holds some entries (row, col, val) of A with GLOBAL ids.  Entry (r, c, v) of A is entry
+    (c, r, v) of A'; it goes to the rank that owns row c of A' (col_bounds = row partition of A').
+    Returns (rows_of_At_local, cols_of_At_global, vals) for this rank, ordered by (source rank, source
+    order): since the source ranks hold ascending row ranges of A, every row of A' receives its entries
+    in ascending A-row order -- the order a stable column sort of the whole A would give.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bounds_t = torch.tensor(col_bounds[1:-1], dtype=cols_global.dtype, device=cols_global.device)
+    dest = torch.bucketize(cols_global, bounds_t, right=True)
+    order = torch.sort(dest, stable=True).indices
+    send_counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    lo = col_bounds[rank]
+    if world == 1:
+        return (cols_global[order] - lo), rows_global[order], (None if vals is None else vals[order])
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    s_split = [int(v) for v in send_counts.cpu()]
+    r_split = [int(v) for v in recv_counts.cpu()]
+    n_recv = sum(r_split)
+
+    def xchg(t):
+        out = torch.empty(n_recv, dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(out, t[order].contiguous(), r_split, s_split, group=group)
+        return out
+
+    at_rows = xchg(cols_global) - lo
+    at_cols = xchg(rows_global)
+    at_vals = None if vals is None else xchg(vals)
+    return at_rows, at_cols, at_vals
+
+
+def hip_local_spmv(matrix, stream_fn=None):
+    """local_spmv backed by the HIP C-ABI (fs_spmv on the current torch stream)"""
+    from . import capi
+
+    def f(y_local, x_full):
+        matrix.spmv(y_local, x_full, stream_fn() if stream_fn else capi.current_stream())
+    return f

@@ -30,20 +30,20 @@ def hip():
     return H
 
 
-def _scale(case, key):
-    """row-scaled error unit sum|a||x| for output `key` (inf-norm fallback for transposed/AA products)"""
-    return None
+VALUED = ("sdm_A_mul_B", "sdm_At_mul_B", "csr_A_mul_B", "csr_A_mul_Bn", "bsdm_A_mul_B")
 
 
 def _check(out, gold, name, exact):
+    """exact: every output bit for bit.  Otherwise: pattern-only products of integer-valued x bit for bit
+    (order-independent), everything else within TOL * max(1, |y|_inf) (a looser form of the
+    row-scaled bound only for rows whose terms cancel; the row-scaled form is used at full size)."""
     for k, v in out.items():
-        g = gold[k.replace("/", "|")] if not isinstance(gold, dict) else gold[k]
+        g = gold[k.replace("/", "|")]
         assert v.shape == g.shape, (name, k)
-        if exact or k.endswith("/int"):
-            assert np.array_equal(v.view(np.int64), g.view(np.int64)), f"{name}:{k} not bit-exact (max diff {np.max(np.abs(v - g))})"
+        if exact or (k.endswith("/int") and k.split("/")[0] not in VALUED):
+            assert np.array_equal(v.view(np.int64), g.view(np.int64)), \
+                f"{name}:{k} not bit-exact (max diff {np.max(np.abs(v - g))})"
         else:
-            # conservative scale: TOL * max(1, |y|_inf * ...) is looser than the row-scaled bound only by
-            # row_nnz; use the per-output sum|terms| bound = nnz_row * max|x| <= ||.||: keep it simple and tight:
             bound = TOL * max(1.0, float(np.max(np.abs(g))))
             assert np.max(np.abs(v - g)) <= bound, f"{name}:{k} off by {np.max(np.abs(v - g))} > {bound}"
 
@@ -80,7 +80,8 @@ def test_reference_kats(hip, backend):
 
 @pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_kernel_variants_agree(hip, kernel):
-    """streaming kernel (nt / cached loads) and the lanes-per-row kernel give the same integer-x bits"""
+    """streaming kernel (nt / cached loads) and the lanes-per-row kernel: same bits for the pattern-only
+    matrix with integer x, 1e-12 for the valued one"""
     from libfastsparse_amd import capi
     capi.set_option("spmv_kernel", kernel)
     try:
@@ -88,11 +89,12 @@ def test_kernel_variants_agree(hip, kernel):
         for name in ("syn_u16_2048", "syn_long_800x5000", "syn_empty_1500x900"):
             c = BY_NAME[name]
             gold = np.load(os.path.join(S.GOLDEN, name + ".npz"))
-            y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs["int"])
-            assert np.array_equal(y, gold["csr_A_mul_B|int"])
-            y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs["bench"])
-            g = gold["csr_A_mul_B|bench"]
-            assert np.max(np.abs(y - g)) <= TOL * max(1.0, np.max(np.abs(g)))
+            y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, None, c.xs["int"])
+            assert np.array_equal(y, gold["bcsr_A_mul_B|int"])
+            for tag in ("int", "bench"):
+                y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs[tag])
+                g = gold["csr_A_mul_B|" + tag]
+                assert np.max(np.abs(y - g)) <= TOL * max(1.0, np.max(np.abs(g)))
     finally:
         capi.set_option("spmv_kernel", 0)
 
@@ -111,7 +113,7 @@ def test_csr_transposed_product(hip, backend):
                 rows_sorted = np.repeat(np.arange(c.nrow, dtype=np.int32), np.diff(rp))
                 ref = O.coo_tmul(c.ncol, rows_sorted, cc, vv, xt)
                 y = be.transposed_csr_mul(c.nrow, c.ncol, c.rows, c.cols, vals, xt)
-                if tag == "int":
+                if tag == "int" and vals is None:
                     assert np.array_equal(y, ref), (name, tag)
                 else:
                     assert np.max(np.abs(y - ref)) <= TOL * max(1.0, np.max(np.abs(ref))), (name, tag)
@@ -146,7 +148,11 @@ def test_edge_shapes(hip):
     for k in (1, 3, 7, 33, 70):
         X = S.X_sin(c.ncol, k)
         Y = be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, c.vals, X, k, "csr_A_mul_Bn")
-        assert np.array_equal(Y, O.csr_mul_n(c.nrow, rp, cc, vv, X, k)), k
+        ref = O.csr_mul_n(c.nrow, rp, cc, vv, X, k)
+        if k == 1:   # k = 1 is the SpMV kernel: rows that cross a chunk are sums of partial sums
+            assert np.max(np.abs(Y - ref)) <= TOL * max(1.0, np.max(np.abs(ref)))
+        else:        # the multi-column kernel adds every row's terms in storage order
+            assert np.array_equal(Y, ref), k
 
 
 def test_y_is_overwritten(hip):
