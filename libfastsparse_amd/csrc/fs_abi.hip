@@ -60,6 +60,9 @@ int fs_set_option(const char *name, int value)
   if (!name) { set_error("fs_set_option: NULL name"); return FS_ERR_ARG; }
   if (!strcmp(name, "strict_order")) { fs::options().strict_order = value; return FS_OK; }
   if (!strcmp(name, "spmv_kernel")) { fs::options().spmv_kernel = value; return FS_OK; }
+  if (!strcmp(name, "tiling")) { fs::options().tiling = value; return FS_OK; }
+  if (!strcmp(name, "tile_rows")) { fs::options().tile_rows = value; return FS_OK; }
+  if (!strcmp(name, "tile_cols")) { fs::options().tile_cols = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
 }
@@ -68,6 +71,9 @@ int fs_get_option(const char *name)
 {
   if (name && !strcmp(name, "strict_order")) return fs::options().strict_order;
   if (name && !strcmp(name, "spmv_kernel")) return fs::options().spmv_kernel;
+  if (name && !strcmp(name, "tiling")) return fs::options().tiling;
+  if (name && !strcmp(name, "tile_rows")) return fs::options().tile_rows;
+  if (name && !strcmp(name, "tile_cols")) return fs::options().tile_cols;
   return FS_ERR_ARG;
 }
 

@@ -17,6 +17,8 @@ constexpr int kBlock = 256;            // threads per workgroup = 4 wave64
 constexpr int kChunk = 2048;           // non-zeros one workgroup streams through LDS
 constexpr int kPerThread = kChunk / kBlock;
 
+struct TiledCsr;
+
 // One CSR in HBM plus the chunk schedule of the streaming SpMV kernel.
 struct DeviceCsr {
   int nrow = 0, ncol = 0;
@@ -32,6 +34,26 @@ struct DeviceCsr {
   double *head = nullptr;      // nchunks: sum of the chunk's leading non-zeros that belong to an earlier row
   double *tail = nullptr;      // nchunks: sum of the chunk's trailing non-zeros of a row that ends later
   int spanning = 0;            // number of rows that cross a chunk boundary (0 => no fix-up launch)
+  TiledCsr *tiled = nullptr;  // optional L2-tiled copy (owned)
+};
+
+// L2-tiled copy of a CSR for the column-band kernel (see DESIGN.md "spmv_tiled_kernel").
+// Rows are cut into panels of R rows (one workgroup each, y slice in LDS), columns into bands of W
+// columns (x slice L2-resident).  Entries are ordered by (panel, band), then row, then CSR order.
+// An entry is one 32-bit word  head:1 | local row:(31-lcol_bits) | local col:lcol_bits  plus its value.
+// Work items are runs of at most kTiledItem consecutive entries of one (panel, band) tile.
+constexpr int kTiledItem = 2048;       // entries per work item (8 per thread)
+constexpr int kTiledRowsMax = 6656;    // R <= this: 52 KiB of y per workgroup, two workgroups per CU
+constexpr int kTiledColBits = 18;      // W <= 262144 columns (2 MiB of x)
+
+struct TiledCsr {
+  bool built = false;
+  int R = 0, W = 0, P = 0, J = 0, lcol_bits = kTiledColBits;
+  unsigned *pk = nullptr;      // nnz packed (head, local row, local col)
+  double *vals = nullptr;      // nnz permuted values (nullptr: pattern-only)
+  int4 *items = nullptr;       // nitems: {first entry, count, band, 0}
+  int *item_ptr = nullptr;     // P + 1
+  int nitems = 0;
 };
 
 }  // namespace fs
@@ -66,7 +88,10 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 struct Options {
   int strict_order = 0;
-  int spmv_kernel = 0;
+  int spmv_kernel = 0;   // 0 auto, 1 stream (nt loads), 2 lanes-per-row, 3 stream (cached loads), 6 tiled
+  int tiling = 1;        // 1: build the L2-tiled copy when the heuristic says it pays, 2: always, 0: never
+  int tile_rows = 0;     // override R (0 = auto)
+  int tile_cols = 0;     // override W (0 = auto)
 };
 Options &options();
 
@@ -77,6 +102,8 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s);
+int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
+int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s);
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,
                       const int *cols_dev, const double *vals_dev, hipStream_t s);
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s);

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <string.h>
 
+#include <vector>
+
 #include <rocprim/rocprim.hpp>
 
 #include "fs_common.h"
@@ -26,6 +28,13 @@ void free_csr(DeviceCsr &A)
   if (A.first_row) (void)hipFree(A.first_row);
   if (A.head) (void)hipFree(A.head);
   if (A.tail) (void)hipFree(A.tail);
+  if (A.tiled) {
+    if (A.tiled->pk) (void)hipFree(A.tiled->pk);
+    if (A.tiled->vals) (void)hipFree(A.tiled->vals);
+    if (A.tiled->items) (void)hipFree(A.tiled->items);
+    if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
+    delete A.tiled;
+  }
   A = DeviceCsr();
 }
 
@@ -82,7 +91,7 @@ int build_schedule(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
   FS_HIP(hipFree(cnt));
-  return FS_OK;
+  return build_tiled(A, s);
 }
 
 // ---- stable COO -> CSR -----------------------------------------------------------------------
@@ -186,6 +195,149 @@ int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
   const int rc = coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows, A.vals, s);
   (void)hipFree(rows);
   return rc;
+}
+
+// ---- L2-tiled copy ---------------------------------------------------------------------------------
+// key of entry e = panel(row) * J + band(col); a stable sort by key starting from CSR order leaves every
+// (panel, band) tile ordered by row and, inside a row, in CSR storage order.
+__global__ void tile_key_kernel(int nrow, int64_t nnz, int R, int W, int J, const int *__restrict__ row_ptr,
+                                const int *__restrict__ cols, int *__restrict__ rows, unsigned *__restrict__ keys)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  int lo = 0, hi = nrow;  // last r with row_ptr[r] <= i
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    if ((int64_t)row_ptr[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  rows[i] = lo;
+  keys[i] = (unsigned)(lo / R) * (unsigned)J + (unsigned)(cols[i] / W);
+}
+
+__global__ void tile_pack_kernel(int64_t nnz, int R, int W, int J, int lcol_bits, const unsigned *__restrict__ skeys,
+                                 const unsigned *__restrict__ perm, const int *__restrict__ rows,
+                                 const int *__restrict__ cols, const double *__restrict__ vals,
+                                 unsigned *__restrict__ pk, double *__restrict__ vals_out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const unsigned src = perm[i];
+  const unsigned key = skeys[i];
+  const int r = rows[src], c = cols[src];
+  const unsigned p = key / (unsigned)J, j = key % (unsigned)J;
+  const unsigned lrow = (unsigned)(r - (int)p * R), lcol = (unsigned)(c - (int)j * W);
+  bool head = true;
+  if (i > 0 && skeys[i - 1] == key && rows[perm[i - 1]] == r) head = false;
+  pk[i] = (head ? 0x80000000u : 0u) | (lrow << lcol_bits) | lcol;
+  if (vals) vals_out[i] = vals[src];
+}
+
+// tile_ptr[k] = first sorted position whose key is >= k, k = 0 .. ntiles
+__global__ void tile_ptr_kernel(int64_t ntiles, int64_t nnz, const unsigned *__restrict__ skeys, int *__restrict__ tile_ptr)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > ntiles) return;
+  int64_t lo = 0, hi = nnz;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if ((int64_t)skeys[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  tile_ptr[k] = (int)lo;
+}
+
+int build_tiled(DeviceCsr &A, hipStream_t s)
+{
+  const Options &o = options();
+  if (o.tiling == 0 || A.nrow == 0 || A.nnz == 0) return FS_OK;
+  int dev = 0, ncu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+  const int slots = 2 * (ncu > 0 ? ncu : 256);
+  // panel height: P a multiple of the resident workgroup count where the matrix is tall enough
+  int R = o.tile_rows;
+  if (R <= 0) {
+    const int64_t g = ((int64_t)A.nrow + (int64_t)slots * kTiledRowsMax - 1) / ((int64_t)slots * kTiledRowsMax);
+    R = (int)(((int64_t)A.nrow + slots * g - 1) / (slots * g));
+    if (R < 256) R = A.nrow < 256 ? A.nrow : 256;
+  }
+  if (R > kTiledRowsMax) R = kTiledRowsMax;
+  const int P = (A.nrow + R - 1) / R;
+  // band width: about 0.9 work items per tile on average, at most 2 MiB of x
+  int W = o.tile_cols;
+  if (W <= 0) {
+    const double per_row = (double)A.nnz / A.nrow;
+    double w = 0.9 * kTiledItem * (double)A.ncol / (per_row * R);
+    if (w < 4096) w = 4096;
+    if (w > (1 << kTiledColBits)) w = (1 << kTiledColBits);
+    W = (int)w;
+  }
+  if (W > (1 << kTiledColBits)) W = 1 << kTiledColBits;
+  if (W > A.ncol) W = A.ncol;
+  const int J = (A.ncol + W - 1) / W;
+  const int64_t ntiles = (int64_t)P * J;
+  if (o.tiling == 1) {
+    // pays when x overflows the 4 MiB L2 of an XCD and tiles are not hopelessly thin
+    const bool big_x = (int64_t)A.ncol * 8 > (3ll << 20);
+    if (!big_x || A.nnz < (4 << 20) || (double)A.nnz / ntiles < 256.0) return FS_OK;
+  }
+  if (ntiles >= (1ll << 31)) return FS_OK;
+  TiledCsr *T = new TiledCsr();
+  T->R = R; T->W = W; T->P = P; T->J = J; T->lcol_bits = kTiledColBits;
+  A.tiled = T;
+  const size_t n = (size_t)A.nnz;
+  int *rows = nullptr, *tile_ptr = nullptr;
+  unsigned *keys = nullptr, *skeys = nullptr, *idx_in = nullptr, *idx_out = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  FS_HIP(hipMalloc(&rows, sizeof(int) * n));
+  FS_HIP(hipMalloc(&keys, sizeof(unsigned) * n));
+  FS_HIP(hipMalloc(&skeys, sizeof(unsigned) * n));
+  FS_HIP(hipMalloc(&idx_in, sizeof(unsigned) * n));
+  FS_HIP(hipMalloc(&idx_out, sizeof(unsigned) * n));
+  FS_HIP(hipMalloc(&tile_ptr, sizeof(int) * ((size_t)ntiles + 1)));
+  FS_HIP(hipMalloc(&T->pk, sizeof(unsigned) * n));
+  if (A.vals) FS_HIP(hipMalloc(&T->vals, sizeof(double) * n));
+  hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, R, W, J, A.row_ptr, A.cols,
+                     rows, keys);
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in);
+  FS_HIP(hipGetLastError());
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) < ntiles) ++bits;
+  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, idx_in, idx_out, n, 0, bits, s));
+  FS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+  FS_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, idx_in, idx_out, n, 0, bits, s));
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, R, W, J, T->lcol_bits, skeys,
+                     idx_out, rows, A.cols, A.vals, T->pk, T->vals);
+  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, s, ntiles, A.nnz, skeys, tile_ptr);
+  FS_HIP(hipGetLastError());
+  // work items are cut on the host from the tile pointers (P*J ints)
+  std::vector<int> tp((size_t)ntiles + 1);
+  FS_HIP(hipMemcpyAsync(tp.data(), tile_ptr, sizeof(int) * tp.size(), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  std::vector<int4> items;
+  std::vector<int> item_ptr((size_t)P + 1);
+  items.reserve((size_t)(A.nnz / kTiledItem + ntiles / 4 + 16));
+  for (int p = 0; p < P; ++p) {
+    item_ptr[p] = (int)items.size();
+    for (int j = 0; j < J; ++j) {
+      const int a = tp[(size_t)p * J + j], b = tp[(size_t)p * J + j + 1];
+      for (int off = a; off < b; off += kTiledItem) {
+        int4 it;
+        it.x = off; it.y = (b - off < kTiledItem) ? b - off : kTiledItem; it.z = j; it.w = 0;
+        items.push_back(it);
+      }
+    }
+  }
+  item_ptr[P] = (int)items.size();
+  T->nitems = (int)items.size();
+  FS_HIP(hipMalloc(&T->items, sizeof(int4) * (items.size() ? items.size() : 1)));
+  FS_HIP(hipMalloc(&T->item_ptr, sizeof(int) * item_ptr.size()));
+  if (!items.empty()) FS_HIP(hipMemcpy(T->items, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
+  FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
+  FS_HIP(hipFree(tmp)); FS_HIP(hipFree(rows)); FS_HIP(hipFree(keys)); FS_HIP(hipFree(skeys));
+  FS_HIP(hipFree(idx_in)); FS_HIP(hipFree(idx_out)); FS_HIP(hipFree(tile_ptr));
+  T->built = true;
+  return FS_OK;
 }
 
 // ---- synthetic inputs (same arithmetic as oracle/fs_synth.c) -------------------------------------

@@ -210,6 +210,112 @@ __global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__
 }
 
 // ------------------------------------------------------------------------------------------
+// y = A x on the L2-tiled copy (TiledCsr, fs_common.h).  Same products and the same per-row
+// terms as csr_A_mul_B (csr.h:425-438); the order in which a row's terms are added is
+// band-major (deterministic, run-to-run reproducible), so arbitrary x agrees with the CPU order
+// to rounding (1e-12 bar) and integer-valued x bit for bit.
+//
+// Why: with x far larger than the 4 MiB L2 of an XCD every gather of x[col] misses and pulls a
+// whole line across the fabric; measured 53-56 G gathers/s however the kernel is shaped, against
+// ~240 G/s when the gathered range is L2-resident (tools/probe_gather, profiles/).  Here one
+// workgroup owns a panel of R rows (its y slice lives in LDS) and sweeps the column bands left
+// to right; the workgroups resident together start together and advance at the same pace, so at
+// any moment an XCD gathers from one or two bands (<= 2 MiB each) that stay in its L2.
+//
+// Per work item (<= 2048 consecutive entries of one tile): coalesced loads of the packed
+// (head, row, col) words and the values, gathers of x inside the band, products parked in LDS,
+// barrier, then every entry that starts a row-run adds the run's sum into its y slot (rows of
+// different runs are distinct inside an item, so plain LDS read-add-write is race free).
+// The next item's entries are loaded while the current one is being reduced.
+// ------------------------------------------------------------------------------------------
+constexpr int kTiledPer = kTiledItem / kBlock;  // 8 entries per thread
+
+template <bool VALUED>
+__global__ __launch_bounds__(kBlock, 2) void spmv_tiled_kernel(
+    int nrow, int R, int W, int lcol_bits, const int4 *__restrict__ items, const int *__restrict__ item_ptr,
+    const unsigned *__restrict__ pk, const double *__restrict__ vals, const double *__restrict__ x,
+    double *__restrict__ y)
+{
+  __shared__ double ytile[kTiledRowsMax];
+  __shared__ double sprod[kTiledItem];
+  __shared__ unsigned spk[kTiledItem + 1];
+  const int t = threadIdx.x;
+  const int p = blockIdx.x;
+  const int row0 = p * R;
+  const int nr = (nrow - row0 < R) ? nrow - row0 : R;
+  for (int i = t; i < nr; i += kBlock) ytile[i] = 0.0;
+  const unsigned cmask = (1u << lcol_bits) - 1u;
+  const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
+
+  unsigned w[kTiledPer];
+  double v[kTiledPer];
+  int4 cur = make_int4(0, 0, 0, 0);
+  if (it0 < it1) {
+    cur = items[it0];
+#pragma unroll
+    for (int q = 0; q < kTiledPer; ++q) {
+      const int pos = q * kBlock + t;
+      w[q] = pos < cur.y ? pk[(int64_t)cur.x + pos] : 0u;
+      if (VALUED) v[q] = pos < cur.y ? vals[(int64_t)cur.x + pos] : 0.0;
+    }
+  }
+  for (int it = it0; it < it1; ++it) {
+    const int n = cur.y;
+    const int64_t cbase = (int64_t)cur.z * W;
+    // gathers for the current item
+    double xv[kTiledPer];
+#pragma unroll
+    for (int q = 0; q < kTiledPer; ++q) {
+      const int pos = q * kBlock + t;
+      xv[q] = pos < n ? x[cbase + (w[q] & cmask)] : 0.0;
+    }
+    // prefetch the next item's entries (in flight during the LDS phases below)
+    unsigned wn[kTiledPer];
+    double vn[kTiledPer];
+    int4 nxt = make_int4(0, 0, 0, 0);
+    if (it + 1 < it1) {
+      nxt = items[it + 1];
+#pragma unroll
+      for (int q = 0; q < kTiledPer; ++q) {
+        const int pos = q * kBlock + t;
+        wn[q] = pos < nxt.y ? pk[(int64_t)nxt.x + pos] : 0u;
+        if (VALUED) vn[q] = pos < nxt.y ? vals[(int64_t)nxt.x + pos] : 0.0;
+      }
+    }
+    __syncthreads();  // previous item's readers are done with sprod/spk (and ytile is zeroed)
+#pragma unroll
+    for (int q = 0; q < kTiledPer; ++q) {
+      const int pos = q * kBlock + t;
+      if (pos < n) {
+        sprod[pos] = VALUED ? xv[q] * v[q] : xv[q];
+        spk[pos] = w[q];
+      }
+    }
+    if (t == 0) spk[n] = 0x80000000u;  // sentinel: a run never extends past the item
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kTiledPer; ++q) {
+      const int pos = q * kBlock + t;
+      if (pos < n) {
+        const unsigned me = w[q];
+        if ((me >> 31) || pos == 0) {  // first entry of a row-run (or of the item)
+          double sum = sprod[pos];
+          int k = pos + 1;
+          while (!(spk[k] >> 31)) { sum += sprod[k]; ++k; }
+          const unsigned lr = (me & 0x7FFFFFFFu) >> lcol_bits;
+          ytile[lr] += sum;
+        }
+      }
+    }
+    cur = nxt;
+#pragma unroll
+    for (int q = 0; q < kTiledPer; ++q) { w[q] = wn[q]; if (VALUED) v[q] = vn[q]; }
+  }
+  __syncthreads();
+  for (int i = t; i < nr; i += kBlock) y[row0 + i] = ytile[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // G-lanes-per-row CSR kernel (A/B alternative; also the simplest correct baseline).
 // ------------------------------------------------------------------------------------------
 template <bool VALUED>
@@ -329,11 +435,28 @@ static int ceil_log2(int v)
   return lg;
 }
 
+int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
+{
+  const TiledCsr &T = *A.tiled;
+  if (A.vals)
+    hipLaunchKernelGGL(spmv_tiled_kernel<true>, dim3(T.P), dim3(kBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, T.items,
+                       T.item_ptr, T.pk, T.vals, x, y);
+  else
+    hipLaunchKernelGGL(spmv_tiled_kernel<false>, dim3(T.P), dim3(kBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, T.items,
+                       T.item_ptr, T.pk, T.vals, x, y);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
   const Options &o = options();
   const bool valued = A.vals != nullptr;
+  // auto: the L2-tiled copy when it was built (format builder decided it pays) and the caller did not
+  // ask for storage-order sums
+  if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6))
+    return launch_spmv_tiled(A, y, x, s);
   if (o.spmv_kernel == 2) {
     const double avg = A.nrow ? (double)A.nnz / A.nrow : 0.0;
     int lg = o.strict_order ? 0 : ceil_log2((int)(avg < 1 ? 1 : (avg > 64 ? 64 : avg)));

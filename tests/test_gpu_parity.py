@@ -119,6 +119,29 @@ def test_csr_transposed_product(hip, backend):
                     assert np.max(np.abs(y - ref)) <= TOL * max(1.0, np.max(np.abs(ref))), (name, tag)
 
 
+@pytest.mark.parametrize("geometry", [(64, 128), (7, 33), (2048, 4096), (0, 0)])
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_tiled_kernel_vs_reference_golden(hip, case, geometry):
+    """the L2-tiled (row panel x column band) kernel, forced on with small panels/bands so that every case
+    spans many tiles; (0, 0) = automatic geometry"""
+    from libfastsparse_amd import capi
+    capi.set_option("tiling", 2)
+    capi.set_option("tile_rows", geometry[0])
+    capi.set_option("tile_cols", geometry[1])
+    try:
+        gold = np.load(os.path.join(S.GOLDEN, case.name + ".npz"))
+        out = _cases.run_case(hip.HipDeviceBackend(), case, light=True)
+        _check(out, gold, case.name, exact=False)
+        # reproducible run to run: the band-major order is fixed
+        out2 = _cases.run_case(hip.HipDeviceBackend(), case, light=True)
+        for k in out:
+            assert np.array_equal(out[k].view(np.int64), out2[k].view(np.int64)), k
+    finally:
+        capi.set_option("tiling", 1)
+        capi.set_option("tile_rows", 0)
+        capi.set_option("tile_cols", 0)
+
+
 def test_edge_shapes(hip):
     """empty matrix, single row/column, all rows empty, row longer than several chunks, k not a power of two"""
     be = hip.HipDeviceBackend()

@@ -41,11 +41,15 @@ def main():
     ap.add_argument("--out", default="gpurun_out/microbench.jsonl")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--what", default="probes,c2,c3,c4")
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--tile-cols", type=int, default=0)
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     out = open(args.out, "a")
     st = capi.current_stream()
     what = args.what.split(",")
+    capi.set_option("tile_rows", args.tile_rows)
+    capi.set_option("tile_cols", args.tile_cols)
     n = args.rows
     if "probes" in what:
         a = torch.empty(240_000_000, dtype=torch.float64, device="cuda").normal_()
@@ -67,7 +71,7 @@ def main():
         x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         B = A.algorithmic_bytes()
-        for kern, label in ((1, "stream_nt"), (3, "stream_cached"), (2, "vector")):
+        for kern, label in ((6, "tiled"), (1, "stream_nt"), (2, "vector")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c2_csr_f64_{label}", B, timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
@@ -95,7 +99,7 @@ def main():
         A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
         x = torch.randint(-1000, 1001, (ncol,), device="cuda").to(torch.float64)
         y = torch.empty(nrow, dtype=torch.float64, device="cuda")
-        for kern, label in ((1, "stream_nt"), (3, "stream_cached"), (2, "vector")):
+        for kern, label in ((6, "tiled"), (1, "stream_nt")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
@@ -105,7 +109,7 @@ def main():
         A = capi.Matrix.from_csr(nrow, nrow, rp, cc, vv, borrow=True)
         x = torch.sin(7.0 * torch.arange(nrow, device="cuda", dtype=torch.float64) + 0.3)
         y = torch.empty(nrow, dtype=torch.float64, device="cuda")
-        for kern, label in ((1, "stream_nt"), (2, "vector")):
+        for kern, label in ((6, "tiled"), (1, "stream_nt"), (2, "vector")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c5shard_powerlaw_{label}_nnz{A.nnz}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
