@@ -92,6 +92,7 @@ struct Options {
   int tiling = 1;        // 1: build the L2-tiled copy when the heuristic says it pays, 2: always, 0: never
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
+  int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
 };
 Options &options();
 

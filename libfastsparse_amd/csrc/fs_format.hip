@@ -262,11 +262,12 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   }
   if (R > kTiledRowsMax) R = kTiledRowsMax;
   const int P = (A.nrow + R - 1) / R;
-  // band width: about 0.9 work items per tile on average, at most 2 MiB of x
+  // band width: about half a work item per tile on average (measured best on config 2: narrower bands
+  // keep more of the sweep L2-resident when workgroups drift apart), at most 2 MiB of x
   int W = o.tile_cols;
   if (W <= 0) {
     const double per_row = (double)A.nnz / A.nrow;
-    double w = 0.9 * kTiledItem * (double)A.ncol / (per_row * R);
+    double w = 0.5 * kTiledItem * (double)A.ncol / (per_row * R);
     if (w < 4096) w = 4096;
     if (w > (1 << kTiledColBits)) w = (1 << kTiledColBits);
     W = (int)w;

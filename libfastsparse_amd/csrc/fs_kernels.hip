@@ -230,7 +230,80 @@ __global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__
 // ------------------------------------------------------------------------------------------
 constexpr int kTiledPer = kTiledItem / kBlock;  // 8 entries per thread
 
-template <bool VALUED>
+// entries of one item for this thread: position q*256 + t.  Whole 256-entry slabs past the item's end
+// are skipped (wave-uniform test); inside the last slab the position is clamped to the last entry, so
+// the loads themselves are unconditional and the clamped lanes re-read one cached word.
+template <bool VALUED, bool NT>
+__device__ __forceinline__ void tiled_load(const int4 d, int t, const unsigned *__restrict__ pk,
+                                           const double *__restrict__ vals, unsigned (&w)[kTiledPer],
+                                           double (&v)[kTiledPer])
+{
+  const int last = d.y > 0 ? d.y - 1 : 0;
+#pragma unroll
+  for (int q = 0; q < kTiledPer; ++q) {
+    if (q * kBlock < d.y || q == 0) {
+      const int pos = q * kBlock + t;
+      const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
+      w[q] = stream_load<NT>(pk + e);
+      if (VALUED) v[q] = stream_load<NT>(vals + e);
+    }
+  }
+}
+
+__device__ __forceinline__ void tiled_gather(const int4 d, int W, unsigned cmask, const double *__restrict__ x,
+                                             const unsigned (&w)[kTiledPer], double (&xv)[kTiledPer])
+{
+  const double *xb = x + (int64_t)d.z * W;
+#pragma unroll
+  for (int q = 0; q < kTiledPer; ++q)
+    if (q * kBlock < d.y || q == 0) xv[q] = xb[w[q] & cmask];
+}
+
+// one pipeline step: reduce item `da` (entries wa/va, gathered xa) through LDS while the gathers of the
+// next item `db` (entries wb already loaded) and the entry loads of the item after it (`dc`) are in flight
+template <bool VALUED, bool NT, bool ATOMIC>
+__device__ __forceinline__ void tiled_step(double *__restrict__ ytile, double *__restrict__ sprod,
+                                           unsigned *__restrict__ spk, int t, int W, unsigned cmask, int lcol_bits,
+                                           const unsigned *__restrict__ pk, const double *__restrict__ vals,
+                                           const double *__restrict__ x, const int4 da, const int4 db, const int4 dc,
+                                           const unsigned (&wa)[kTiledPer], const double (&va)[kTiledPer],
+                                           const double (&xa)[kTiledPer], const unsigned (&wb)[kTiledPer],
+                                           double (&xb)[kTiledPer], unsigned (&wc)[kTiledPer], double (&vc)[kTiledPer])
+{
+  const int n = da.y;
+#pragma unroll
+  for (int q = 0; q < kTiledPer; ++q) {
+    const int pos = q * kBlock + t;
+    if (pos < n) {
+      sprod[pos] = VALUED ? xa[q] * va[q] : xa[q];
+      spk[pos] = wa[q];
+    }
+  }
+  if (t == 0) spk[n] = 0x80000000u;  // sentinel: a run never extends past the item
+  __syncthreads();
+  tiled_gather(db, W, cmask, x, wb, xb);
+  tiled_load<VALUED, NT>(dc, t, pk, vals, wc, vc);
+#pragma unroll
+  for (int q = 0; q < kTiledPer; ++q) {
+    const int pos = q * kBlock + t;
+    if (pos < n) {
+      const unsigned me = wa[q];
+      if ((me >> 31) || pos == 0) {  // first entry of a row-run (or of the item)
+        double sum = sprod[pos];
+        int k = pos + 1;
+        while (!(spk[k] >> 31)) { sum += sprod[k]; ++k; }
+        // the runs of one item are distinct rows: one add per address, so the LDS atomic (fire and
+        // forget, no read-add-write dependency chain in the wave) gives the same bits as a plain update
+        double *slot = &ytile[(me & 0x7FFFFFFFu) >> lcol_bits];
+        if (ATOMIC) __hip_atomic_fetch_add(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else *slot += sum;
+      }
+    }
+  }
+  __syncthreads();  // stage buffers free again
+}
+
+template <bool VALUED, bool NT, bool ATOMIC>
 __global__ __launch_bounds__(kBlock, 2) void spmv_tiled_kernel(
     int nrow, int R, int W, int lcol_bits, const int4 *__restrict__ items, const int *__restrict__ item_ptr,
     const unsigned *__restrict__ pk, const double *__restrict__ vals, const double *__restrict__ x,
@@ -246,72 +319,32 @@ __global__ __launch_bounds__(kBlock, 2) void spmv_tiled_kernel(
   for (int i = t; i < nr; i += kBlock) ytile[i] = 0.0;
   const unsigned cmask = (1u << lcol_bits) - 1u;
   const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
+  const int4 none = make_int4(0, 0, 0, 0);  // an empty item: loads entry 0, contributes nothing
+#define FS_ITEM(i) ((i) < it1 ? items[(i)] : none)
+#define FS_STEP(DA, DB, DC, WA, VA, XA, WB, XB, WC, VC) \
+  tiled_step<VALUED, NT, ATOMIC>(ytile, sprod, spk, t, W, cmask, lcol_bits, pk, vals, x, DA, DB, DC, WA, VA, XA, WB, XB, WC, VC)
 
-  unsigned w[kTiledPer];
-  double v[kTiledPer];
-  int4 cur = make_int4(0, 0, 0, 0);
-  if (it0 < it1) {
-    cur = items[it0];
-#pragma unroll
-    for (int q = 0; q < kTiledPer; ++q) {
-      const int pos = q * kBlock + t;
-      w[q] = pos < cur.y ? pk[(int64_t)cur.x + pos] : 0u;
-      if (VALUED) v[q] = pos < cur.y ? vals[(int64_t)cur.x + pos] : 0.0;
-    }
+  // software pipeline, three items deep, unrolled three times so that the three register sets rotate
+  // by name (a register copy would force the in-flight loads to complete)
+  int4 d0 = FS_ITEM(it0), d1 = FS_ITEM(it0 + 1), d2;
+  unsigned w0[kTiledPer], w1[kTiledPer], w2[kTiledPer];
+  double v0[kTiledPer], v1[kTiledPer], v2[kTiledPer], x0[kTiledPer], x1[kTiledPer], x2[kTiledPer];
+  tiled_load<VALUED, NT>(d0, t, pk, vals, w0, v0);
+  tiled_load<VALUED, NT>(d1, t, pk, vals, w1, v1);
+  tiled_gather(d0, W, cmask, x, w0, x0);
+  __syncthreads();  // ytile zeroed
+  for (int it = it0; it < it1; it += 3) {
+    d2 = FS_ITEM(it + 2);
+    FS_STEP(d0, d1, d2, w0, v0, x0, w1, x1, w2, v2);
+    if (it + 1 >= it1) break;
+    d0 = FS_ITEM(it + 3);
+    FS_STEP(d1, d2, d0, w1, v1, x1, w2, x2, w0, v0);
+    if (it + 2 >= it1) break;
+    d1 = FS_ITEM(it + 4);
+    FS_STEP(d2, d0, d1, w2, v2, x2, w0, x0, w1, v1);
   }
-  for (int it = it0; it < it1; ++it) {
-    const int n = cur.y;
-    const int64_t cbase = (int64_t)cur.z * W;
-    // gathers for the current item
-    double xv[kTiledPer];
-#pragma unroll
-    for (int q = 0; q < kTiledPer; ++q) {
-      const int pos = q * kBlock + t;
-      xv[q] = pos < n ? x[cbase + (w[q] & cmask)] : 0.0;
-    }
-    // prefetch the next item's entries (in flight during the LDS phases below)
-    unsigned wn[kTiledPer];
-    double vn[kTiledPer];
-    int4 nxt = make_int4(0, 0, 0, 0);
-    if (it + 1 < it1) {
-      nxt = items[it + 1];
-#pragma unroll
-      for (int q = 0; q < kTiledPer; ++q) {
-        const int pos = q * kBlock + t;
-        wn[q] = pos < nxt.y ? pk[(int64_t)nxt.x + pos] : 0u;
-        if (VALUED) vn[q] = pos < nxt.y ? vals[(int64_t)nxt.x + pos] : 0.0;
-      }
-    }
-    __syncthreads();  // previous item's readers are done with sprod/spk (and ytile is zeroed)
-#pragma unroll
-    for (int q = 0; q < kTiledPer; ++q) {
-      const int pos = q * kBlock + t;
-      if (pos < n) {
-        sprod[pos] = VALUED ? xv[q] * v[q] : xv[q];
-        spk[pos] = w[q];
-      }
-    }
-    if (t == 0) spk[n] = 0x80000000u;  // sentinel: a run never extends past the item
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kTiledPer; ++q) {
-      const int pos = q * kBlock + t;
-      if (pos < n) {
-        const unsigned me = w[q];
-        if ((me >> 31) || pos == 0) {  // first entry of a row-run (or of the item)
-          double sum = sprod[pos];
-          int k = pos + 1;
-          while (!(spk[k] >> 31)) { sum += sprod[k]; ++k; }
-          const unsigned lr = (me & 0x7FFFFFFFu) >> lcol_bits;
-          ytile[lr] += sum;
-        }
-      }
-    }
-    cur = nxt;
-#pragma unroll
-    for (int q = 0; q < kTiledPer; ++q) { w[q] = wn[q]; if (VALUED) v[q] = vn[q]; }
-  }
-  __syncthreads();
+#undef FS_ITEM
+#undef FS_STEP
   for (int i = t; i < nr; i += kBlock) y[row0 + i] = ytile[i];
 }
 
@@ -438,12 +471,19 @@ static int ceil_log2(int v)
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
 {
   const TiledCsr &T = *A.tiled;
-  if (A.vals)
-    hipLaunchKernelGGL(spmv_tiled_kernel<true>, dim3(T.P), dim3(kBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, T.items,
-                       T.item_ptr, T.pk, T.vals, x, y);
-  else
-    hipLaunchKernelGGL(spmv_tiled_kernel<false>, dim3(T.P), dim3(kBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, T.items,
-                       T.item_ptr, T.pk, T.vals, x, y);
+  const int f = options().tiled_flags;  // bit 0: cached (not nt) entry loads, bit 1: plain LDS update instead of atomic
+#define FS_TILED(V, N, AT)                                                                                        \
+  hipLaunchKernelGGL((spmv_tiled_kernel<V, N, AT>), dim3(T.P), dim3(kBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, \
+                     T.items, T.item_ptr, T.pk, T.vals, x, y)
+  const bool nt = !(f & 1), at = !(f & 2);
+  if (A.vals) {
+    if (nt && at) FS_TILED(true, true, true); else if (nt) FS_TILED(true, true, false);
+    else if (at) FS_TILED(true, false, true); else FS_TILED(true, false, false);
+  } else {
+    if (nt && at) FS_TILED(false, true, true); else if (nt) FS_TILED(false, true, false);
+    else if (at) FS_TILED(false, false, true); else FS_TILED(false, false, false);
+  }
+#undef FS_TILED
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

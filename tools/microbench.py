@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--what", default="probes,c2,c3,c4")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--tile-cols", type=int, default=0)
+    ap.add_argument("--tiled-flags", type=int, default=0)
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     out = open(args.out, "a")
@@ -50,6 +51,7 @@ def main():
     what = args.what.split(",")
     capi.set_option("tile_rows", args.tile_rows)
     capi.set_option("tile_cols", args.tile_cols)
+    capi.set_option("tiled_flags", args.tiled_flags)
     n = args.rows
     if "probes" in what:
         a = torch.empty(240_000_000, dtype=torch.float64, device="cuda").normal_()
