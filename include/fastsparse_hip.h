@@ -59,6 +59,13 @@ int  fs_set_device(int device);
 int  fs_set_option(const char *name, int value);
 int  fs_get_option(const char *name);
 
+/* ---- dense vectors in HBM (thin wrappers over hipMalloc/hipMemcpy for C callers without HIP headers) */
+void *fs_device_alloc(int64_t bytes);
+void  fs_device_free(void *p);
+int   fs_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes);
+int   fs_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes);
+int   fs_device_synchronize(void);
+
 /* ---- matrices in HBM ---------------------------------------------------------------- */
 /* CSR arrays -> handle.  vals == NULL makes a pattern-only (BinaryCSR) matrix.
  * space says where row_ptr/cols/vals live.  With space == FS_DEVICE and borrow != 0 the

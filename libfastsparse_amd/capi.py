@@ -17,6 +17,7 @@ _lib = None
 # every symbol declared in include/*.h (tests check that the library exports all of them)
 DEVICE_API = [
     "fs_version", "fs_last_error", "fs_device_count", "fs_set_device", "fs_set_option", "fs_get_option",
+    "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
     "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
     "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul",

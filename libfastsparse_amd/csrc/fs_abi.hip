@@ -55,6 +55,33 @@ int fs_set_device(int device)
   return FS_OK;
 }
 
+void *fs_device_alloc(int64_t bytes)
+{
+  void *p = nullptr;
+  if (bytes < 0 || hipMalloc(&p, (size_t)(bytes ? bytes : 1)) != hipSuccess) { set_error("fs_device_alloc failed"); return nullptr; }
+  return p;
+}
+
+void fs_device_free(void *p) { if (p) (void)hipFree(p); }
+
+int fs_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes)
+{
+  FS_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+  return FS_OK;
+}
+
+int fs_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes)
+{
+  FS_HIP(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+  return FS_OK;
+}
+
+int fs_device_synchronize(void)
+{
+  FS_HIP(hipDeviceSynchronize());
+  return FS_OK;
+}
+
 int fs_set_option(const char *name, int value)
 {
   if (!name) { set_error("fs_set_option: NULL name"); return FS_ERR_ARG; }

@@ -151,3 +151,43 @@ def test_dropin_product_dies_loudly_without_gpu():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert p.returncode != 0 and "COMPUTED" not in p.stdout
     assert "libfastsparse_hip" in p.stderr
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference headers (build container only)")
+def test_objects_built_against_original_headers_link(tmp_path):
+    """C99 inline leaves the reference's API calls as undefined symbols; an object compiled
+    against the ORIGINAL headers must link against libfastsparse_hip.so unchanged.  Link only: the binary
+    is not run and does not leave this container."""
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "sparse.h"
+#include "dsparse.h"
+#include "csr.h"
+#include "cbcsr.h"
+int main(int argc, char** argv) {
+  struct SparseBinaryMatrix* A = read_sbm(argv[1]);
+  struct SparseDoubleMatrix* D = read_sdm(argv[2]);
+  double x[64], y[128];
+  A_mul_B(y, A, x); At_mul_B(x, A, y); sdm_A_mul_B(y, D, x); sdm_At_mul_B(x, D, y);
+  struct BlockedSBM* B = new_bsbm(A, 8); bsbm_A_mul_B(y, B, x); bsbm_A_mul_B2(y, B, x); bsbm_A_mul_B4(y, B, x); bsbm_A_mul_Bn(y, B, x, 3);
+  struct BlockedSDM* E = new_bsdm(D, 8); bsdm_A_mul_B(y, E, x);
+  struct BinaryCSR c; bcsr_from_sbm(&c, A);
+  bcsr_A_mul_B(y, &c, x); bcsr_A_mul_B2(y, &c, x); bcsr_A_mul_B4(y, &c, x); bcsr_A_mul_B8(y, &c, x); bcsr_A_mul_B8_auto(y, &c, x);
+  bcsr_A_mul_Bn(y, &c, x, 3); bcsr_A_mul_B32n(y, &c, x, 3); bcsr_AA_mul_B(x, &c, x); parallel_bcsr_AA_mul_B(x, &c, x, y); free_bcsr(&c);
+  struct CSR v; new_csr(&v, D->nnz, D->nrow, D->ncol, D->rows, D->cols, D->vals); csr_A_mul_B(y, &v, x); csr_A_mul_Bn(y, &v, x, 2); free_csr(&v);
+  struct ColBinaryCSR k; cbcsr_from_sbm(&k, A, 8); cbcsr_A_mul_B(y, &k, x);
+  return 0;
+}''')
+    obj = tmp_path / "caller.o"
+    # -O0 and no -fgnu89-inline: every API call stays an undefined reference, like `make test` of the reference
+    subprocess.check_call(["gcc", "-std=gnu99", "-O0", "-w", "-I/root/reference", "-c", str(src), "-o", str(obj)])
+    undef = subprocess.check_output(["nm", "-u", str(obj)]).decode()
+    for sym in ("A_mul_B", "csr_A_mul_B", "bcsr_A_mul_B8_auto", "cbcsr_A_mul_B", "new_bsbm", "read_sdm"):
+        assert sym in undef
+    exe = tmp_path / "caller"
+    lib_dir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", str(obj), "-o", str(exe), "-L" + lib_dir, "-lfastsparse_hip", "-lm",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)

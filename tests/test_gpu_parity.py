@@ -217,3 +217,20 @@ def test_synthetic_generator_matches_cpu_twin(hip):
     hrp, hcc, hvv = pysynth.powerlaw(20000, 50000, 2.3, 100000, 0x5EED0005, row_offset=7)
     assert np.array_equal(rp.cpu().numpy(), hrp) and np.array_equal(cc.cpu().numpy(), hcc)
     assert np.array_equal(vv.cpu().numpy(), hvv)
+
+
+def test_c_bench_driver_config1(hip):
+    """BASELINE config 1 (plumbing): the label-compatible C driver runs on both bundled fixtures, host and
+    device vectors, and prints every section of the reference's bench plus [csr-f64]"""
+    import subprocess
+    from libfastsparse_amd import _build
+    exe = _build.build_c_bench()
+    labels = ["unsorted", "sort", "block", "2xblock", "2xblock*", "cg", "cg2", "csr", "csr2", "cg2-csr", "cg4-csr",
+              "cg8-csr", "cg8a-csr", "cg8*-csr", "cg8**-csr", "4xblock", "sort+block", "rowsort+block", "2x cg2"]
+    for fixture, extra in (("sdm-100-50.data", ["csr-f64", "csr-f64 At"]), ("sbm-100-50.data", [])):
+        for flags in (["-r", "-b", "8"], ["-r", "-d"], ["-r", "-t", "-c"]):
+            p = subprocess.run([exe, "-f", os.path.join(S.GOLDEN, fixture)] + flags, capture_output=True, text=True,
+                               timeout=120)
+            assert p.returncode == 0, p.stderr
+            got = [ln.split("]")[0][1:] for ln in p.stdout.splitlines() if ln.startswith("[") and "Wall:" in ln]
+            assert got == labels + extra, (fixture, flags, got)
