@@ -11,11 +11,11 @@ form of config 5's scheme: the global matrix is (N*10M) x (N*10M), rank r owns r
 and of A' (the latter built once by an all-to-all of the entries), x is replicated, and each product is a
 local SpMV followed by an RCCL all-gather of the y shards.
 
-One step = y = A x  then  z = A' u  (two launches of the streaming SpMV kernel per rank, plus the two
+One step = y = A x  then  z = A' u  (two launches of the L2-tiled SpMV kernel per rank, plus the two
 all-gathers when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
 Algorithmic bytes per product: 12*nnz + 4*(nrow+1) + 8*nrow + 8*ncol.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = spmv_stream_kernel, HIP-event timed
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = spmv_tiled_kernel, HIP-event timed
 inside the timed region) and, at N = 1, `cpu_baseline` (the oracle's OpenMP restatement of csr_A_mul_B,
 built with the reference's flags, timed on this box's host cores on the same matrix).
 """
@@ -179,7 +179,7 @@ def main():
 
     if rank == 0:
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_stream.json")
+        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_tiled.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
@@ -198,7 +198,7 @@ def main():
                        "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
                        "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
                        "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt)},
-            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel<valued,nt>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "fs::spmv_tiled_kernel<valued>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "launches_timed": launches},

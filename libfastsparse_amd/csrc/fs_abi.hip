@@ -91,6 +91,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "tile_rows")) { fs::options().tile_rows = value; return FS_OK; }
   if (!strcmp(name, "tile_cols")) { fs::options().tile_cols = value; return FS_OK; }
   if (!strcmp(name, "tiled_flags")) { fs::options().tiled_flags = value; return FS_OK; }
+  if (!strcmp(name, "gate_kb")) { fs::options().gate_kb = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
 }
@@ -215,6 +216,37 @@ int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
   if (int rc = check_mul(A, y, x, "fs_spmv")) return rc;
   std::lock_guard<std::mutex> g(A->lock);
   return fs::launch_spmv(A->a, y, x, (hipStream_t)stream);
+}
+
+// ---- diagnostics (not part of include/fastsparse_hip.h; used by tools/trace_tiled.py) ---------------------
+int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
+{
+  if (!A || !A->a.tiled || !A->a.tiled->built) { set_error("no tiled copy"); return FS_ERR_ARG; }
+  const fs::TiledCsr &T = *A->a.tiled;
+  out6[0] = T.R; out6[1] = T.W; out6[2] = T.P; out6[3] = T.J; out6[4] = T.nitems; out6[5] = T.lcol_bits;
+  return FS_OK;
+}
+
+int fs_debug_tiled_trace(fs_matrix_t A, double *y, const double *x, long long *times_host, int *xcc_host,
+                         int *items_host, int *item_ptr_host)
+{
+  if (!A || !A->a.tiled || !A->a.tiled->built) { set_error("no tiled copy"); return FS_ERR_ARG; }
+  const fs::TiledCsr &T = *A->a.tiled;
+  long long *td = nullptr;
+  int *xd = nullptr;
+  FS_HIP(hipMalloc(&td, sizeof(long long) * (size_t)(T.nitems + 1)));
+  FS_HIP(hipMalloc(&xd, sizeof(int) * (size_t)T.P));
+  FS_HIP(hipMemset(td, 0, sizeof(long long) * (size_t)(T.nitems + 1)));
+  for (int rep = 0; rep < 3; ++rep)  // the last of three back-to-back launches is the one kept
+    if (int rc = fs::launch_spmv_tiled_trace(A->a, y, x, td, xd, nullptr)) return rc;
+  FS_HIP(hipDeviceSynchronize());
+  FS_HIP(hipMemcpy(times_host, td, sizeof(long long) * (size_t)T.nitems, hipMemcpyDeviceToHost));
+  FS_HIP(hipMemcpy(xcc_host, xd, sizeof(int) * (size_t)T.P, hipMemcpyDeviceToHost));
+  FS_HIP(hipMemcpy(items_host, T.items, sizeof(int) * 4 * (size_t)T.nitems, hipMemcpyDeviceToHost));
+  FS_HIP(hipMemcpy(item_ptr_host, T.item_ptr, sizeof(int) * (size_t)(T.P + 1), hipMemcpyDeviceToHost));
+  FS_HIP(hipFree(td));
+  FS_HIP(hipFree(xd));
+  return FS_OK;
 }
 
 int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)

@@ -40,20 +40,30 @@ struct DeviceCsr {
 // L2-tiled copy of a CSR for the column-band kernel (see DESIGN.md "spmv_tiled_kernel").
 // Rows are cut into panels of R rows (one workgroup each, y slice in LDS), columns into bands of W
 // columns (x slice L2-resident).  Entries are ordered by (panel, band), then row, then CSR order.
-// An entry is one 32-bit word  head:1 | local row:(31-lcol_bits) | local col:lcol_bits  plus its value.
+// An entry is one 32-bit word  local row:(32-lcol_bits) | local col:lcol_bits  plus its value.
 // Work items are runs of at most kTiledItem consecutive entries of one (panel, band) tile.
-constexpr int kTiledItem = 2048;       // entries per work item (8 per thread)
-constexpr int kTiledRowsMax = 6656;    // R <= this: 52 KiB of y per workgroup, two workgroups per CU
-constexpr int kTiledColBits = 18;      // W <= 262144 columns (2 MiB of x)
+constexpr int kTiledBlock = 512;       // threads per workgroup of the tiled kernel: ONE workgroup per CU.  Two
+                                       // co-resident 256-thread workgroups were measured to run at different
+                                       // speeds (the older one wins issue arbitration: 401 vs 450 us per panel),
+                                       // which pulls the band sweep of an XCD apart and out of its L2.
+constexpr int kTiledItem = 4096;       // entries per work item (8 per thread)
+constexpr int kTiledRowsMax = 13056;   // R <= this: 102 KiB of y per workgroup
+constexpr int kTiledColBits = 18;      // W <= 262144 columns (2 MiB of x); the other 14 bits are the local row
 
 struct TiledCsr {
   bool built = false;
   int R = 0, W = 0, P = 0, J = 0, lcol_bits = kTiledColBits;
-  unsigned *pk = nullptr;      // nnz packed (head, local row, local col)
+  unsigned *pk = nullptr;      // nnz packed (local row, local col)
   double *vals = nullptr;      // nnz permuted values (nullptr: pattern-only)
   int4 *items = nullptr;       // nitems: {first entry, count, band, 0}
   int *item_ptr = nullptr;     // P + 1
   int nitems = 0;
+  // pace gates of the tiled kernel (see spmv_tiled_kernel): one counter per (generation, XCD label, gate)
+  int *gate_cnt = nullptr;
+  int gate_bands = 0;          // bands between gates (0 = no gates)
+  int ngates = 0;              // gates per sweep (+1)
+  int slots = 256;             // workgroups resident together (1 per CU)
+  int epoch = 0;               // launches so far (counters are monotonic)
 };
 
 }  // namespace fs
@@ -93,6 +103,7 @@ struct Options {
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
   int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
+  int gate_kb = 0;       // x progress between two pace gates of the tiled kernel, KiB (0 = no gates)
 };
 Options &options();
 
@@ -105,6 +116,8 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 int build_schedule(DeviceCsr &A, hipStream_t s);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s);
+int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
+                            hipStream_t s);
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,
                       const int *cols_dev, const double *vals_dev, hipStream_t s);
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s);

@@ -33,6 +33,7 @@ void free_csr(DeviceCsr &A)
     if (A.tiled->vals) (void)hipFree(A.tiled->vals);
     if (A.tiled->items) (void)hipFree(A.tiled->items);
     if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
+    if (A.tiled->gate_cnt) (void)hipFree(A.tiled->gate_cnt);
     delete A.tiled;
   }
   A = DeviceCsr();
@@ -226,9 +227,7 @@ __global__ void tile_pack_kernel(int64_t nnz, int R, int W, int J, int lcol_bits
   const int r = rows[src], c = cols[src];
   const unsigned p = key / (unsigned)J, j = key % (unsigned)J;
   const unsigned lrow = (unsigned)(r - (int)p * R), lcol = (unsigned)(c - (int)j * W);
-  bool head = true;
-  if (i > 0 && skeys[i - 1] == key && rows[perm[i - 1]] == r) head = false;
-  pk[i] = (head ? 0x80000000u : 0u) | (lrow << lcol_bits) | lcol;
+  pk[i] = (lrow << lcol_bits) | lcol;
   if (vals) vals_out[i] = vals[src];
 }
 
@@ -252,7 +251,7 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-  const int slots = 2 * (ncu > 0 ? ncu : 256);
+  const int slots = (ncu > 8 ? ncu : 256) / 8 * 8;  // one workgroup per CU, a multiple of the 8 XCDs
   // panel height: P a multiple of the resident workgroup count where the matrix is tall enough
   int R = o.tile_rows;
   if (R <= 0) {
@@ -262,12 +261,12 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   }
   if (R > kTiledRowsMax) R = kTiledRowsMax;
   const int P = (A.nrow + R - 1) / R;
-  // band width: about half a work item per tile on average (measured best on config 2: narrower bands
-  // keep more of the sweep L2-resident when workgroups drift apart), at most 2 MiB of x
+  // band width: tiles of about 0.9 work items on average (full 8-entries-per-thread items amortise the
+  // two barriers per item), at most 2 MiB of x
   int W = o.tile_cols;
   if (W <= 0) {
     const double per_row = (double)A.nnz / A.nrow;
-    double w = 0.5 * kTiledItem * (double)A.ncol / (per_row * R);
+    double w = 0.9 * kTiledItem * (double)A.ncol / (per_row * R);
     if (w < 4096) w = 4096;
     if (w > (1 << kTiledColBits)) w = (1 << kTiledColBits);
     W = (int)w;
@@ -337,6 +336,17 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
   FS_HIP(hipFree(tmp)); FS_HIP(hipFree(rows)); FS_HIP(hipFree(keys)); FS_HIP(hipFree(skeys));
   FS_HIP(hipFree(idx_in)); FS_HIP(hipFree(idx_out)); FS_HIP(hipFree(tile_ptr));
+  // pace gates: every gate_kb KiB of x progress
+  T->slots = slots;
+  T->gate_bands = 0;
+  if (o.gate_kb > 0) {
+    int gb = (int)(((int64_t)o.gate_kb * 1024) / ((int64_t)W * 8));
+    T->gate_bands = gb < 1 ? 1 : gb;
+  }
+  T->ngates = (T->gate_bands > 0 ? J / T->gate_bands : 0) + 2;
+  const size_t ncnt = (size_t)((P + slots - 1) / slots) * 8 * (size_t)T->ngates;
+  FS_HIP(hipMalloc(&T->gate_cnt, sizeof(int) * ncnt));
+  FS_HIP(hipMemset(T->gate_cnt, 0, sizeof(int) * ncnt));
   T->built = true;
   return FS_OK;
 }

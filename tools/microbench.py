@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--tile-cols", type=int, default=0)
     ap.add_argument("--tiled-flags", type=int, default=0)
+    ap.add_argument("--gate-kb", type=int, default=8192)
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     out = open(args.out, "a")
@@ -52,6 +53,7 @@ def main():
     capi.set_option("tile_rows", args.tile_rows)
     capi.set_option("tile_cols", args.tile_cols)
     capi.set_option("tiled_flags", args.tiled_flags)
+    capi.set_option("gate_kb", args.gate_kb)
     n = args.rows
     if "probes" in what:
         a = torch.empty(240_000_000, dtype=torch.float64, device="cuda").normal_()
