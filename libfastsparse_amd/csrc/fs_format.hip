@@ -244,6 +244,14 @@ __global__ void tile_ptr_kernel(int64_t ntiles, int64_t nnz, const unsigned *__r
   tile_ptr[k] = (int)lo;
 }
 
+__global__ void max_row_len_kernel(int nrow, const int *__restrict__ row_ptr, int *__restrict__ out)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  int len = r < nrow ? row_ptr[r + 1] - row_ptr[r] : 0;
+  for (int m = 32; m > 0; m >>= 1) { const int o = __shfl_xor(len, m); len = o > len ? o : len; }
+  if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
+}
+
 int build_tiled(DeviceCsr &A, hipStream_t s)
 {
   const Options &o = options();
@@ -276,9 +284,27 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   const int J = (A.ncol + W - 1) / W;
   const int64_t ntiles = (int64_t)P * J;
   if (o.tiling == 1) {
-    // pays when x overflows the 4 MiB L2 of an XCD and tiles are not hopelessly thin
+    // pays when x overflows the 4 MiB L2 of an XCD and tiles are not hopelessly thin ...
     const bool big_x = (int64_t)A.ncol * 8 > (3ll << 20);
     if (!big_x || A.nnz < (4 << 20) || (double)A.nnz / ntiles < 256.0) return FS_OK;
+    // ... and while re-reading x once per XCD and per generation of resident workgroups costs less than the
+    // L2 misses it saves.  Measured rates: tiled ~130 G entries/s plus x refills at ~5 TB/s; streaming kernel
+    // with every gather missing ~53 G entries/s.
+    const double gens = (double)((P + slots - 1) / slots);
+    const double t_tiled = (double)A.nnz / 130e9 + gens * 8.0 * (double)A.ncol * 8.0 / 5e12;
+    const double t_stream = (double)A.nnz / 53e9;
+    if (t_tiled > 0.9 * t_stream) return FS_OK;
+    // ... and the matrix has no very long rows: a row's entries inside one tile are summed by one lane, and
+    // a panel that holds a dense row falls behind the band sweep.  Heavy-tailed matrices (BASELINE config 5)
+    // stay on the chunk-streaming kernel, whose work per workgroup does not depend on row lengths.
+    int *mx = nullptr, max_len = 0;
+    FS_HIP(hipMalloc(&mx, sizeof(int)));
+    FS_HIP(hipMemsetAsync(mx, 0, sizeof(int), s));
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(A.nrow)), dim3(256), 0, s, A.nrow, A.row_ptr, mx);
+    FS_HIP(hipMemcpyAsync(&max_len, mx, sizeof(int), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    FS_HIP(hipFree(mx));
+    if ((double)max_len * W / A.ncol > 64.0 || (double)max_len > 16.0 * A.nnz / A.nrow + 4096.0) return FS_OK;
   }
   if (ntiles >= (1ll << 31)) return FS_OK;
   TiledCsr *T = new TiledCsr();

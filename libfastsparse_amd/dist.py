@@ -14,6 +14,30 @@ import torch
 import torch.distributed as dist
 
 
+def _host_collective(t, group):
+    """gloo moves CUDA tensors only for some collectives; route through the host when the backend is gloo
+    (used by the single-GPU rehearsal of the multi-rank path; RCCL takes device tensors directly)"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_into(out, inp, group=None):
+    if _host_collective(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def all_to_all(out, inp, out_split=None, in_split=None, group=None):
+    if _host_collective(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_split, in_split, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, out_split, in_split, group=group)
+
+
 def even_row_partition(nrow, world):
     """contiguous row ranges of (almost) equal size: bounds[r] .. bounds[r+1]"""
     base, rem = divmod(nrow, world)
@@ -81,9 +105,9 @@ class ShardedOperator:
         y_local = self._buffers(y_full)
         self.local_spmv(y_local[:n_local], x_full)
         if self.equal:
-            dist.all_gather_into_tensor(y_full, y_local[:n_local], group=self.group)
+            all_gather_into(y_full, y_local[:n_local], self.group)
         else:
-            dist.all_gather_into_tensor(self._pad, y_local, group=self.group)
+            all_gather_into(self._pad, y_local, self.group)
             for r in range(self.world):
                 y_full[self.bounds[r]:self.bounds[r + 1]] = \
                     self._pad[r * self.max_rows: r * self.max_rows + self.sizes[r]]
@@ -109,14 +133,14 @@ def exchange_transpose_entries(rows_global, cols_global, vals, col_bounds, group
     if world == 1:
         return (cols_global[order] - lo), rows_global[order], (None if vals is None else vals[order])
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    all_to_all(recv_counts, send_counts, group=group)
     s_split = [int(v) for v in send_counts.cpu()]
     r_split = [int(v) for v in recv_counts.cpu()]
     n_recv = sum(r_split)
 
     def xchg(t):
         out = torch.empty(n_recv, dtype=t.dtype, device=t.device)
-        dist.all_to_all_single(out, t[order].contiguous(), r_split, s_split, group=group)
+        all_to_all(out, t[order].contiguous(), r_split, s_split, group=group)
         return out
 
     at_rows = xchg(cols_global) - lo
