@@ -5,14 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload: per GPU a CSR shard of 10 000 000 rows x 16 non-zeros, columns uniform over
-the global column range, values uniform(-1,1), generated on the device by the counter-based generator
-(seed 0x5EED0002, identical on CPU).  N = 1 is exactly config 2 (10M x 10M).  N > 1 is the weak-scaling
-form of config 5's scheme: the global matrix is (N*10M) x (N*10M), rank r owns rows [r*10M, (r+1)*10M) of A
-and of A' (the latter built once by an all-to-all of the entries), x is replicated, and each product is a
-local SpMV followed by an RCCL all-gather of the y shards.
+10 000 000 columns, values uniform(-1,1), generated on the device by the counter-based generator (seed
+0x5EED0002, identical on CPU).  N = 1 is exactly config 2 (10M x 10M).  N > 1 is weak scaling by rows, the
+partition config 5 names: the global matrix is (N*10M) x 10M, rank r owns rows [r*10M, (r+1)*10M) -- a
+config-2 matrix of its own -- x (80 MB) is replicated, y = A x is a local SpMV followed by the RCCL
+all-gather of the y shards, and z = A' u is the local transposed product of the rank's rows with its slice
+of u followed by an RCCL all-reduce (sum) of the 80 MB partial results.
 
-One step = y = A x  then  z = A' u  (two launches of the L2-tiled SpMV kernel per rank, plus the two
-all-gathers when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
+One step = y = A x  then  z = A' u  (two launches of the L2-tiled SpMV kernel per rank, plus one all-gather
+and one all-reduce when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
 Algorithmic bytes per product: 12*nnz + 4*(nrow+1) + 8*nrow + 8*ncol.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = spmv_tiled_kernel, HIP-event timed
@@ -94,63 +95,49 @@ def main():
     capi.lib()
 
     n_local, per = args.rows, args.per_row
-    n_global = n_local * world
+    ncol = n_local                      # column space stays config 2's: every rank's shard is a config-2 matrix
+    n_global = n_local * world          # global rows
     lo = rank * n_local
     st = capi.current_stream()
 
-    # ---- this rank's shard of A (rows lo .. lo+n_local, global columns) -----------------------------
-    rp, cc, vv = capi.synth_uniform(n_local, n_global, per, SEED, row_offset=lo)
-    A = capi.Matrix.from_csr(n_local, n_global, rp, cc, vv, borrow=True)
+    # ---- this rank's shard: rows lo .. lo+n_local of the (N*10M) x 10M matrix ------------------------
+    rp, cc, vv = capi.synth_uniform(n_local, ncol, per, SEED, row_offset=lo)
+    A = capi.Matrix.from_csr(n_local, ncol, rp, cc, vv, borrow=True)
+    A.build_transpose(st)
     bounds = fsd.even_row_partition(n_global, world)
-    if world == 1:
-        A.build_transpose(st)
-        At = None
-        t_spmv = lambda y, x: A.spmv(y, x, capi.current_stream(), transposed=True)   # noqa: E731
-        bytes_t = A.algorithmic_bytes()
-    else:
-        rows_g = torch.arange(lo, lo + n_local, device=dev, dtype=torch.int32).repeat_interleave(per)
-        tr, tc, tv = fsd.exchange_transpose_entries(rows_g, cc, vv, bounds)
-        del rows_g
-        At = capi.Matrix.from_coo(n_local, n_global, tr.to(torch.int32), tc, tv)
-        del tr, tc, tv
-        t_spmv = fsd.hip_local_spmv(At)
-        bytes_t = At.algorithmic_bytes()
     bytes_a = A.algorithmic_bytes()
+    bytes_t = bytes_a                   # same entries, nrow and ncol swap roles (both 10M here)
     op_a = fsd.ShardedOperator(fsd.hip_local_spmv(A), bounds)
-    op_t = fsd.ShardedOperator(t_spmv, bounds)
+    op_t = fsd.TransposedShardedOperator(
+        lambda z, u_local: A.spmv(z, u_local, capi.current_stream(), transposed=True), bounds)
 
-    i = torch.arange(n_global, device=dev, dtype=torch.float64)
-    x = torch.sin(7.0 * i + 0.3)           # bench_a_mul_b.c:142
-    u = torch.sin(11.0 * i - 0.2)          # second column of X2col, bench_a_mul_b.c:145
-    del i
+    x = torch.sin(7.0 * torch.arange(ncol, device=dev, dtype=torch.float64) + 0.3)        # bench_a_mul_b.c:142
+    u = torch.sin(11.0 * torch.arange(n_global, device=dev, dtype=torch.float64) - 0.2)   # 2nd column of X2col, :145
     y = torch.empty(n_global, dtype=torch.float64, device=dev)
-    z = torch.empty(n_global, dtype=torch.float64, device=dev)
+    z = torch.empty(ncol, dtype=torch.float64, device=dev)
 
-    def step(events=None):
-        if events is not None:
-            events[0].record()
-        op_a.apply(y, x)
-        if events is not None:
-            events[1].record()
-        op_t.apply(z, u)
-        if events is not None:
-            events[2].record()
-
-    def local_only(events):
-        """kernel-only timing of the two local products (no collective), for the roofline object"""
-        yl, zl = y[:n_local], z[:n_local]
-        events[0].record()
-        op_a.apply_local(yl, x)
-        events[1].record()
-        op_t.apply_local(zl, u)
-        events[2].record()
+    def step(ev=None):
+        """one step; with ev, HIP events bracket each local kernel on the launch stream: ev[0]|A x|ev[1] all-gather
+        ev[2]|A' u|ev[3] all-reduce"""
+        if ev is not None:
+            ev[0].record()
+        yl = op_a.local(y, x)
+        if ev is not None:
+            ev[1].record()
+        op_a.gather(y, yl)
+        if ev is not None:
+            ev[2].record()
+        op_t.apply_local(z, u)
+        if ev is not None:
+            ev[3].record()
+        op_t.reduce(z)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -164,17 +151,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-launch durations of the dominant kernel inside the timed region (HIP events on the launch stream).
-    # With N > 1 the interval e0->e1 also holds the all-gather, so the kernel-only figure is re-measured below.
+    # per-launch durations of the dominant kernel inside the timed region (HIP events on the launch stream)
     ka = [e[0].elapsed_time(e[1]) for e in evs]
-    kt = [e[1].elapsed_time(e[2]) for e in evs]
-    if world > 1:
-        evs2 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-        for k in range(args.steps):
-            local_only(evs2[k])
-        torch.cuda.synchronize()
-        ka = [e[0].elapsed_time(e[1]) for e in evs2]
-        kt = [e[1].elapsed_time(e[2]) for e in evs2]
+    kt = [e[2].elapsed_time(e[3]) for e in evs]
     launches = 2 * args.steps
     avg_ms = (sum(ka) + sum(kt)) / launches
     bytes_per_launch = (bytes_a + bytes_t) / 2.0
@@ -198,9 +177,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B"
-                                   % (n_global, n_global, per) if world == 1 else
-                                   "config-2 shards, weak scaling: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
-                                   "(A_mul_B + all-gather y) + (At_mul_B + all-gather z)" % (n_global, n_global, n_local, per),
+                                   % (n_global, ncol, per) if world == 1 else
+                                   "config-2 shards, weak scaling by rows: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
+                                   "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (n_global, ncol, n_local, per),
                        "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
                        "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
                        "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt)},
@@ -211,7 +190,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                rec["cpu_baseline"] = cpu_baseline(n_local, n_global, per)
+                rec["cpu_baseline"] = cpu_baseline(n_local, ncol, per)
             except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
                 rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(rec), flush=True)

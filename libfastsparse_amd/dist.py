@@ -97,13 +97,21 @@ class ShardedOperator:
     def apply_local(self, y_local, x_full):
         self.local_spmv(y_local, x_full)
 
-    def apply(self, y_full, x_full):
+    def local(self, y_full, x_full):
+        """local product only; returns the tensor `gather` has to be called with"""
         n_local = self.hi - self.lo
         if self.world == 1:
             self.local_spmv(y_full, x_full)
             return y_full
         y_local = self._buffers(y_full)
         self.local_spmv(y_local[:n_local], x_full)
+        return y_local
+
+    def gather(self, y_full, y_local):
+        """the exchange step: all-gather of the y shards (no-op on one rank)"""
+        if self.world == 1:
+            return y_full
+        n_local = self.hi - self.lo
         if self.equal:
             all_gather_into(y_full, y_local[:n_local], self.group)
         else:
@@ -112,6 +120,45 @@ class ShardedOperator:
                 y_full[self.bounds[r]:self.bounds[r + 1]] = \
                     self._pad[r * self.max_rows: r * self.max_rows + self.sizes[r]]
         return y_full
+
+    def apply(self, y_full, x_full):
+        return self.gather(y_full, self.local(y_full, x_full))
+
+
+def all_reduce_sum(t, group=None):
+    if _host_collective(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+class TransposedShardedOperator:
+    """z = A' u for a row-sharded A: every rank multiplies its own rows' transpose with its own slice of u
+    (z_r = A_r' u_r, a full-length vector) and the partial results are summed by an all-reduce.
+    `local_tspmv(z_full, u_local)` is the local transposed product (cached CSR of A_r' on the GPU)."""
+
+    def __init__(self, local_tspmv, bounds, group=None):
+        self.local_tspmv = local_tspmv
+        self.bounds = list(bounds)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+
+    def apply_local(self, z_full, u_full):
+        self.local_tspmv(z_full, u_full[self.lo:self.hi])
+
+    def reduce(self, z_full):
+        """the exchange step: sum of the partial results over the ranks (no-op on one rank)"""
+        if self.world > 1:
+            all_reduce_sum(z_full, self.group)
+        return z_full
+
+    def apply(self, z_full, u_full):
+        self.apply_local(z_full, u_full)
+        return self.reduce(z_full)
 
 
 def exchange_transpose_entries(rows_global, cols_global, vals, col_bounds, group=None):

@@ -72,6 +72,17 @@ def _worker(rank, world, port, mode, ret):
         rows_all = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
         zref = O.coo_tmul(n, rows_all, cc, vv, x)                  # column sums in ascending-row order
         ok = ok and np.array_equal(z.numpy(), zref)
+        # transposed direction, second scheme (bench.py): local A_r' u_r, partial results summed by all-reduce
+        rows_l = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(lrp))
+
+        def local_tspmv2(z_full, u_local):
+            z_full.copy_(torch.from_numpy(O.coo_tmul(n, rows_l, lcc, lvv, u_local.numpy())))
+
+        opr = fsd.TransposedShardedOperator(local_tspmv2, bounds)
+        z2 = torch.full((n,), -1.0, dtype=torch.float64)
+        opr.apply(z2, torch.from_numpy(x))
+        scale = O.coo_tmul(n, rows_all, cc, np.abs(vv), np.abs(x))
+        ok = ok and bool(np.all(np.abs(z2.numpy() - zref) <= 1e-12 * np.maximum(scale, 1e-300)))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
