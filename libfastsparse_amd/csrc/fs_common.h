@@ -42,11 +42,12 @@ struct DeviceCsr {
 // columns (x slice L2-resident).  Entries are ordered by (panel, band), then row, then CSR order.
 // An entry is one 32-bit word  local row:(32-lcol_bits) | local col:lcol_bits  plus its value.
 // Work items are runs of at most kTiledItem consecutive entries of one (panel, band) tile.
-constexpr int kTiledBlock = 512;       // threads per workgroup of the tiled kernel: ONE workgroup per CU.  Two
-                                       // co-resident 256-thread workgroups were measured to run at different
-                                       // speeds (the older one wins issue arbitration: 401 vs 450 us per panel),
-                                       // which pulls the band sweep of an XCD apart and out of its L2.
-constexpr int kTiledItem = 4096;       // entries per work item (8 per thread)
+constexpr int kTiledBlock = 1024;      // threads per workgroup of the tiled kernel: ONE workgroup per CU (two
+                                       // co-resident workgroups were measured to run at different speeds -- the
+                                       // older one wins issue arbitration, 401 vs 450 us per panel -- which pulls
+                                       // the band sweep of an XCD apart and out of its L2)
+constexpr int kTiledProd = 512;        // waves 0-7 produce (stream + gather), waves 8-15 consume (LDS reduction)
+constexpr int kTiledItem = 2048;       // entries per work item (4 per producer thread)
 constexpr int kTiledRowsMax = 13056;   // R <= this: 102 KiB of y per workgroup
 constexpr int kTiledColBits = 18;      // W <= 262144 columns (2 MiB of x); the other 14 bits are the local row
 
@@ -58,12 +59,7 @@ struct TiledCsr {
   int4 *items = nullptr;       // nitems: {first entry, count, band, 0}
   int *item_ptr = nullptr;     // P + 1
   int nitems = 0;
-  // pace gates of the tiled kernel (see spmv_tiled_kernel): one counter per (generation, XCD label, gate)
-  int *gate_cnt = nullptr;
-  int gate_bands = 0;          // bands between gates (0 = no gates)
-  int ngates = 0;              // gates per sweep (+1)
   int slots = 256;             // workgroups resident together (1 per CU)
-  int epoch = 0;               // launches so far (counters are monotonic)
 };
 
 }  // namespace fs
@@ -103,7 +99,6 @@ struct Options {
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
   int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
-  int gate_kb = 0;       // x progress between two pace gates of the tiled kernel, KiB (0 = no gates)
 };
 Options &options();
 

@@ -33,7 +33,6 @@ void free_csr(DeviceCsr &A)
     if (A.tiled->vals) (void)hipFree(A.tiled->vals);
     if (A.tiled->items) (void)hipFree(A.tiled->items);
     if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
-    if (A.tiled->gate_cnt) (void)hipFree(A.tiled->gate_cnt);
     delete A.tiled;
   }
   A = DeviceCsr();
@@ -362,17 +361,7 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
   FS_HIP(hipFree(tmp)); FS_HIP(hipFree(rows)); FS_HIP(hipFree(keys)); FS_HIP(hipFree(skeys));
   FS_HIP(hipFree(idx_in)); FS_HIP(hipFree(idx_out)); FS_HIP(hipFree(tile_ptr));
-  // pace gates: every gate_kb KiB of x progress
   T->slots = slots;
-  T->gate_bands = 0;
-  if (o.gate_kb > 0) {
-    int gb = (int)(((int64_t)o.gate_kb * 1024) / ((int64_t)W * 8));
-    T->gate_bands = gb < 1 ? 1 : gb;
-  }
-  T->ngates = (T->gate_bands > 0 ? J / T->gate_bands : 0) + 2;
-  const size_t ncnt = (size_t)((P + slots - 1) / slots) * 8 * (size_t)T->ngates;
-  FS_HIP(hipMalloc(&T->gate_cnt, sizeof(int) * ncnt));
-  FS_HIP(hipMemset(T->gate_cnt, 0, sizeof(int) * ncnt));
   T->built = true;
   return FS_OK;
 }

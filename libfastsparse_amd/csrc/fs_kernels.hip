@@ -228,21 +228,22 @@ __global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__
 // different runs are distinct inside an item, so plain LDS read-add-write is race free).
 // The next item's entries are loaded while the current one is being reduced.
 // ------------------------------------------------------------------------------------------
-constexpr int kTiledPer = kTiledItem / kTiledBlock;  // 8 entries per thread
+constexpr int kTiledPer = kTiledItem / kTiledProd;  // 4 entries per producer (and per consumer) thread
 
-// entries of one item for this thread: position q*512 + t.  Whole 512-entry slabs past the item's end
-// are skipped (wave-uniform test); inside the last slab the position is clamped to the last entry, so
-// the loads themselves are unconditional and the clamped lanes re-read one cached word.
+// ---- producer side (waves 0-7): entries of one item for producer thread tp are positions q*512 + tp.
+// Whole 512-entry slabs past the item's end are skipped (wave-uniform test); inside the last slab the
+// position is clamped to the last entry, so the loads themselves are unconditional and the clamped lanes
+// re-read one cached word.
 template <bool VALUED, bool NT>
-__device__ __forceinline__ void tiled_load(const int4 d, int t, const unsigned *__restrict__ pk,
+__device__ __forceinline__ void tiled_load(const int4 d, int tp, const unsigned *__restrict__ pk,
                                            const double *__restrict__ vals, unsigned (&w)[kTiledPer],
                                            double (&v)[kTiledPer])
 {
   const int last = d.y > 0 ? d.y - 1 : 0;
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q) {
-    if (q * kTiledBlock < d.y || q == 0) {
-      const int pos = q * kTiledBlock + t;
+    if (q * kTiledProd < d.y || q == 0) {
+      const int pos = q * kTiledProd + tp;
       const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
       w[q] = stream_load<NT>(pk + e);
       if (VALUED) v[q] = stream_load<NT>(vals + e);
@@ -256,61 +257,67 @@ __device__ __forceinline__ void tiled_gather(const int4 d, int W, unsigned cmask
   const double *xb = x + (int64_t)d.z * W;
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q)
-    if (q * kTiledBlock < d.y || q == 0) xv[q] = xb[w[q] & cmask];
+    if (q * kTiledProd < d.y || q == 0) xv[q] = xb[w[q] & cmask];
 }
 
-// LDS phases of one item: products and packed words to the stage buffers, then (after the barrier placed
-// by the caller) every entry that starts a row-run adds the run's sum to its row of the y slice.
+// products and packed words of one item into a stage buffer (entry i at spk[i + 1]; spk[0], spk[n + 1] guards)
 template <bool VALUED>
-__device__ __forceinline__ void tiled_stage(double *__restrict__ sprod, unsigned *__restrict__ spk, int t, int n,
+__device__ __forceinline__ void tiled_stage(double *__restrict__ sprod, unsigned *__restrict__ spk, int tp, int n,
                                             const unsigned (&w)[kTiledPer], const double (&v)[kTiledPer],
                                             const double (&xv)[kTiledPer])
 {
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q) {
-    const int pos = q * kTiledBlock + t;
+    const int pos = q * kTiledProd + tp;
     if (pos < n) {
       sprod[pos] = VALUED ? xv[q] * v[q] : xv[q];
       spk[pos + 1] = w[q];
     }
   }
-  if (t == 0) { spk[0] = 0xFFFFFFFFu; spk[n + 1] = 0xFFFFFFFFu; }  // row id no entry has: runs stop at both ends
+  if (tp == 0) { spk[0] = 0xFFFFFFFFu; spk[n + 1] = 0xFFFFFFFFu; }  // row id no entry has: runs stop at both ends
 }
 
-template <bool ATOMIC>
+// ---- consumer side (waves 8-15): every entry that starts a row-run adds the run's sum to its row of the
+// y slice.  The runs of one item are distinct rows: one add per address, so the LDS atomic (fire and forget,
+// no read-add-write chain in the wave) gives the same bits as a plain update, in a fixed order.
 __device__ __forceinline__ void tiled_reduce(double *__restrict__ ytile, const double *__restrict__ sprod,
-                                             const unsigned *__restrict__ spk, int t, int n, int lcol_bits,
-                                             const unsigned (&w)[kTiledPer])
+                                             const unsigned *__restrict__ spk, int tc, int n, int lcol_bits)
 {
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q) {
-    const int pos = q * kTiledBlock + t;
+    const int pos = q * kTiledProd + tc;
     if (pos < n) {
-      const unsigned lr = w[q] >> lcol_bits;
+      const unsigned lr = spk[pos + 1] >> lcol_bits;
       if ((spk[pos] >> lcol_bits) != lr) {  // previous entry is another row (or the item's start): run head
         double sum = sprod[pos];
         int k = pos + 1;
         while ((spk[k + 1] >> lcol_bits) == lr) { sum += sprod[k]; ++k; }
-        // the runs of one item are distinct rows: one add per address, so the LDS atomic (fire and forget,
-        // no read-add-write dependency chain in the wave) gives the same bits as a plain update
-        if (ATOMIC) __hip_atomic_fetch_add(&ytile[lr], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else ytile[lr] += sum;
+        __hip_atomic_fetch_add(&ytile[lr], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
 }
 
-template <bool VALUED, bool NT, bool ATOMIC, bool DEBUG = false>
-__global__ __launch_bounds__(kTiledBlock, 2) void spmv_tiled_kernel(
+// ONE 1024-thread workgroup per CU and row panel.  Waves 0-7 are producers: they stream the panel's
+// entries, gather x inside the current column band and park products in one of two LDS stage buffers.
+// Waves 8-15 are consumers: they reduce the other stage buffer into the y slice.  One barrier per item
+// separates the roles' phases, so the LDS reduction of item k-1 overlaps the memory work of items k..k+3.
+// Producer software pipeline: four register sets rotate by name (a register copy would force in-flight
+// loads to complete); while item k is staged, the gathers of k+1 and k+2 and the entry loads of k+3 are in
+// flight.  Inside a phase the loads of k+3 are issued before the gathers of k+2: vmcnt retires in order
+// and the loads are needed one phase earlier than the gathers issued with them.
+template <bool VALUED, bool NT, bool DEBUG = false>
+__global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
     int nrow, int R, int W, int lcol_bits, const int4 *__restrict__ items, const int *__restrict__ item_ptr,
     const unsigned *__restrict__ pk, const double *__restrict__ vals, const double *__restrict__ x,
-    double *__restrict__ y, int *__restrict__ gate_cnt, int gate_bands, int ngates, int slots, int nblocks, int epoch,
-    long long *__restrict__ dbg_time = nullptr, int *__restrict__ dbg_xcc = nullptr)
+    double *__restrict__ y, long long *__restrict__ dbg_time = nullptr, int *__restrict__ dbg_xcc = nullptr)
 {
   __shared__ double ytile[kTiledRowsMax];
-  __shared__ double sprod[kTiledItem];
-  __shared__ unsigned spk[kTiledItem + 2];  // entry i at spk[i + 1]; spk[0] and spk[n + 1] are guards
+  __shared__ double sprod[2][kTiledItem];
+  __shared__ unsigned spk[2][kTiledItem + 2];
   const int t = threadIdx.x;
+  const bool producer = t < kTiledProd;      // wave-uniform: waves 0-7
+  const int tr = producer ? t : t - kTiledProd;  // index inside the role
   const int p = blockIdx.x;
   const int row0 = p * R;
   const int nr = (nrow - row0 < R) ? nrow - row0 : R;
@@ -319,81 +326,48 @@ __global__ __launch_bounds__(kTiledBlock, 2) void spmv_tiled_kernel(
   const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
   const int4 none = make_int4(0, 0, 0, 0);  // an empty item: loads entry 0, contributes nothing
 #define FS_ITEM(i) ((i) < it1 ? items[(i)] : none)
-
   if (DEBUG && t == 0) {  // diagnostic build only: which XCD runs this panel, and when each item starts
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     dbg_xcc[p] = (int)(xcc & 0xf);
   }
-#define FS_STAMP(i) do { if (DEBUG && t == 0) dbg_time[(i)] = (long long)wall_clock64(); } while (0)
-  // Pace gates (speed only, never correctness; off by default): the workgroups dispatched together that
-  // share an XCD (same blockIdx % 8 under round-robin placement, same generation of `slots` resident
-  // workgroups) can wait for each other every `gate_bands` column bands.  Every wait is bounded (~20 us) and
-  // nothing is communicated.  Counters are never reset: launch `epoch` waits for epoch * members arrivals.
-  int gate_done = 0, gate_members = 0, gate_base = 0;
-  if (gate_bands > 0) {
-    const int gen = p / slots, label = p & 7;
-    const int g_lo = gen * slots, g_hi = (g_lo + slots < nblocks) ? g_lo + slots : nblocks;
-    gate_members = (g_hi - g_lo - label + 7) / 8;  // blocks b in [g_lo, g_hi) with b % 8 == label (g_lo % 8 == 0)
-    if (gate_members < 0) gate_members = 0;
-    gate_base = (gen * 8 + label) * ngates;
-  }
-#define FS_GATE(D)                                                                                         \
-  do {                                                                                                     \
-    if (gate_bands > 0 && t == 0) {                                                                        \
-      const int g = (D).z / gate_bands;                                                                    \
-      if (g > gate_done) {                                                                                 \
-        for (int gg = gate_done + 1; gg <= g; ++gg)                                                        \
-          __hip_atomic_fetch_add(&gate_cnt[gate_base + gg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-        const int want = gate_members * epoch;                                                             \
-        const long long t_end = (long long)wall_clock64() + 2000; /* 20 us at 100 MHz */                   \
-        while (__hip_atomic_load(&gate_cnt[gate_base + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && \
-               (long long)wall_clock64() < t_end)                                                          \
-          __builtin_amdgcn_s_sleep(8);                                                                     \
-        gate_done = g;                                                                                     \
-      }                                                                                                    \
-    }                                                                                                      \
-  } while (0)
-
-  // Software pipeline over the panel's items, unrolled four times so that the four register sets rotate by
-  // name (a register copy would force in-flight loads to complete).  While item k goes through LDS, the
-  // gathers of items k+1 and k+2 and the entry loads of item k+3 are in flight.  Issue order inside a step
-  // is "loads of k+3, then gathers of k+2": vmcnt retires in order, and the loads are needed one step
-  // earlier than the gathers issued in the same step.
-  int4 dA = FS_ITEM(it0), dB = FS_ITEM(it0 + 1), dC = FS_ITEM(it0 + 2), dD = none;
+  int4 dA = none, dB = none, dC = none, dD = none;
   unsigned wA[kTiledPer], wB[kTiledPer], wC[kTiledPer], wD[kTiledPer];
   double vA[kTiledPer], vB[kTiledPer], vC[kTiledPer], vD[kTiledPer];
   double xA[kTiledPer], xB[kTiledPer], xC[kTiledPer], xD[kTiledPer];
-  tiled_load<VALUED, NT>(dA, t, pk, vals, wA, vA);
-  tiled_load<VALUED, NT>(dB, t, pk, vals, wB, vB);
-  tiled_load<VALUED, NT>(dC, t, pk, vals, wC, vC);
-  tiled_gather(dA, W, cmask, x, wA, xA);
-  tiled_gather(dB, W, cmask, x, wB, xB);
+  if (producer) {
+    dA = FS_ITEM(it0); dB = FS_ITEM(it0 + 1); dC = FS_ITEM(it0 + 2);
+    tiled_load<VALUED, NT>(dA, tr, pk, vals, wA, vA);
+    tiled_load<VALUED, NT>(dB, tr, pk, vals, wB, vB);
+    tiled_load<VALUED, NT>(dC, tr, pk, vals, wC, vC);
+    tiled_gather(dA, W, cmask, x, wA, xA);
+    tiled_gather(dB, W, cmask, x, wB, xB);
+  }
   __syncthreads();  // ytile zeroed
-  // one step: item in set 0 is reduced; set 2 gets its gathers; set 3 gets the loads of the item three ahead
-#define FS_STEP(IT, D0, W0, V0, X0, D2, W2, X2, D3, W3, V3)          \
-  D3 = FS_ITEM((IT) + 3);                                            \
-  FS_STAMP(IT);                                                      \
-  FS_GATE(D0);                                                       \
-  tiled_stage<VALUED>(sprod, spk, t, D0.y, W0, V0, X0);              \
-  __syncthreads();                                                   \
-  tiled_load<VALUED, NT>(D3, t, pk, vals, W3, V3);                   \
-  tiled_gather(D2, W, cmask, x, W2, X2);                             \
-  tiled_reduce<ATOMIC>(ytile, sprod, spk, t, D0.y, lcol_bits, W0);   \
+  // phase IT: producers stage item IT (register set 0) into buffer IT&1, then issue the loads of IT+3
+  // (set 3) and the gathers of IT+2 (set 2); consumers reduce item IT-1 from the other buffer.
+#define FS_PHASE(IT, D0, W0, V0, X0, D2, W2, X2, D3, W3, V3)                                   \
+  if (producer) {                                                                              \
+    if (DEBUG && t == 0 && (IT) < it1) dbg_time[(IT)] = (long long)wall_clock64();             \
+    if ((IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
+    D3 = FS_ITEM((IT) + 3);                                                                    \
+    tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                                          \
+    tiled_gather(D2, W, cmask, x, W2, X2);                                                     \
+  } else if ((IT) > it0) {                                                                     \
+    tiled_reduce(ytile, sprod[((IT) - 1) & 1], spk[((IT) - 1) & 1], tr, items[(IT) - 1].y, lcol_bits); \
+  }                                                                                            \
   __syncthreads();
-  for (int it = it0; it < it1; it += 4) {
-    FS_STEP(it, dA, wA, vA, xA, dC, wC, xC, dD, wD, vD)
-    if (it + 1 >= it1) break;
-    FS_STEP(it + 1, dB, wB, vB, xB, dD, wD, xD, dA, wA, vA)
-    if (it + 2 >= it1) break;
-    FS_STEP(it + 2, dC, wC, vC, xC, dA, wA, xA, dB, wB, vB)
-    if (it + 3 >= it1) break;
-    FS_STEP(it + 3, dD, wD, vD, xD, dB, wB, xB, dC, wC, vC)
+  for (int it = it0; it <= it1; it += 4) {
+    FS_PHASE(it, dA, wA, vA, xA, dC, wC, xC, dD, wD, vD)
+    if (it + 1 > it1) break;
+    FS_PHASE(it + 1, dB, wB, vB, xB, dD, wD, xD, dA, wA, vA)
+    if (it + 2 > it1) break;
+    FS_PHASE(it + 2, dC, wC, vC, xC, dA, wA, xA, dB, wB, vB)
+    if (it + 3 > it1) break;
+    FS_PHASE(it + 3, dD, wD, vD, xD, dB, wB, xB, dC, wC, vC)
   }
 #undef FS_ITEM
-#undef FS_STEP
-#undef FS_STAMP
-#undef FS_GATE
+#undef FS_PHASE
   for (int i = t; i < nr; i += kTiledBlock) y[row0 + i] = ytile[i];
 }
 
@@ -519,21 +493,13 @@ static int ceil_log2(int v)
 
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
 {
-  TiledCsr &T = *A.tiled;
-  const int f = options().tiled_flags;  // bit 0: cached (not nt) entry loads, bit 1: plain LDS update instead of atomic
-  const int gate_bands = (f & 4) ? 0 : T.gate_bands;  // bit 2: no pace gates
-  const int epoch = gate_bands > 0 ? ++T.epoch : 0;
-#define FS_TILED(V, N, AT)                                                                                        \
-  hipLaunchKernelGGL((spmv_tiled_kernel<V, N, AT>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, \
-                     T.items, T.item_ptr, T.pk, T.vals, x, y, T.gate_cnt, gate_bands, T.ngates, T.slots, T.P, epoch)
-  const bool nt = !(f & 1), at = !(f & 2);
-  if (A.vals) {
-    if (nt && at) FS_TILED(true, true, true); else if (nt) FS_TILED(true, true, false);
-    else if (at) FS_TILED(true, false, true); else FS_TILED(true, false, false);
-  } else {
-    if (nt && at) FS_TILED(false, true, true); else if (nt) FS_TILED(false, true, false);
-    else if (at) FS_TILED(false, false, true); else FS_TILED(false, false, false);
-  }
+  const TiledCsr &T = *A.tiled;
+  const bool nt = !(options().tiled_flags & 1);  // bit 0: cached (not nt) entry loads
+#define FS_TILED(V, N)                                                                                          \
+  hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, \
+                     T.items, T.item_ptr, T.pk, T.vals, x, y)
+  if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
+  else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
 #undef FS_TILED
   FS_HIP(hipGetLastError());
   return FS_OK;
@@ -544,17 +510,13 @@ int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
                             hipStream_t s)
 {
-  TiledCsr &T = *A.tiled;
-  const int gate_bands = (options().tiled_flags & 4) ? 0 : T.gate_bands;
-  const int epoch = gate_bands > 0 ? ++T.epoch : 0;
+  const TiledCsr &T = *A.tiled;
   if (A.vals)
-    hipLaunchKernelGGL((spmv_tiled_kernel<true, true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, T.gate_cnt, gate_bands, T.ngates, T.slots,
-                       T.P, epoch, times_dev, xcc_dev);
+    hipLaunchKernelGGL((spmv_tiled_kernel<true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
+                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, times_dev, xcc_dev);
   else
-    hipLaunchKernelGGL((spmv_tiled_kernel<false, true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, T.gate_cnt, gate_bands, T.ngates, T.slots,
-                       T.P, epoch, times_dev, xcc_dev);
+    hipLaunchKernelGGL((spmv_tiled_kernel<false, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
+                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, times_dev, xcc_dev);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

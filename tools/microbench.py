@@ -53,7 +53,6 @@ def main():
     capi.set_option("tile_rows", args.tile_rows)
     capi.set_option("tile_cols", args.tile_cols)
     capi.set_option("tiled_flags", args.tiled_flags)
-    capi.set_option("gate_kb", args.gate_kb)
     n = args.rows
     if "probes" in what:
         a = torch.empty(240_000_000, dtype=torch.float64, device="cuda").normal_()

@@ -22,7 +22,6 @@ ap.add_argument("--gate-kb", type=int, default=8192)
 a = ap.parse_args()
 capi.set_option("tile_rows", a.tile_rows)
 capi.set_option("tile_cols", a.tile_cols)
-capi.set_option("gate_kb", a.gate_kb)
 n = a.rows
 rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
 A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
