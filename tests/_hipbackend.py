@@ -69,9 +69,12 @@ class HipDeviceBackend:
         return Y.reshape(nrow, k) if k > 1 else Y
 
     def cbcsr_mul(self, nrow, ncol, rows, cols, cbs, x):
-        from oracle import pyoracle as O   # format builder only (checker-side helper)
-        nb, rp, cc = O.coo_to_cbcsr(cbs, nrow, ncol, rows, cols)
-        m = capi.ColBlockMatrix(nrow, ncol, nb, cbs, self._d(rp), self._d(cc))
+        # format built by the product's own host constructor (new_cbcsr, fs_host.c), then uploaded
+        F = HostFormats()
+        K = F.cbcsr(cbs, nrow, ncol, np.ascontiguousarray(rows), np.ascontiguousarray(cols))
+        rp = F.arr(K.row_ptr, K.nblocks * nrow + 1, np.int32)
+        cc = F.arr(K.cols, len(rows), np.int32)
+        m = capi.ColBlockMatrix(nrow, ncol, K.nblocks, cbs, self._d(rp), self._d(cc))
         y = self._out(nrow)
         m.spmv(y, self._d(x), capi.current_stream())
         return y.cpu().numpy()

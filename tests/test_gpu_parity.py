@@ -234,3 +234,63 @@ def test_c_bench_driver_config1(hip):
             assert p.returncode == 0, p.stderr
             got = [ln.split("]")[0][1:] for ln in p.stdout.splitlines() if ln.startswith("[") and "Wall:" in ln]
             assert got == labels + extra, (fixture, flags, got)
+
+
+@pytest.mark.parametrize("shape", [(1_000_000, 1_000_000, 8, True), (700_000, 2_000_000, 12, False), (300_000, 600_000, 40, True)])
+def test_tiled_auto_geometry_midsize_vs_oracle(hip, shape):
+    """matrices big enough for the format builder to choose the L2-tiled kernel by itself (x > 3 MB, > 4 M
+    non-zeros): every row against the oracle, row-scaled 1e-12 bound; pattern-only + integer x bit-exact"""
+    import torch
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    nrow, ncol, per, valued = shape
+    rp, cc, vv = capi.synth_uniform(nrow, ncol, per, 0xABC + nrow, valued=valued)
+    A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+    hrp, hcc, hvv = pysynth.uniform(nrow, ncol, per, 0xABC + nrow, valued=valued)
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    xs = S.x_sin(ncol)
+    A.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+    ref = O.csr_mul(nrow, hrp, hcc, hvv, xs)
+    scale = O.csr_abs_scale(nrow, hrp, hcc, hvv, xs)
+    assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(scale, 1e-300))
+    xi = S.x_int(9, ncol)
+    A.spmv(y, torch.from_numpy(xi).cuda(), capi.current_stream())
+    ref = O.csr_mul(nrow, hrp, hcc, hvv, xi)
+    if valued:
+        scale = O.csr_abs_scale(nrow, hrp, hcc, hvv, xi)
+        assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(scale, 1e-300))
+    else:
+        assert np.array_equal(y.cpu().numpy(), ref)
+    A.build_transpose(capi.current_stream())
+    z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+    xt = S.x_sin(nrow, 11.0, -0.2)
+    A.spmv(z, torch.from_numpy(xt).cuda(), capi.current_stream(), transposed=True)
+    rows = np.repeat(np.arange(nrow, dtype=np.int32), per)
+    zref = O.coo_tmul(ncol, rows, hcc, hvv, xt)
+    zscale = O.coo_tmul(ncol, rows, hcc, None if hvv is None else np.abs(hvv), np.abs(xt))
+    assert np.all(np.abs(z.cpu().numpy() - zref) <= TOL * np.maximum(zscale, 1e-300))
+
+
+def test_dropin_cache_invalidation(hip):
+    """the side table keyed by the host struct: a matrix changed in place is re-uploaded (fingerprint or
+    fs_invalidate), a freed one is dropped"""
+    import ctypes as C
+    be = hip.HipDropinBackend()
+    c = BY_NAME["syn_dup_1024"]
+    rows, cols = c.rows.copy(), c.cols.copy()
+    A = hip.SBM(c.nrow, c.ncol, len(rows), rows.ctypes.data_as(hip.ip), cols.ctypes.data_as(hip.ip))
+    x = S.x_int(4, c.ncol)
+    y = np.full(c.nrow, -1.0)
+    f = be.L.A_mul_B
+    f.restype = None
+    f(y.ctypes.data_as(hip.dp), C.byref(A), x.ctypes.data_as(hip.dp))
+    assert np.array_equal(y, O.coo_mul(c.nrow, rows, cols, None, x))
+    cols[:] = (cols + 1) % c.ncol                      # mutate in place: same pointers, new content
+    be.L.fs_invalidate(C.byref(A))
+    f(y.ctypes.data_as(hip.dp), C.byref(A), x.ctypes.data_as(hip.dp))
+    assert np.array_equal(y, O.coo_mul(c.nrow, rows, cols, None, x))
+    rows[:] = rows[::-1].copy()                        # no invalidate: the sampled fingerprint catches it
+    cols[:] = cols[::-1].copy()
+    f(y.ctypes.data_as(hip.dp), C.byref(A), x.ctypes.data_as(hip.dp))
+    assert np.array_equal(y, O.coo_mul(c.nrow, rows, cols, None, x))
+    be.L.fs_release_all()

@@ -106,6 +106,45 @@ def main():
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
+    if "dropin" in what:
+        # the reference-named entry point with HOST vectors and a host struct (what an unmodified C caller does):
+        # per call = fingerprint of the host arrays + 80 MB up + kernel + 80 MB down
+        import ctypes as C
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _hipbackend as H
+        from oracle import pysynth
+        rp, cc, vv = pysynth.uniform(n, n, 16, 0x5EED0002)
+        A = H.CSR(n, n, len(cc), rp.ctypes.data_as(H.ip), cc.ctypes.data_as(H.ip), vv.ctypes.data_as(H.dp))
+        xh = np.sin(7.0 * np.arange(n) + 0.3)
+        yh = np.empty(n)
+        L = capi.lib()
+        L.csr_A_mul_B.restype = None
+        t0 = time.time()
+        L.csr_A_mul_B(yh.ctypes.data_as(H.dp), C.byref(A), xh.ctypes.data_as(H.dp))
+        first = time.time() - t0
+        ts = []
+        for _ in range(10):
+            t0 = time.time()
+            L.csr_A_mul_B(yh.ctypes.data_as(H.dp), C.byref(A), xh.ctypes.data_as(H.dp))
+            ts.append((time.time() - t0) * 1e3)
+        ts.sort()
+        B = 12 * len(cc) + 4 * (n + 1) + 16 * n
+        rec = {"name": "dropin_csr_A_mul_B_host_vectors", "first_call_s_incl_upload": first, "ms_min": ts[0],
+               "ms_med": ts[5], "GBs_med": B / ts[5] / 1e6}
+        print(json.dumps(rec), flush=True)
+        out.write(json.dumps(rec) + "\n")
+        xd = torch.from_numpy(xh).cuda()
+        yd = torch.empty(n, dtype=torch.float64, device="cuda")
+        ts = []
+        for _ in range(10):
+            t0 = time.time()
+            L.csr_A_mul_B(C.c_void_p(yd.data_ptr()), C.byref(A), C.c_void_p(xd.data_ptr()))
+            ts.append((time.time() - t0) * 1e3)
+        ts.sort()
+        rec = {"name": "dropin_csr_A_mul_B_device_vectors", "ms_min": ts[0], "ms_med": ts[5], "GBs_med": B / ts[5] / 1e6}
+        print(json.dumps(rec), flush=True)
+        out.write(json.dumps(rec) + "\n")
     if "c5" in what:
         nrow = n
         rp, cc, vv = capi.synth_powerlaw(nrow, nrow, 2.3, 1_000_000, 0x5EED0005)
