@@ -110,7 +110,7 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
-int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s);
+int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
                             hipStream_t s);
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,

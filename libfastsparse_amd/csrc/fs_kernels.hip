@@ -251,13 +251,14 @@ __device__ __forceinline__ void tiled_load(const int4 d, int tp, const unsigned 
   }
 }
 
-__device__ __forceinline__ void tiled_gather(const int4 d, int W, unsigned cmask, const double *__restrict__ x,
+// x may be one column of a row-major k-column X: element c lives at x[c * xs] (xs = 1 for a plain vector)
+__device__ __forceinline__ void tiled_gather(const int4 d, int W, unsigned cmask, const double *__restrict__ x, int xs,
                                              const unsigned (&w)[kTiledPer], double (&xv)[kTiledPer])
 {
-  const double *xb = x + (int64_t)d.z * W;
+  const double *xb = x + (int64_t)d.z * W * xs;
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q)
-    if (q * kTiledProd < d.y || q == 0) xv[q] = xb[w[q] & cmask];
+    if (q * kTiledProd < d.y || q == 0) xv[q] = xb[(int64_t)(w[q] & cmask) * xs];
 }
 
 // products and packed words of one item into a stage buffer (entry i at spk[i + 1]; spk[0], spk[n + 1] guards)
@@ -310,7 +311,8 @@ template <bool VALUED, bool NT, bool DEBUG = false>
 __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
     int nrow, int R, int W, int lcol_bits, const int4 *__restrict__ items, const int *__restrict__ item_ptr,
     const unsigned *__restrict__ pk, const double *__restrict__ vals, const double *__restrict__ x,
-    double *__restrict__ y, long long *__restrict__ dbg_time = nullptr, int *__restrict__ dbg_xcc = nullptr)
+    double *__restrict__ y, int xs, int ys, long long *__restrict__ dbg_time = nullptr,
+    int *__restrict__ dbg_xcc = nullptr)
 {
   __shared__ double ytile[kTiledRowsMax];
   __shared__ double sprod[2][kTiledItem];
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
     tiled_load<VALUED, NT>(dA, tr, pk, vals, wA, vA);
     tiled_load<VALUED, NT>(dB, tr, pk, vals, wB, vB);
     tiled_load<VALUED, NT>(dC, tr, pk, vals, wC, vC);
-    tiled_gather(dA, W, cmask, x, wA, xA);
-    tiled_gather(dB, W, cmask, x, wB, xB);
+    tiled_gather(dA, W, cmask, x, xs, wA, xA);
+    tiled_gather(dB, W, cmask, x, xs, wB, xB);
   }
   __syncthreads();  // ytile zeroed
   // phase IT: producers stage item IT (register set 0) into buffer IT&1, then issue the loads of IT+3
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
     if ((IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
     D3 = FS_ITEM((IT) + 3);                                                                    \
     tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                                          \
-    tiled_gather(D2, W, cmask, x, W2, X2);                                                     \
+    tiled_gather(D2, W, cmask, x, xs, W2, X2);                                                 \
   } else if ((IT) > it0) {                                                                     \
     tiled_reduce(ytile, sprod[((IT) - 1) & 1], spk[((IT) - 1) & 1], tr, items[(IT) - 1].y, lcol_bits); \
   }                                                                                            \
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
   }
 #undef FS_ITEM
 #undef FS_PHASE
-  for (int i = t; i < nr; i += kTiledBlock) y[row0 + i] = ytile[i];
+  for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -491,13 +493,13 @@ static int ceil_log2(int v)
   return lg;
 }
 
-int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
+int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys)
 {
   const TiledCsr &T = *A.tiled;
   const bool nt = !(options().tiled_flags & 1);  // bit 0: cached (not nt) entry loads
 #define FS_TILED(V, N)                                                                                          \
   hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, \
-                     T.items, T.item_ptr, T.pk, T.vals, x, y)
+                     T.items, T.item_ptr, T.pk, T.vals, x, y, xs, ys)
   if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
   else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
 #undef FS_TILED
@@ -513,10 +515,10 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
   const TiledCsr &T = *A.tiled;
   if (A.vals)
     hipLaunchKernelGGL((spmv_tiled_kernel<true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, times_dev, xcc_dev);
+                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, 1, 1, times_dev, xcc_dev);
   else
     hipLaunchKernelGGL((spmv_tiled_kernel<false, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, times_dev, xcc_dev);
+                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, 1, 1, times_dev, xcc_dev);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -574,6 +576,15 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
 int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
+  // two right-hand sides (the block-CG case, bsbm_A_mul_B2 / bcsr_A_mul_B2) on a matrix with an L2-tiled copy:
+  // one tiled sweep per column of the
+  // row-major X / Y (strided gathers and stores) beats the row kernel, whose every X-row gather misses L2
+  if (k <= 2 && A.tiled && A.tiled->built && !options().strict_order &&
+      (options().spmv_kernel == 0 || options().spmv_kernel == 6)) {
+    for (int j = 0; j < k; ++j)
+      if (int rc = launch_spmv_tiled(A, Y + j, X + j, s, k, k)) return rc;
+    return FS_OK;
+  }
   int lg = ceil_log2(k > 64 ? 64 : k);
   const int gpb = kBlock >> lg;
   const unsigned grid = (unsigned)(((int64_t)A.nrow + gpb - 1) / gpb);

@@ -261,6 +261,16 @@ def test_tiled_auto_geometry_midsize_vs_oracle(hip, shape):
         assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(scale, 1e-300))
     else:
         assert np.array_equal(y.cpu().numpy(), ref)
+    # two / three right-hand sides go through the tiled kernel column by column (strided X / Y)
+    for k in (2, 3):
+        X = S.X_sin(ncol, k)
+        Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+        A.spmm(Y, torch.from_numpy(X).cuda(), k, capi.current_stream())
+        Yref = O.csr_mul_n(nrow, hrp, hcc, hvv, X, k)
+        Yg = Y.cpu().numpy()
+        for j in range(k):
+            sc = O.csr_abs_scale(nrow, hrp, hcc, hvv, np.ascontiguousarray(X[:, j]))
+            assert np.all(np.abs(Yg[:, j] - Yref[:, j]) <= TOL * np.maximum(sc, 1e-300)), (k, j)
     A.build_transpose(capi.current_stream())
     z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
     xt = S.x_sin(nrow, 11.0, -0.2)

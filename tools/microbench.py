@@ -106,6 +106,15 @@ def main():
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
+    if "spmm" in what:
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+        for k in (2, 3, 4, 8, 32):
+            X = torch.sin(torch.arange(n * k, device="cuda", dtype=torch.float64)).reshape(n, k)
+            Y = torch.empty(n, k, dtype=torch.float64, device="cuda")
+            report(out, f"c2_spmm_k{k}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
+            del X, Y
+        del A, rp, cc, vv
     if "dropin" in what:
         # the reference-named entry point with HOST vectors and a host struct (what an unmodified C caller does):
         # per call = fingerprint of the host arrays + 80 MB up + kernel + 80 MB down
