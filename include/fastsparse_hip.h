@@ -103,6 +103,17 @@ int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stre
 /* y[ncol] = A'A x[ncol]; tmp is caller scratch of nrow doubles in HBM   (bcsr_AA_mul_B, parallel_bcsr_AA_mul_B) */
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream);
 
+/* ---- consumers of the path, device resident (cg.h of the reference) -------------------- */
+/* (A'A + lambda I) x = b by conjugate gradients; A and the handle of its transpose as the reference passes
+ * them (bsbm_cg cg.h:25); x, b: F = ncol(A) doubles in HBM; stops at ||r|| <= tol ||b|| or after F iterations */
+int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lambda, double tol, int *out_iter,
+          fs_stream_t stream);
+/* the same for two right-hand sides, X and B row-major F x 2 (bsbm_cg2 cg.h:85) */
+int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lambda, double tol, int *out_iter,
+           fs_stream_t stream);
+/* y += a x on device vectors (the "+ lambda x" of bsbm_AtA, cg.h:17-21) */
+int fs_axpy(int n, double a, const double *x, double *y, fs_stream_t stream);
+
 /* ---- column-blocked binary CSR (cbcsr.h) -------------------------------------------- */
 fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, const int *row_ptr,
                            const int *cols, int space);

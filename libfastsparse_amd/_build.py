@@ -10,10 +10,10 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libfastsparse_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["fs_kernels.hip", "fs_format.hip", "fs_abi.hip", "fs_dropin.hip"]
+HIP_SOURCES = ["fs_kernels.hip", "fs_format.hip", "fs_abi.hip", "fs_dropin.hip", "fs_cg.hip"]
 C_SOURCES = ["fs_host.c"]
 HEADERS = [os.path.join(CSRC, "fs_common.h")] + [os.path.join(ROOT, "include", h) for h in
-                                                 ("fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h")]
+                                                 ("fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h")]
 
 
 def _hipcc():

@@ -20,7 +20,7 @@ DEVICE_API = [
     "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
     "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
-    "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul",
+    "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all",
     "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill",
 ]
@@ -37,6 +37,8 @@ REFERENCE_API = [
     "csr_At_mul_B", "bcsr_At_mul_B",
     # cbcsr.h
     "new_cbcsr", "cbcsr_from_sbm", "cbcsr_A_mul_B",
+    # cg.h, linalg.h
+    "bsbm_AtA", "bsbm_cg", "bsbm_cg2", "dist", "pnormsq", "pnormsq2", "pouter2", "pdot", "pdot2sym", "solve2sym",
 ]
 
 
@@ -78,6 +80,9 @@ def lib():
     for f in ("fs_spmm", "fs_spmm_t"):
         getattr(L, f).argtypes = [vp, vp, vp, C.c_int, vp]
     L.fs_ata_mul.argtypes = [vp, vp, vp, vp, vp]
+    for f in ("fs_cg", "fs_cg2"):
+        getattr(L, f).argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_int), vp]
+    L.fs_axpy.argtypes = [C.c_int, C.c_double, vp, vp, vp]
     L.fs_cbcsr_create.restype = vp
     L.fs_cbcsr_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.fs_cbcsr_destroy.argtypes = [vp]

@@ -1,0 +1,320 @@
+// fs_cg.hip -- the consumers of the A_mul_B path, device resident:
+// conjugate gradients on (A'A + lambda I) with one right-hand side (bsbm_cg, cg.h:25-82) and with two
+// row-major right-hand sides (bsbm_cg2, cg.h:85-187).  Every vector lives in HBM for the whole solve; per
+// iteration two products (fs_spmv / fs_spmm on A and A') and three fused vector kernels run, and one or two
+// 8..24-byte reductions travel to the host, which does the scalar / 2x2 algebra (solve2sym, linalg.h:77-88)
+// exactly as the reference does.
+//
+// Reductions are two-stage with a fixed shape (1024 workgroup partials, then one workgroup), so results are
+// reproducible run to run; they are NOT the CPU's single left-to-right sums, so iterates agree with the
+// reference to rounding, not bit for bit.
+#include <math.h>
+
+#include <vector>
+
+#include "fs_common.h"
+
+namespace fs {
+
+constexpr int kRedBlocks = 1024;
+constexpr int kRedThreads = 256;
+
+// sum of NV values per thread over the workgroup -> part[blockIdx * NV + j]
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *__restrict__ part)
+{
+  __shared__ double sm[NV][kRedThreads / 64];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double s = v[j];
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) sm[j][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < kRedThreads / 64; ++w) s += sm[threadIdx.x][w];
+    part[blockIdx.x * NV + threadIdx.x] = s;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kRedThreads) void final_sum_kernel(const double *__restrict__ part, int nblocks,
+                                                               double *__restrict__ out)
+{
+  double v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kRedThreads) v[j] += part[b * NV + j];
+  }
+  block_sum<NV>(v, out);  // gridDim == 1: out[0..NV)
+}
+
+// ---- one right-hand side --------------------------------------------------------------------------------
+// x = 0, r = p = b, partial b.b                                   (cg.h:46-51)
+__global__ __launch_bounds__(kRedThreads) void cg_init_kernel(int n, const double *__restrict__ b, double *__restrict__ x,
+                                                             double *__restrict__ r, double *__restrict__ p,
+                                                             double *__restrict__ part)
+{
+  double v[1] = {0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double bi = b[i];
+    x[i] = 0.0; r[i] = bi; p[i] = bi;
+    v[0] += bi * bi;
+  }
+  block_sum<1>(v, part);
+}
+
+// q += lambda p, partial q.p                                      (cg.h:17-21, :59)
+__global__ __launch_bounds__(kRedThreads) void cg_shift_dot_kernel(int n, double lambda, double *__restrict__ q,
+                                                                  const double *__restrict__ p, double *__restrict__ part)
+{
+  double v[1] = {0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pi = p[i];
+    const double qi = q[i] + lambda * pi;
+    q[i] = qi;
+    v[0] += qi * pi;
+  }
+  block_sum<1>(v, part);
+}
+
+// x += alpha p, r -= alpha q, partial r.r                         (cg.h:61-67)
+__global__ __launch_bounds__(kRedThreads) void cg_update_kernel(int n, double alpha, double *__restrict__ x,
+                                                               double *__restrict__ r, const double *__restrict__ p,
+                                                               const double *__restrict__ q, double *__restrict__ part)
+{
+  double v[1] = {0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    v[0] += ri * ri;
+  }
+  block_sum<1>(v, part);
+}
+
+// p = r + beta p                                                  (cg.h:71-75)
+__global__ __launch_bounds__(kRedThreads) void cg_direction_kernel(int n, double beta, double *__restrict__ p,
+                                                                  const double *__restrict__ r)
+{
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) p[i] = r[i] + beta * p[i];
+}
+
+// ---- two right-hand sides, row-major -------------------------------------------------------------------
+// partial {a'a, b'b, a'b} of X with Y                             (pnormsq2 / pouter2 / pdot2sym, linalg.h:24-73)
+__global__ __launch_bounds__(kRedThreads) void cg2_dot_kernel(int n, const double *__restrict__ X,
+                                                             const double *__restrict__ Y, double *__restrict__ part)
+{
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double xa = X[2 * i], xb = X[2 * i + 1], ya = Y[2 * i], yb = Y[2 * i + 1];
+    v[0] += xa * ya; v[1] += xb * yb; v[2] += xa * yb;
+  }
+  block_sum<3>(v, part);
+}
+
+// X = 0, R = P = B * inorms, partial R'R                          (cg.h:113-125)
+__global__ __launch_bounds__(kRedThreads) void cg2_init_kernel(int n, double in0, double in1, const double *__restrict__ B,
+                                                              double *__restrict__ X, double *__restrict__ R,
+                                                              double *__restrict__ P, double *__restrict__ part)
+{
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double a = B[2 * i] * in0, c = B[2 * i + 1] * in1;
+    X[2 * i] = 0.0; X[2 * i + 1] = 0.0;
+    R[2 * i] = a; R[2 * i + 1] = c; P[2 * i] = a; P[2 * i + 1] = c;
+    v[0] += a * a; v[1] += c * c; v[2] += a * c;
+  }
+  block_sum<3>(v, part);
+}
+
+// Q += lambda P, partial P'Q (symmetric form)                      (cg.h:136-142)
+__global__ __launch_bounds__(kRedThreads) void cg2_shift_dot_kernel(int n, double lambda, double *__restrict__ Q,
+                                                                   const double *__restrict__ P, double *__restrict__ part)
+{
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pa = P[2 * i], pb = P[2 * i + 1];
+    const double qa = Q[2 * i] + lambda * pa, qb = Q[2 * i + 1] + lambda * pb;
+    Q[2 * i] = qa; Q[2 * i + 1] = qb;
+    v[0] += pa * qa; v[1] += pb * qb; v[2] += pa * qb;
+  }
+  block_sum<3>(v, part);
+}
+
+// X += Alpha' P, R -= Alpha' Q, partial R'R                        (cg.h:148-157)
+__global__ __launch_bounds__(kRedThreads) void cg2_update_kernel(int n, double a0, double a1, double a2, double a3,
+                                                                double *__restrict__ X, double *__restrict__ R,
+                                                                const double *__restrict__ P, const double *__restrict__ Q,
+                                                                double *__restrict__ part)
+{
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pa = P[2 * i], pb = P[2 * i + 1], qa = Q[2 * i], qb = Q[2 * i + 1];
+    X[2 * i] += a0 * pa + a1 * pb;
+    X[2 * i + 1] += a2 * pa + a3 * pb;
+    const double ra = R[2 * i] - (a0 * qa + a1 * qb), rb = R[2 * i + 1] - (a2 * qa + a3 * qb);
+    R[2 * i] = ra; R[2 * i + 1] = rb;
+    v[0] += ra * ra; v[1] += rb * rb; v[2] += ra * rb;
+  }
+  block_sum<3>(v, part);
+}
+
+// P = R + Psi' P                                                   (cg.h:165-171)
+__global__ __launch_bounds__(kRedThreads) void cg2_direction_kernel(int n, double s0, double s1, double s2, double s3,
+                                                                   double *__restrict__ P, const double *__restrict__ R)
+{
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pa = P[2 * i], pb = P[2 * i + 1];
+    P[2 * i] = R[2 * i] + s0 * pa + s1 * pb;
+    P[2 * i + 1] = R[2 * i + 1] + s2 * pa + s3 * pb;
+  }
+}
+
+// y += a x
+__global__ __launch_bounds__(kRedThreads) void axpy_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y)
+{
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg2_scale_kernel(int n, double n0, double n1, double *__restrict__ X)
+{
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    X[2 * i] *= n0;
+    X[2 * i + 1] *= n1;
+  }
+}
+
+static void solve2sym_host(double *X, const double *A, const double *RHS)  // linalg.h:77-88
+{
+  const double dinv = 1.0 / (A[0] * A[1] - A[2] * A[2]);
+  const double i0 = dinv * A[1], i1 = dinv * A[0], i2 = -dinv * A[2];
+  X[0] = i0 * RHS[0] + i2 * RHS[1];
+  X[1] = i2 * RHS[0] + i1 * RHS[1];
+  X[2] = i0 * RHS[2] + i2 * RHS[3];
+  X[3] = i2 * RHS[2] + i1 * RHS[3];
+}
+
+struct Workspace {
+  std::vector<void *> bufs;
+  double *get(size_t n)
+  {
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(double) * (n ? n : 1)) != hipSuccess) return nullptr;
+    bufs.push_back(p);
+    return (double *)p;
+  }
+  ~Workspace() { for (void *p : bufs) (void)hipFree(p); }
+};
+
+}  // namespace fs
+
+using namespace fs;
+
+// fetch NV reduced values: partials -> one workgroup -> host
+template <int NV>
+static int reduce_to_host(const double *part, double *red_dev, double *host, hipStream_t s)
+{
+  hipLaunchKernelGGL(final_sum_kernel<NV>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red_dev);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipMemcpyAsync(host, red_dev, sizeof(double) * NV, hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  return FS_OK;
+}
+
+extern "C" {
+
+// y += a x on device vectors (the "+ lambda x" of bsbm_AtA, cg.h:17-21)
+int fs_axpy(int n, double a, const double *x, double *y, fs_stream_t stream)
+{
+  if (n < 0 || !x || !y) { set_error("fs_axpy: bad argument"); return FS_ERR_ARG; }
+  hipLaunchKernelGGL(axpy_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, (hipStream_t)stream, n, a, x, y);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+// (A'A + lambda I) x = b with A given by its handle and the handle of its transpose (the reference passes both
+// matrices, cg.h:26-27); x, b device vectors of F = ncol(A) doubles.  Stops like cg.h:69 (||r|| <= tol ||b||) or
+// after F iterations; *out_iter as the reference reports it.
+int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lambda, double tol, int *out_iter,
+          fs_stream_t stream)
+{
+  if (!A || !At || !x || !b) { set_error("fs_cg: NULL argument"); return FS_ERR_ARG; }
+  const int N = A->a.nrow, F = A->a.ncol;
+  if (At->a.nrow != F || At->a.ncol != N) { set_error("fs_cg: At is not the transpose shape of A"); return FS_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  Workspace ws;
+  double *r = ws.get(F), *p = ws.get(F), *q = ws.get(F), *tmp = ws.get(N), *part = ws.get(kRedBlocks * 3), *red = ws.get(4);
+  if (!r || !p || !q || !tmp || !part || !red) { set_error("fs_cg: out of device memory"); return FS_ERR_HIP; }
+  const dim3 g(kRedBlocks), blk(kRedThreads);
+  double h[1];
+  hipLaunchKernelGGL(cg_init_kernel, g, blk, 0, s, F, b, x, r, p, part);
+  if (int rc = reduce_to_host<1>(part, red, h, s)) return rc;
+  double rsq_old = h[0];
+  const double stop = tol * sqrt(rsq_old);
+  int iter;
+  for (iter = 0; iter < F; iter++) {
+    if (int rc = fs_spmv(A, tmp, p, stream)) return rc;
+    if (int rc = fs_spmv(At, q, tmp, stream)) return rc;
+    hipLaunchKernelGGL(cg_shift_dot_kernel, g, blk, 0, s, F, lambda, q, p, part);
+    if (int rc = reduce_to_host<1>(part, red, h, s)) return rc;
+    const double alpha = rsq_old / h[0];
+    hipLaunchKernelGGL(cg_update_kernel, g, blk, 0, s, F, alpha, x, r, p, q, part);
+    if (int rc = reduce_to_host<1>(part, red, h, s)) return rc;
+    const double rsq_new = h[0];
+    if (sqrt(rsq_new) <= stop) break;
+    hipLaunchKernelGGL(cg_direction_kernel, g, blk, 0, s, F, rsq_new / rsq_old, p, r);
+    rsq_old = rsq_new;
+  }
+  FS_HIP(hipStreamSynchronize(s));
+  if (out_iter) *out_iter = iter;
+  return FS_OK;
+}
+
+// two right-hand sides, X and B row-major F x 2 (cg.h:85-187)
+int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lambda, double tol, int *out_iter,
+           fs_stream_t stream)
+{
+  if (!A || !At || !X || !B) { set_error("fs_cg2: NULL argument"); return FS_ERR_ARG; }
+  const int N = A->a.nrow, F = A->a.ncol;
+  if (At->a.nrow != F || At->a.ncol != N) { set_error("fs_cg2: At is not the transpose shape of A"); return FS_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  Workspace ws;
+  double *R = ws.get(2 * (size_t)F), *P = ws.get(2 * (size_t)F), *Q = ws.get(2 * (size_t)F), *tmp = ws.get(2 * (size_t)N);
+  double *part = ws.get(kRedBlocks * 3), *red = ws.get(4);
+  if (!R || !P || !Q || !tmp || !part || !red) { set_error("fs_cg2: out of device memory"); return FS_ERR_HIP; }
+  const dim3 g(kRedBlocks), blk(kRedThreads);
+  const double tolsq = tol * tol;
+  double h[3], norms[2];
+  hipLaunchKernelGGL(cg2_dot_kernel, g, blk, 0, s, F, B, B, part);
+  if (int rc = reduce_to_host<3>(part, red, h, s)) return rc;
+  norms[0] = sqrt(h[0]); norms[1] = sqrt(h[1]);
+  hipLaunchKernelGGL(cg2_init_kernel, g, blk, 0, s, F, 1.0 / norms[0], 1.0 / norms[1], B, X, R, P, part);
+  double RtR[3], RtR2[3], PtKP[3], Alpha[4], Psi[4];
+  if (int rc = reduce_to_host<3>(part, red, RtR, s)) return rc;
+  int iter;
+  for (iter = 0; iter < F; iter++) {
+    if (int rc = fs_spmm(A, tmp, P, 2, stream)) return rc;
+    if (int rc = fs_spmm(At, Q, tmp, 2, stream)) return rc;
+    hipLaunchKernelGGL(cg2_shift_dot_kernel, g, blk, 0, s, F, lambda, Q, P, part);
+    if (int rc = reduce_to_host<3>(part, red, PtKP, s)) return rc;
+    const double rhs[4] = {RtR[0], RtR[2], RtR[2], RtR[1]};
+    solve2sym_host(Alpha, PtKP, rhs);
+    hipLaunchKernelGGL(cg2_update_kernel, g, blk, 0, s, F, Alpha[0], Alpha[1], Alpha[2], Alpha[3], X, R, P, Q, part);
+    if (int rc = reduce_to_host<3>(part, red, RtR2, s)) return rc;
+    if (RtR2[0] <= tolsq && RtR2[1] <= tolsq) break;
+    const double rhs_psi[4] = {RtR2[0], RtR2[2], RtR2[2], RtR2[1]};
+    solve2sym_host(Psi, RtR, rhs_psi);
+    hipLaunchKernelGGL(cg2_direction_kernel, g, blk, 0, s, F, Psi[0], Psi[1], Psi[2], Psi[3], P, R);
+    RtR[0] = RtR2[0]; RtR[1] = RtR2[1]; RtR[2] = RtR2[2];
+  }
+  hipLaunchKernelGGL(cg2_scale_kernel, g, blk, 0, s, F, norms[0], norms[1], X);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipStreamSynchronize(s));
+  if (out_iter) *out_iter = iter;
+  return FS_OK;
+}
+
+}  // extern "C"

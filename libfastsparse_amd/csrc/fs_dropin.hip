@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cbcsr.h"
+#include "cg.h"
 #include "csr.h"
 #include "dsparse.h"
 #include "fs_common.h"
@@ -268,6 +269,52 @@ void bsbm_A_mul_B(double *y, struct BlockedSBM *B, double *x) { bsbm_mul_k(y, B,
 void bsbm_A_mul_B2(double *y, struct BlockedSBM *B, double *x) { bsbm_mul_k(y, B, x, 2, "bsbm_A_mul_B2"); }
 void bsbm_A_mul_B4(double *y, struct BlockedSBM *B, double *x) { bsbm_mul_k(y, B, x, 4, "bsbm_A_mul_B4"); }
 void bsbm_A_mul_Bn(double *y, struct BlockedSBM *B, double *x, int ncol) { bsbm_mul_k(y, B, x, ncol, "bsbm_A_mul_Bn"); }
+
+// ---- cg.h --------------------------------------------------------------------------------------------------
+void bsbm_AtA(double *y, struct BlockedSBM *A, struct BlockedSBM *At, double *x, double *tmp, double lambda)
+{
+  (void)tmp;  // host scratch of the CPU version; the intermediate A x stays in HBM here
+  fs_matrix_t a = blocked_handle(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, "bsbm_AtA");
+  fs_matrix_t at = blocked_handle(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, "bsbm_AtA");
+  double *t = nullptr;
+  if (hipMalloc(&t, sizeof(double) * (size_t)(A->nrow ? A->nrow : 1)) != hipSuccess) {
+    fs::set_error("hipMalloc of the A x scratch failed"); die("bsbm_AtA");
+  }
+  with_vectors(y, At->nrow, x, A->ncol, [&](double *yd, const double *xd) {
+    if (int rc = fs_spmv(a, t, xd, nullptr)) return rc;
+    if (int rc = fs_spmv(at, yd, t, nullptr)) return rc;
+    // y += lambda x (cg.h:17-21): reuse the SpMV-side axpy of the solver through a tiny CG-free path
+    return fs_axpy(At->nrow, lambda, xd, yd, nullptr);
+  }, "bsbm_AtA");
+  (void)hipFree(t);
+}
+
+static void cg_common(double *x, struct BlockedSBM *A, struct BlockedSBM *At, double *b, double lambda, double tol,
+                      int *out_iter, int k, const char *who)
+{
+  if (A->nrow != At->ncol || A->ncol != At->nrow) {  // cg.h:32-36
+    printf("A (%d x %d) and At (%d x %d) must be transposes of each other.\n", A->nrow, A->ncol, At->nrow, At->ncol);
+    exit(1);
+  }
+  fs_matrix_t a = blocked_handle(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, who);
+  fs_matrix_t at = blocked_handle(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, who);
+  const size_t n = (size_t)A->ncol * k;
+  int iters = 0;
+  with_vectors(x, n, b, n, [&](double *xd, const double *bd) {
+    return k == 1 ? fs_cg(a, at, xd, bd, lambda, tol, &iters, nullptr) : fs_cg2(a, at, xd, bd, lambda, tol, &iters, nullptr);
+  }, who);
+  if (out_iter) *out_iter = iters;
+}
+
+void bsbm_cg(double *x, struct BlockedSBM *A, struct BlockedSBM *At, double *b, double lambda, double tol, int *out_iter)
+{
+  cg_common(x, A, At, b, lambda, tol, out_iter, 1, "bsbm_cg");
+}
+
+void bsbm_cg2(double *X, struct BlockedSBM *A, struct BlockedSBM *At, double *B, double lambda, double tol, int *out_iter)
+{
+  cg_common(X, A, At, B, lambda, tol, out_iter, 2, "bsbm_cg2");
+}
 
 // ---- dsparse.h ---------------------------------------------------------------------------------------
 void sdm_A_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)

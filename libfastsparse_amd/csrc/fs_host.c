@@ -245,3 +245,53 @@ FS_EXPORT struct BlockedSDM *new_bsdm(struct SparseDoubleMatrix *A, int block_si
                &B->cols, &B->vals);
   return B;
 }
+
+/* ---- linalg.h helpers (host; linalg.h:6-88 of the reference) -------------------------------------- */
+#include "linalg.h"
+
+FS_EXPORT double dist(double *x, double *y, int n)
+{
+  double d = 0;
+  for (int i = 0; i < n; i++) { double t = x[i] - y[i]; d += t * t; }
+  return sqrt(d);
+}
+
+FS_EXPORT double pnormsq(double *x, int n)
+{
+  double s = 0;
+  for (int i = 0; i < n; i++) s += x[i] * x[i];
+  return s;
+}
+
+FS_EXPORT double pdot(double *x, double *y, int n)
+{
+  double s = 0;
+  for (int i = 0; i < n; i++) s += x[i] * y[i];
+  return s;
+}
+
+FS_EXPORT void pdot2sym(double *D, double *X, double *Y, int n)
+{
+  double aa = 0, bb = 0, ab = 0;
+  for (int i = 0; i < n; i++) { aa += X[2 * i] * Y[2 * i]; bb += X[2 * i + 1] * Y[2 * i + 1]; ab += X[2 * i] * Y[2 * i + 1]; }
+  D[0] = aa; D[1] = bb; D[2] = ab;
+}
+
+FS_EXPORT void pnormsq2(double *normsq, double *X, int n)
+{
+  double d[3];
+  pdot2sym(d, X, X, n);
+  normsq[0] = d[0]; normsq[1] = d[1];
+}
+
+FS_EXPORT void pouter2(double *outer, double *X, int n) { pdot2sym(outer, X, X, n); }
+
+FS_EXPORT void solve2sym(double *X, double *A, double *RHS)
+{
+  double dinv = 1.0 / (A[0] * A[1] - A[2] * A[2]);
+  double i0 = dinv * A[1], i1 = dinv * A[0], i2 = -dinv * A[2];
+  X[0] = i0 * RHS[0] + i2 * RHS[1];
+  X[1] = i2 * RHS[0] + i1 * RHS[1];
+  X[2] = i0 * RHS[2] + i2 * RHS[3];
+  X[3] = i2 * RHS[2] + i1 * RHS[3];
+}

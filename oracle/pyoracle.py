@@ -21,7 +21,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile liboracle.so with gcc (strict IEEE flags, see oracle/Makefile)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("fs_oracle.c", "fs_synth.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("fs_oracle.c", "fs_synth.c", "fs_oracle_cg.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -62,6 +62,9 @@ def load(path=None):
     lib.fso_cbcsr_mul.argtypes = [_f64p, C.c_int, C.c_int, _i32p, _i32p, _f64p]
     lib.fso_csr_abs_scale.argtypes = [_f64p, C.c_int, _i32p, _i32p, C.c_void_p, _f64p]
     lib.fso_threads.restype = C.c_int
+    for f in ("fso_cg", "fso_cg2"):
+        getattr(lib, f).argtypes = [_f64p, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p, C.c_double, C.c_double]
+        getattr(lib, f).restype = C.c_int
     for f in ("fso_coo_to_csr", "fso_coo_to_blocked", "fso_coo_to_cbcsr", "fso_csr_mul", "fso_csr_mul_n",
               "fso_bcsr_aa_mul", "fso_coo_mul", "fso_coo_tmul", "fso_blocked_mul_n", "fso_cbcsr_mul",
               "fso_csr_abs_scale"):
@@ -166,3 +169,15 @@ def csr_abs_scale(nrow, row_ptr, cols, vals, x, lib=None):
     s = np.empty(nrow)
     lib.fso_csr_abs_scale(s, nrow, row_ptr, cols, _vp(vals), x)
     return s
+
+
+def cg_normal(nrow, ncol, rows, cols, b, lam, tol, two=False, lib=None):
+    """(A'A + lam I) x = b on the pattern-only COO (rows, cols); b is F or F x 2 row-major.  Returns (x, iterations)."""
+    lib = lib or load()
+    a_rp, a_cc, _ = coo_to_csr(nrow, rows, cols, None, lib=lib)
+    t_rp, t_cc, _ = coo_to_csr(ncol, cols, rows, None, lib=lib)     # A' rows keep the COO entry order, like new_bsbm(At)
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
+    x = np.full(b.size, -1.0)
+    f = lib.fso_cg2 if two else lib.fso_cg
+    it = f(x, nrow, ncol, a_rp, a_cc, t_rp, t_cc, b, float(lam), float(tol))
+    return (x.reshape(ncol, 2) if two else x), it

@@ -22,6 +22,7 @@
 #include "dsparse.h"
 #include "csr.h"
 #include "cbcsr.h"
+#include "cg.h"   /* bsbm_cg / bsbm_cg2: plain (non-inline) definitions, exported as they are */
 
 void ref_new_bcsr(struct BinaryCSR *A, long nnz, int nrow, int ncol, int *rows, int *cols)
 { new_bcsr(A, nnz, nrow, ncol, rows, cols); }

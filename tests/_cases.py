@@ -123,7 +123,25 @@ def run_case(be, case, tags=None, light=False):
                 continue
             X = S.X_sin(c.ncol, k)
             res[f"csr_A_mul_Bn/k{k}"] = be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, c.vals, X, k, "csr_A_mul_Bn")
+    # --- the consumers of the path: CG on (A'A + lambda I), one and two right-hand sides ---
+    # (F >= 16: on a 3-column matrix the second 2-column search block is rank deficient and the 2x2 solves of
+    #  bsbm_cg2 divide by rounding noise -- in the reference too)
+    if 16 <= c.ncol <= 2100 and hasattr(be, "cg"):
+        b1, b2 = cg_rhs(c.ncol)
+        x, it = be.cg(c.nrow, c.ncol, c.rows, c.cols, b1, CG_LAMBDA, CG_TOL, False)
+        res["bsbm_cg/x"], res["bsbm_cg/iter"] = x, np.array([float(it)])
+        X, it = be.cg(c.nrow, c.ncol, c.rows, c.cols, np.stack([b1, b2], axis=1).copy(), CG_LAMBDA, CG_TOL, True)
+        res["bsbm_cg2/X"], res["bsbm_cg2/iter"] = X, np.array([float(it)])
     return res
+
+
+CG_LAMBDA, CG_TOL = 5.0, 1e-6
+
+
+def cg_rhs(F):
+    """right-hand sides of test_cg (test_sparse.c:570-572, :594-597)"""
+    i = np.arange(F, dtype=np.float64)
+    return np.sin(i * 19 + 0.4) + np.cos(i * i * 3), np.cos(i * 23 + 0.7) + np.sin(i * i * 7)
 
 
 # ----------------------------------------------------------------------------
@@ -159,6 +177,9 @@ class OracleBackend:
     def cbcsr_mul(self, nrow, ncol, rows, cols, cbs, x):
         nb, rp, cc = self.O.coo_to_cbcsr(cbs, nrow, ncol, rows, cols, lib=self.lib)
         return self.O.cbcsr_mul(nrow, nb, rp, cc, x, lib=self.lib)
+
+    def cg(self, nrow, ncol, rows, cols, b, lam, tol, two):
+        return self.O.cg_normal(nrow, ncol, rows, cols, b, lam, tol, two, lib=self.lib)
 
 
 class RefBackend:
@@ -207,3 +228,19 @@ class RefBackend:
 
     def cbcsr_mul(self, nrow, ncol, rows, cols, cbs, x):
         return self.R.cbcsr_A_mul_B(self.R.cbcsr(cbs, nrow, ncol, rows, cols), x)
+
+    def cg(self, nrow, ncol, rows, cols, b, lam, tol, two):
+        # as test_cg (test_sparse.c:560-566) without the Hilbert pre-sort: B = new_bsbm(A, 8), Bt = new_bsbm(A', 8)
+        C = self.C
+        s = self.R.sbm(nrow, ncol, rows, cols)
+        B = self.R.lib.new_bsbm(C.byref(s), 8)
+        st = self.R.sbm(ncol, nrow, cols, rows)
+        Bt = self.R.lib.new_bsbm(C.byref(st), 8)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1).copy()
+        x = np.full(b.size, -1.0)
+        it = C.c_int(-1)
+        f = self.R.lib.bsbm_cg2 if two else self.R.lib.bsbm_cg
+        f.restype = None
+        f(x.ctypes.data_as(C.POINTER(C.c_double)), B, Bt, b.ctypes.data_as(C.POINTER(C.c_double)),
+          C.c_double(lam), C.c_double(tol), C.byref(it))
+        return (x.reshape(ncol, 2) if two else x), it.value

@@ -79,6 +79,18 @@ class HipDeviceBackend:
         m.spmv(y, self._d(x), capi.current_stream())
         return y.cpu().numpy()
 
+    def cg(self, nrow, ncol, rows, cols, b, lam, tol, two):
+        """fs_cg / fs_cg2 on device vectors; A and A' as two handles, like the reference passes B and Bt"""
+        A = self._coo(nrow, ncol, rows, cols, None)
+        At = self._coo(ncol, nrow, cols, rows, None)
+        bd = self._d(np.ascontiguousarray(b, dtype=np.float64).reshape(-1))
+        xd = self._out(bd.numel())
+        it = C.c_int(-1)
+        f = self.L.fs_cg2 if two else self.L.fs_cg
+        capi.check(f(A.h, At.h, xd.data_ptr(), bd.data_ptr(), float(lam), float(tol), C.byref(it), capi.current_stream()))
+        x = xd.cpu().numpy()
+        return (x.reshape(ncol, 2) if two else x), it.value
+
     def transposed_csr_mul(self, nrow, ncol, rows, cols, vals, x):
         """A' x through fs_matrix_build_transpose + fs_spmv_t (the CSR At_mul_B of BASELINE config 2)"""
         m = self._coo(nrow, ncol, rows, cols, vals)
@@ -230,6 +242,22 @@ class HipDropinBackend(HostFormats):
 
     def cbcsr_mul(self, nrow, ncol, rows, cols, cbs, x):
         return self._call("cbcsr_A_mul_B", nrow, self.cbcsr(cbs, nrow, ncol, rows, cols), x)
+
+    def cg(self, nrow, ncol, rows, cols, b, lam, tol, two):
+        """bsbm_cg / bsbm_cg2 with host structs and host vectors, as test_cg (test_sparse.c:560-608) calls them"""
+        s = self.sbm(nrow, ncol, rows, cols)
+        B = self.L.new_bsbm(C.byref(s), 8)
+        st = self.sbm(ncol, nrow, cols, rows)
+        Bt = self.L.new_bsbm(C.byref(st), 8)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1).copy()
+        x = np.full(b.size, -1.0)
+        it = C.c_int(-1)
+        f = self.L.bsbm_cg2 if two else self.L.bsbm_cg
+        f.restype = None
+        f(_dp(x), B, Bt, _dp(b), C.c_double(lam), C.c_double(tol), C.byref(it))
+        self.L.fs_invalidate(B)
+        self.L.fs_invalidate(Bt)
+        return (x.reshape(ncol, 2) if two else x), it.value
 
     def transposed_csr_mul(self, nrow, ncol, rows, cols, vals, x):
         if vals is None:

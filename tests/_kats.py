@@ -64,6 +64,17 @@ def check_kats(be, cases_by_name):
               be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, None, X, 2, "bcsr_A_mul_Bn")]:
         assert np.max(np.abs(Y[:, 0] - y)) < 1e-6 and np.max(np.abs(Y[:, 1] - yc1)) < 1e-6
 
+    # test_cg (:560-608): x[0], x[1] of (A'A + 5 I) x = b, residual, and the same through the 2-RHS solver
+    if hasattr(be, "cg"):
+        import _cases
+        b1, b2 = _cases.cg_rhs(c.ncol)
+        xs, _ = be.cg(c.nrow, c.ncol, c.rows, c.cols, b1, 5.0, 1e-6, False)
+        assert abs(xs[0] - 0.0638578) < 1e-4 and abs(xs[1] + 0.0302702) < 1e-4
+        t = be.coo_tmul(c.nrow, c.ncol, c.rows, c.cols, None, be.coo_mul(c.nrow, c.ncol, c.rows, c.cols, None, xs))
+        assert np.linalg.norm(t + 5.0 * xs - b1) < 1e-5
+        X2, _ = be.cg(c.nrow, c.ncol, c.rows, c.cols, np.stack([b1, b2], axis=1).copy(), 5.0, 1e-6, True)
+        assert abs(X2[0, 0] - 0.0638578) < 1e-4 and abs(X2[1, 0] + 0.0302702) < 1e-4
+
     c = cases_by_name["kat_sdm_6x4"]
     x = c.xs["kat"]
     assert np.max(np.abs(be.coo_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, x) - KAT_SDM_Y)) < 1e-6

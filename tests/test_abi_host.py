@@ -27,7 +27,7 @@ def _declared_functions(header):
     return [n for n in names if n not in ("defined",)]
 
 
-@pytest.mark.parametrize("header", ["fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h"])
+@pytest.mark.parametrize("header", ["fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h"])
 def test_library_exports_every_declared_symbol(header):
     L = capi.lib()
     names = _declared_functions(header)
@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(header):
 
 def test_binding_lists_match_headers():
     declared = set()
-    for h in ("sparse.h", "dsparse.h", "csr.h", "cbcsr.h"):
+    for h in ("sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h"):
         declared |= set(_declared_functions(h))
     assert declared == set(capi.REFERENCE_API)
     assert set(_declared_functions("fastsparse_hip.h")) == set(capi.DEVICE_API)

@@ -40,6 +40,14 @@ def _check(out, gold, name, exact):
     for k, v in out.items():
         g = gold[k.replace("/", "|")]
         assert v.shape == g.shape, (name, k)
+        if k.startswith("bsbm_cg"):
+            # iterative consumer: device reductions are tree sums, so iterates follow the CPU's to
+            # rounding; the stopping iteration may move by one when ||r|| lands on the threshold
+            if k.endswith("/iter"):
+                assert abs(v[0] - g[0]) <= 1, (name, k, v, g)
+            else:
+                assert np.max(np.abs(v - g)) <= 1e-5 * max(1e-300, float(np.max(np.abs(g)))), (name, k)
+            continue
         if exact or (k.endswith("/int") and k.split("/")[0] not in VALUED):
             assert np.array_equal(v.view(np.int64), g.view(np.int64)), \
                 f"{name}:{k} not bit-exact (max diff {np.max(np.abs(v - g))})"
