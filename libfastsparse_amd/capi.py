@@ -55,7 +55,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FastsparseError(f"{LIB_PATH} is missing: build it first (libfastsparse_amd._build.build()); "
                               "there is no CPU fallback")
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH)   # RTLD_LOCAL: the reference-named symbols must not interpose other libraries
     L.fs_version.restype = C.c_char_p
     L.fs_last_error.restype = C.c_char_p
     L.fs_set_option.argtypes = [C.c_char_p, C.c_int]
