@@ -115,6 +115,37 @@ def main():
             report(out, f"c2_spmm_k{k}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
             del X, Y
         del A, rp, cc, vv
+    if "cg" in what:
+        # the consumer of the path (cg.h): (A'A + 5 I) x = b on the config-2 pattern, vectors resident in HBM
+        import ctypes as C
+        rp, cc, _ = capi.synth_uniform(n, n, 16, 0x5EED0002, valued=False)
+        A = capi.Matrix.from_csr(n, n, rp, cc, None, borrow=True)
+        A.build_transpose(st)
+        # A' as its own handle (the reference passes B and Bt): rows of A' = columns of A
+        rows = torch.arange(n, device="cuda", dtype=torch.int32).repeat_interleave(16)
+        At = capi.Matrix.from_coo(n, n, cc, rows, None)
+        del rows
+        b = torch.sin(19.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.4)
+        x = torch.empty(n, dtype=torch.float64, device="cuda")
+        L = capi.lib()
+        for two in (False, True):
+            bb = torch.stack([b, torch.cos(23.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.7)], 1).contiguous() if two else b
+            xx = torch.empty_like(bb)
+            it = C.c_int(0)
+            f = L.fs_cg2 if two else L.fs_cg
+            capi.check(f(A.h, At.h, xx.data_ptr(), bb.data_ptr(), 5.0, 1e-8, C.byref(it), st))   # warm
+            torch.cuda.synchronize()
+            t0 = time.time()
+            capi.check(f(A.h, At.h, xx.data_ptr(), bb.data_ptr(), 5.0, 1e-8, C.byref(it), st))
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            iters = it.value + 1
+            rec = {"name": "cg2_config2_pattern" if two else "cg_config2_pattern", "iterations": iters, "total_ms": dt * 1e3,
+                   "ms_per_iteration": dt * 1e3 / iters,
+                   "spmv_GBs_equiv": (2 if two else 1) * 2 * A.algorithmic_bytes() * iters / dt / 1e9}
+            print(json.dumps(rec), flush=True)
+            out.write(json.dumps(rec) + "\n")
+        del A, At
     if "dropin" in what:
         # the reference-named entry point with HOST vectors and a host struct (what an unmodified C caller does):
         # per call = fingerprint of the host arrays + 80 MB up + kernel + 80 MB down
