@@ -283,16 +283,18 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   const int J = (A.ncol + W - 1) / W;
   const int64_t ntiles = (int64_t)P * J;
   if (o.tiling == 1) {
-    // pays when x overflows the 4 MiB L2 of an XCD and tiles are not hopelessly thin ...
-    const bool big_x = (int64_t)A.ncol * 8 > (3ll << 20);
-    if (!big_x || A.nnz < (4 << 20) || (double)A.nnz / ntiles < 256.0) return FS_OK;
+    // pays when x does not fit the 32 KiB L1 of a CU many times over and tiles are not hopelessly thin ...
+    // (measured, config-2 rows and non-zeros: x of 0.5-2 MB 0.75-0.82 ms tiled vs 0.92 ms streaming -- narrow
+    // bands are L1 resident; x of 4-80 MB 0.70-1.06 ms vs 1.07-2.99 ms; x of 64 KB 1.3 ms vs 0.8 ms)
+    const int64_t x_bytes = (int64_t)A.ncol * 8;
+    if (x_bytes <= (256 << 10) || A.nnz < (4 << 20) || (double)A.nnz / ntiles < 256.0) return FS_OK;
     // ... and while re-reading x once per XCD and per generation of resident workgroups costs less than the
-    // L2 misses it saves.  Measured rates: tiled ~130 G entries/s plus x refills at ~5 TB/s; streaming kernel
-    // with every gather missing ~53 G entries/s.
+    // L2 misses it saves.  Measured rates: tiled ~150 G entries/s plus x refills at ~5 TB/s; streaming kernel
+    // ~172 G entries/s while x stays L2 resident, ~53 G entries/s once every gather misses.
     const double gens = (double)((P + slots - 1) / slots);
-    const double t_tiled = (double)A.nnz / 130e9 + gens * 8.0 * (double)A.ncol * 8.0 / 5e12;
-    const double t_stream = (double)A.nnz / 53e9;
-    if (t_tiled > 0.9 * t_stream) return FS_OK;
+    const double t_tiled = (double)A.nnz / 150e9 + gens * 8.0 * (double)A.ncol * 8.0 / 5e12;
+    const double t_stream = (double)A.nnz / (x_bytes <= (3 << 20) ? 172e9 : 53e9);
+    if (t_tiled > 0.95 * t_stream) return FS_OK;
     // ... and the matrix has no very long rows: a row's entries inside one tile are summed by one lane, and
     // a panel that holds a dense row falls behind the band sweep.  Heavy-tailed matrices (BASELINE config 5)
     // stay on the chunk-streaming kernel, whose work per workgroup does not depend on row lengths.

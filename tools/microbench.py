@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--tile-cols", type=int, default=0)
     ap.add_argument("--tiled-flags", type=int, default=0)
+    ap.add_argument("--tiling", type=int, default=1)
+    ap.add_argument("--ncols", type=int, nargs="*", default=None)
     ap.add_argument("--gate-kb", type=int, default=8192)
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
@@ -106,6 +108,19 @@ def main():
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
+    if "cols" in what:
+        # how the product behaves as x shrinks (column count), rows and non-zeros as config 2
+        capi.set_option("tiling", args.tiling)
+        for ncol in (args.ncols or (131072, 262144, 393216, 524288, 1048576, 4194304)):
+            rp, cc, vv = capi.synth_uniform(n, ncol, 16, 0x5EED0002)
+            A = capi.Matrix.from_csr(n, ncol, rp, cc, vv, borrow=True)
+            x = torch.sin(7.0 * torch.arange(ncol, device="cuda", dtype=torch.float64) + 0.3)
+            y = torch.empty(n, dtype=torch.float64, device="cuda")
+            for kern, label in ((0, "auto"), (1, "stream_nt"), (6, "tiled_if_built")):
+                capi.set_option("spmv_kernel", kern)
+                report(out, f"c2rows_ncol{ncol}_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st), iters=10))
+            capi.set_option("spmv_kernel", 0)
+            del A, rp, cc, vv
     if "spmm" in what:
         rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
         A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
