@@ -10,7 +10,8 @@ Workload: per GPU a CSR shard of 10 000 000 rows x 16 non-zer
 partition config 5 names: the global matrix is (N*10M) x 10M, rank r owns rows [r*10M, (r+1)*10M) -- a
 config-2 matrix of its own -- x (80 MB) is replicated, y = A x is a local SpMV followed by the RCCL
 all-gather of the y shards, and z = A' u is the local transposed product of the rank's rows with its slice
-of u followed by an RCCL all-reduce (sum) of the 80 MB partial results.
+of u followed by an RCCL all-reduce (sum) of the 80 MB partial results.  The two products of a step are
+independent, so each exchange is started asynchronously and overlaps the next local product.
 
 One step = y = A x  then  z = A' u  (two launches of the L2-tiled SpMV kernel per rank, plus one all-gather
 and one all-reduce when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
@@ -116,24 +117,37 @@ def main():
     y = torch.empty(n_global, dtype=torch.float64, device=dev)
     z = torch.empty(ncol, dtype=torch.float64, device=dev)
 
+    pending = [None]   # the all-reduce of the previous step's z, still in flight
+
     def step(ev=None):
-        """one step; with ev, HIP events bracket each local kernel on the launch stream: ev[0]|A x|ev[1] all-gather
-        ev[2]|A' u|ev[3] all-reduce"""
+        """one step: ev[0]|A x|ev[1]  start all-gather(y)  ev[2]|A' u|ev[3]  wait all-gather, start all-reduce(z).
+        The two products are independent, so each exchange overlaps the next local product (RCCL runs on its
+        own stream); every collective is waited for before its buffer is reused and before the clock stops."""
         if ev is not None:
             ev[0].record()
         yl = op_a.local(y, x)
         if ev is not None:
             ev[1].record()
-        op_a.gather(y, yl)
+        g = op_a.gather_async(y, yl)
+        if pending[0] is not None:
+            pending[0].wait()            # z of the previous step is complete before it is overwritten
+            pending[0] = None
         if ev is not None:
             ev[2].record()
         op_t.apply_local(z, u)
         if ev is not None:
             ev[3].record()
-        op_t.reduce(z)
+        g.wait()
+        pending[0] = op_t.reduce_async(z)
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -142,6 +156,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(evs[k])
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -20,6 +20,29 @@ def _host_collective(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+class _Done:
+    """handle of a collective that already completed (host-routed gloo path, single rank)"""
+
+    def wait(self):
+        return True
+
+
+def all_gather_into_async(out, inp, group=None):
+    """start the all-gather; the returned handle's wait() orders the CURRENT stream after it.  Kernels launched
+    on the current stream in between overlap with the transfer (RCCL runs on its own stream)."""
+    if _host_collective(inp, group):
+        all_gather_into(out, inp, group)
+        return _Done()
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
+
+
+def all_reduce_sum_async(t, group=None):
+    if _host_collective(t, group):
+        all_reduce_sum(t, group)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def all_gather_into(out, inp, group=None):
     if _host_collective(inp, group):
         o = torch.empty(out.shape, dtype=out.dtype)
@@ -121,6 +144,15 @@ class ShardedOperator:
                     self._pad[r * self.max_rows: r * self.max_rows + self.sizes[r]]
         return y_full
 
+    def gather_async(self, y_full, y_local):
+        """start the exchange step and return a handle; only the equal-shard layout has an asynchronous form"""
+        if self.world == 1:
+            return _Done()
+        if not self.equal:
+            self.gather(y_full, y_local)
+            return _Done()
+        return all_gather_into_async(y_full, y_local[:self.hi - self.lo], self.group)
+
     def apply(self, y_full, x_full):
         return self.gather(y_full, self.local(y_full, x_full))
 
@@ -155,6 +187,9 @@ class TransposedShardedOperator:
         if self.world > 1:
             all_reduce_sum(z_full, self.group)
         return z_full
+
+    def reduce_async(self, z_full):
+        return all_reduce_sum_async(z_full, self.group) if self.world > 1 else _Done()
 
     def apply(self, z_full, u_full):
         self.apply_local(z_full, u_full)

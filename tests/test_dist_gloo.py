@@ -83,6 +83,15 @@ def _worker(rank, world, port, mode, ret):
         opr.apply(z2, torch.from_numpy(x))
         scale = O.coo_tmul(n, rows_all, cc, np.abs(vv), np.abs(x))
         ok = ok and bool(np.all(np.abs(z2.numpy() - zref) <= 1e-12 * np.maximum(scale, 1e-300)))
+        # asynchronous form used by bench.py: start the exchange, do other work, wait
+        y3 = torch.full((n,), -1.0, dtype=torch.float64)
+        h = op.gather_async(y3, op.local(y3, torch.from_numpy(x)))
+        z3 = torch.full((n,), -1.0, dtype=torch.float64)
+        opr.apply_local(z3, torch.from_numpy(x))
+        h.wait()
+        h2 = opr.reduce_async(z3)
+        h2.wait()
+        ok = ok and np.array_equal(y3.numpy(), ref) and np.array_equal(z3.numpy(), z2.numpy())
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
