@@ -18,6 +18,29 @@
 namespace fs {
 
 // ---- small helpers -------------------------------------------------------------------------
+// device scratch that is released on every exit path
+template <typename T>
+struct Scratch {
+  T *p = nullptr;
+  Scratch() = default;
+  Scratch(const Scratch &) = delete;
+  Scratch &operator=(const Scratch &) = delete;
+  ~Scratch() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * (n ? n : 1)); }
+  operator T *() const { return p; }
+};
+
+static void free_tiled(DeviceCsr &A)
+{
+  if (!A.tiled) return;
+  if (A.tiled->pk) (void)hipFree(A.tiled->pk);
+  if (A.tiled->vals) (void)hipFree(A.tiled->vals);
+  if (A.tiled->items) (void)hipFree(A.tiled->items);
+  if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
+  delete A.tiled;
+  A.tiled = nullptr;
+}
+
 void free_csr(DeviceCsr &A)
 {
   if (A.owns) {
@@ -28,13 +51,7 @@ void free_csr(DeviceCsr &A)
   if (A.first_row) (void)hipFree(A.first_row);
   if (A.head) (void)hipFree(A.head);
   if (A.tail) (void)hipFree(A.tail);
-  if (A.tiled) {
-    if (A.tiled->pk) (void)hipFree(A.tiled->pk);
-    if (A.tiled->vals) (void)hipFree(A.tiled->vals);
-    if (A.tiled->items) (void)hipFree(A.tiled->items);
-    if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
-    delete A.tiled;
-  }
+  free_tiled(A);
   A = DeviceCsr();
 }
 
@@ -82,15 +99,14 @@ int build_schedule(DeviceCsr &A, hipStream_t s)
   hipLaunchKernelGGL(schedule_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A.nrow, A.nchunks, A.row_ptr,
                      A.first_row);
   FS_HIP(hipGetLastError());
-  int *cnt = nullptr;
-  FS_HIP(hipMalloc(&cnt, sizeof(int)));
+  Scratch<int> cnt;
+  FS_HIP(cnt.alloc(1));
   FS_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
   hipLaunchKernelGGL(count_spanning_kernel, dim3((A.nchunks + 255) / 256), dim3(256), 0, s, A.nchunks, A.nnz,
                      A.row_ptr, A.first_row, cnt);
   FS_HIP(hipGetLastError());
   FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
-  FS_HIP(hipFree(cnt));
   return build_tiled(A, s);
 }
 
@@ -136,33 +152,29 @@ int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int
   FS_HIP(hipMalloc(&out.row_ptr, sizeof(int) * ((size_t)nrow + 1)));
   FS_HIP(hipMalloc(&out.cols, sizeof(int) * n));
   if (vals_dev) FS_HIP(hipMalloc(&out.vals, sizeof(double) * n));
-  int *keys_out = nullptr;
-  unsigned *idx_in = nullptr, *idx_out = nullptr;
-  void *tmp = nullptr;
+  Scratch<int> keys_out;
+  Scratch<unsigned> idx_in, idx_out;
+  Scratch<char> tmp;
   size_t tmp_bytes = 0;
-  FS_HIP(hipMalloc(&keys_out, sizeof(int) * n));
-  FS_HIP(hipMalloc(&idx_in, sizeof(unsigned) * n));
-  FS_HIP(hipMalloc(&idx_out, sizeof(unsigned) * n));
+  FS_HIP(keys_out.alloc(n));
+  FS_HIP(idx_in.alloc(n));
+  FS_HIP(idx_out.alloc(n));
   if (nnz > 0) {
     hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_in);
     FS_HIP(hipGetLastError());
     int bits = 1;
     while (bits < 31 && (1ll << bits) < (long long)nrow) ++bits;
-    FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, rows_dev, keys_out, idx_in, idx_out, (size_t)nnz, 0, bits, s));
-    FS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
-    FS_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, rows_dev, keys_out, idx_in, idx_out, (size_t)nnz, 0, bits, s));
-    hipLaunchKernelGGL(permute_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_out, cols_dev, vals_dev,
+    FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, rows_dev, keys_out.p, idx_in.p, idx_out.p, (size_t)nnz, 0, bits, s));
+    FS_HIP(tmp.alloc(tmp_bytes));
+    FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, rows_dev, keys_out.p, idx_in.p, idx_out.p, (size_t)nnz, 0, bits, s));
+    hipLaunchKernelGGL(permute_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_out.p, cols_dev, vals_dev,
                        out.cols, out.vals);
     FS_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((int64_t)nrow + 1)), dim3(256), 0, s, nrow, nnz, keys_out,
+  hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((int64_t)nrow + 1)), dim3(256), 0, s, nrow, nnz, keys_out.p,
                      out.row_ptr);
   FS_HIP(hipGetLastError());
   FS_HIP(hipStreamSynchronize(s));
-  if (tmp) FS_HIP(hipFree(tmp));
-  FS_HIP(hipFree(keys_out));
-  FS_HIP(hipFree(idx_in));
-  FS_HIP(hipFree(idx_out));
   return build_schedule(out, s);
 }
 
@@ -182,19 +194,17 @@ __global__ void expand_rows_kernel(int nrow, int64_t nnz, const int *__restrict_
 
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
 {
-  int *rows = nullptr;
+  Scratch<int> rows;
   const size_t n = (size_t)(A.nnz > 0 ? A.nnz : 1);
-  FS_HIP(hipMalloc(&rows, sizeof(int) * n));
+  FS_HIP(rows.alloc(n));
   if (A.nnz > 0) {
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, A.row_ptr, rows);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, A.row_ptr, rows.p);
     FS_HIP(hipGetLastError());
   }
   // A' in COO is (cols, rows, vals); stable sort by column keeps the row order inside each column,
   // i.e. the order in which the serial loops of At_mul_B (sparse.h:72-74) visit a column's entries
   // when the COO itself is row ordered.
-  const int rc = coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows, A.vals, s);
-  (void)hipFree(rows);
-  return rc;
+  return coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows.p, A.vals, s);
 }
 
 // ---- L2-tiled copy ---------------------------------------------------------------------------------
@@ -251,7 +261,21 @@ __global__ void max_row_len_kernel(int nrow, const int *__restrict__ row_ptr, in
   if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
 }
 
+static int build_tiled_impl(DeviceCsr &A, hipStream_t s);
+
+// The tiled copy is an optimisation: if building it fails (typically: not enough HBM for the second copy) the
+// matrix stays usable on the chunk-streaming kernel.
 int build_tiled(DeviceCsr &A, hipStream_t s)
+{
+  const int rc = build_tiled_impl(A, s);
+  if (rc != FS_OK || (A.tiled && !A.tiled->built)) {
+    free_tiled(A);
+    (void)hipGetLastError();
+  }
+  return FS_OK;
+}
+
+static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
 {
   const Options &o = options();
   if (o.tiling == 0 || A.nrow == 0 || A.nnz == 0) return FS_OK;
@@ -298,13 +322,13 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
     // ... and the matrix has no very long rows: a row's entries inside one tile are summed by one lane, and
     // a panel that holds a dense row falls behind the band sweep.  Heavy-tailed matrices (BASELINE config 5)
     // stay on the chunk-streaming kernel, whose work per workgroup does not depend on row lengths.
-    int *mx = nullptr, max_len = 0;
-    FS_HIP(hipMalloc(&mx, sizeof(int)));
+    Scratch<int> mx;
+    int max_len = 0;
+    FS_HIP(mx.alloc(1));
     FS_HIP(hipMemsetAsync(mx, 0, sizeof(int), s));
-    hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(A.nrow)), dim3(256), 0, s, A.nrow, A.row_ptr, mx);
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(A.nrow)), dim3(256), 0, s, A.nrow, A.row_ptr, mx.p);
     FS_HIP(hipMemcpyAsync(&max_len, mx, sizeof(int), hipMemcpyDeviceToHost, s));
     FS_HIP(hipStreamSynchronize(s));
-    FS_HIP(hipFree(mx));
     if ((double)max_len * W / A.ncol > 64.0 || (double)max_len > 16.0 * A.nnz / A.nrow + 4096.0) return FS_OK;
   }
   if (ntiles >= (1ll << 31)) return FS_OK;
@@ -312,34 +336,34 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   T->R = R; T->W = W; T->P = P; T->J = J; T->lcol_bits = kTiledColBits;
   A.tiled = T;
   const size_t n = (size_t)A.nnz;
-  int *rows = nullptr, *tile_ptr = nullptr;
-  unsigned *keys = nullptr, *skeys = nullptr, *idx_in = nullptr, *idx_out = nullptr;
-  void *tmp = nullptr;
+  Scratch<int> rows, tile_ptr;
+  Scratch<unsigned> keys, skeys, idx_in, idx_out;
+  Scratch<char> tmp;
   size_t tmp_bytes = 0;
-  FS_HIP(hipMalloc(&rows, sizeof(int) * n));
-  FS_HIP(hipMalloc(&keys, sizeof(unsigned) * n));
-  FS_HIP(hipMalloc(&skeys, sizeof(unsigned) * n));
-  FS_HIP(hipMalloc(&idx_in, sizeof(unsigned) * n));
-  FS_HIP(hipMalloc(&idx_out, sizeof(unsigned) * n));
-  FS_HIP(hipMalloc(&tile_ptr, sizeof(int) * ((size_t)ntiles + 1)));
+  FS_HIP(rows.alloc(n));
+  FS_HIP(keys.alloc(n));
+  FS_HIP(skeys.alloc(n));
+  FS_HIP(idx_in.alloc(n));
+  FS_HIP(idx_out.alloc(n));
+  FS_HIP(tile_ptr.alloc((size_t)ntiles + 1));
   FS_HIP(hipMalloc(&T->pk, sizeof(unsigned) * n));
   if (A.vals) FS_HIP(hipMalloc(&T->vals, sizeof(double) * n));
   hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, R, W, J, A.row_ptr, A.cols,
-                     rows, keys);
-  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in);
+                     rows.p, keys.p);
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
   FS_HIP(hipGetLastError());
   int bits = 1;
   while (bits < 32 && (1ll << bits) < ntiles) ++bits;
-  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, idx_in, idx_out, n, 0, bits, s));
-  FS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
-  FS_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, idx_in, idx_out, n, 0, bits, s));
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, R, W, J, T->lcol_bits, skeys,
-                     idx_out, rows, A.cols, A.vals, T->pk, T->vals);
-  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, s, ntiles, A.nnz, skeys, tile_ptr);
+  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
+  FS_HIP(tmp.alloc(tmp_bytes));
+  FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, R, W, J, T->lcol_bits, skeys.p,
+                     idx_out.p, rows.p, A.cols, A.vals, T->pk, T->vals);
+  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, s, ntiles, A.nnz, skeys.p, tile_ptr.p);
   FS_HIP(hipGetLastError());
   // work items are cut on the host from the tile pointers (P*J ints)
   std::vector<int> tp((size_t)ntiles + 1);
-  FS_HIP(hipMemcpyAsync(tp.data(), tile_ptr, sizeof(int) * tp.size(), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipMemcpyAsync(tp.data(), tile_ptr.p, sizeof(int) * tp.size(), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
   std::vector<int4> items;
   std::vector<int> item_ptr((size_t)P + 1);
@@ -361,8 +385,6 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMalloc(&T->item_ptr, sizeof(int) * item_ptr.size()));
   if (!items.empty()) FS_HIP(hipMemcpy(T->items, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
-  FS_HIP(hipFree(tmp)); FS_HIP(hipFree(rows)); FS_HIP(hipFree(keys)); FS_HIP(hipFree(skeys));
-  FS_HIP(hipFree(idx_in)); FS_HIP(hipFree(idx_out)); FS_HIP(hipFree(tile_ptr));
   T->slots = slots;
   T->built = true;
   return FS_OK;
