@@ -1,7 +1,6 @@
 /*
  * csr.h -- drop-in replacement for libfastsparse's csr.h (BinaryCSR and CSR), MI355X build.
- * See sparse.h in this directory for the rules.  Out of scope here: the BinaryCSR
- * (de)serialisation helpers (csr.h:83-146 of the reference).
+ * See sparse.h in this directory for the rules.
  */
 #ifndef CSR_H
 #define CSR_H
@@ -39,6 +38,10 @@ void bcsr_from_sbm(struct BinaryCSR* A, struct SparseBinaryMatrix* sbm);        
 void free_bcsr(struct BinaryCSR* bcsr);                                                             /* csr.h:24 */
 void new_csr(struct CSR* A, long nnz, int nrow, int ncol, int* rows, int* cols, double* vals);     /* csr.h:375 */
 void free_csr(struct CSR* csr);                                                                     /* csr.h:368 */
+
+/* on-disk form of a BinaryCSR (host I/O; same bytes as the reference writes, csr.h:97-146) */
+void serialize_to_file(const struct BinaryCSR* bcsr, const char* filename);
+void deserialize_from_file(struct BinaryCSR* bcsr, const char* filename);
 
 /* binary CSR products (GPU); X and Y are row-major ("row-ordered") for the multi-column forms */
 void bcsr_A_mul_B(double* y, struct BinaryCSR* A, double* x);                  /* csr.h:149 */

@@ -31,7 +31,7 @@ REFERENCE_API = [
     # dsparse.h
     "new_sdm", "sdm_transpose", "read_sdm", "new_bsdm", "sdm_A_mul_B", "sdm_At_mul_B", "bsdm_A_mul_B",
     # csr.h
-    "new_bcsr", "bcsr_from_sbm", "free_bcsr", "new_csr", "free_csr",
+    "new_bcsr", "bcsr_from_sbm", "free_bcsr", "new_csr", "free_csr", "serialize_to_file", "deserialize_from_file",
     "bcsr_A_mul_B", "bcsr_A_mul_B2", "bcsr_A_mul_B4", "bcsr_A_mul_B8", "bcsr_A_mul_B8_auto", "bcsr_A_mul_Bn",
     "bcsr_A_mul_B32n", "bcsr_AA_mul_B", "parallel_bcsr_AA_mul_B", "csr_A_mul_B", "csr_A_mul_Bn",
     "csr_At_mul_B", "bcsr_At_mul_B",

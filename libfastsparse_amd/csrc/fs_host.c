@@ -295,3 +295,51 @@ FS_EXPORT void solve2sym(double *X, double *A, double *RHS)
   X[2] = i0 * RHS[2] + i2 * RHS[3];
   X[3] = i2 * RHS[2] + i1 * RHS[3];
 }
+
+/* ---- BinaryCSR on-disk form (csr.h:83-146 of the reference) ----------------------
+ * text-tagged raw dump: header line, "struct BinaryCSR\n" + the 32-byte struct as it sits in memory (its two
+ * pointers are meaningless on disk), "int[nrow+1]\n" + row_ptr, "int[nnz]\n" + cols.  Files written by the
+ * reference load here and vice versa. */
+#define FS_BCSR_HEADER "BINARY_CSR: struct BinaryCSR, int[nrow], int[nnz]\n"
+
+static void expect_line(FILE *f, const char *want, const char *what)
+{
+  char buf[256];
+  if (!fgets(buf, sizeof buf, f) || strncmp(buf, want, sizeof buf)) {
+    printf("ERROR: could not read data from file, %s\n  expected: \"%s\"\n      read: \"%s\"\n", what, want, buf);
+    exit(-1);
+  }
+}
+
+FS_EXPORT void serialize_to_file(const struct BinaryCSR *bcsr, const char *filename)
+{
+  FILE *f = fopen(filename, "w+");
+  if (!f) { fprintf(stderr, "File error: %s\n", filename); exit(1); }
+  fputs(FS_BCSR_HEADER, f);
+  fputs("struct BinaryCSR\n", f);
+  fwrite(bcsr, sizeof *bcsr, 1, f);
+  fprintf(f, "int[%d]\n", bcsr->nrow + 1);
+  fwrite(bcsr->row_ptr, sizeof(int), (size_t)bcsr->nrow + 1, f);
+  fprintf(f, "int[%ld]\n", bcsr->nnz);
+  fwrite(bcsr->cols, sizeof(int), (size_t)bcsr->nnz, f);
+  fclose(f);
+}
+
+FS_EXPORT void deserialize_from_file(struct BinaryCSR *bcsr, const char *filename)
+{
+  char tag[32];
+  FILE *f = fopen(filename, "r");
+  if (!f) { fprintf(stderr, "File error: %s\n", filename); exit(1); }
+  expect_line(f, FS_BCSR_HEADER, "Invalid file format or version");
+  expect_line(f, "struct BinaryCSR\n", "struct data corrupted");
+  if (fread(bcsr, sizeof *bcsr, 1, f) != 1) { printf("ERROR: struct data truncated\n"); exit(-1); }
+  bcsr->row_ptr = (int *)xmalloc(sizeof(int) * ((size_t)bcsr->nrow + 1));
+  bcsr->cols = (int *)xmalloc(sizeof(int) * (size_t)bcsr->nnz);
+  snprintf(tag, sizeof tag, "int[%d]\n", bcsr->nrow + 1);
+  expect_line(f, tag, "nrow data corrupted");
+  if (fread(bcsr->row_ptr, sizeof(int), (size_t)bcsr->nrow + 1, f) != (size_t)bcsr->nrow + 1) { printf("ERROR: row_ptr truncated\n"); exit(-1); }
+  snprintf(tag, sizeof tag, "int[%ld]\n", bcsr->nnz);
+  expect_line(f, tag, "cols data corrupted");
+  if (fread(bcsr->cols, sizeof(int), (size_t)bcsr->nnz, f) != (size_t)bcsr->nnz) { printf("ERROR: cols truncated\n"); exit(-1); }
+  fclose(f);
+}

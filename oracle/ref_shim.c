@@ -39,3 +39,7 @@ void ref_bcsr_from_sbm(struct BinaryCSR *A, struct SparseBinaryMatrix *sbm)
 
 void ref_cbcsr_from_sbm(struct ColBinaryCSR *A, struct SparseBinaryMatrix *sbm, int colblocksize)
 { cbcsr_from_sbm(A, sbm, colblocksize); }
+
+/* static in csr.h:97,117 */
+void ref_serialize_to_file(const struct BinaryCSR *b, const char *fn) { serialize_to_file(b, fn); }
+void ref_deserialize_from_file(struct BinaryCSR *b, const char *fn) { deserialize_from_file(b, fn); }

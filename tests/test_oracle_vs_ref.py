@@ -80,3 +80,27 @@ def test_fixture_loader_matches_read_sbm_read_sdm():
     nrow, ncol, rows, cols, vals = S.fixture_sdm()
     assert (D.nrow, D.ncol, D.nnz) == (100, 50, 470)
     assert np.array_equal(R.arr(D.vals, D.nnz, np.float64), vals)
+
+
+def test_bcsr_file_format_interoperates_with_reference(tmp_path):
+    """csr.h:97-146: a BinaryCSR written by the reference loads through the product's deserialize_from_file
+    and the other way round; same bytes on disk (up to the two meaningless pointers inside the struct dump)"""
+    import _hipbackend as H
+    R = _refbind.Ref()
+    F = H.HostFormats()
+    nrow, ncol, rows, cols, _ = S.fixture_sbm()
+    A_ref = R.bcsr(nrow, ncol, rows, cols)
+    A_own = F.bcsr(nrow, ncol, rows.copy(), cols.copy())
+    f1, f2 = str(tmp_path / "ref.csr.bin").encode(), str(tmp_path / "own.csr.bin").encode()
+    R.lib.ref_serialize_to_file(C.byref(A_ref), f1)
+    F.L.serialize_to_file(C.byref(A_own), f2)
+    b1, b2 = open(f1, "rb").read(), open(f2, "rb").read()
+    off = len(b"BINARY_CSR: struct BinaryCSR, int[nrow], int[nnz]\nstruct BinaryCSR\n")
+    assert len(b1) == len(b2) and b1[:off + 16] == b2[:off + 16] and b1[off + 32:] == b2[off + 32:]
+    B1, B2 = H.BCSR(), _refbind.BCSR()
+    F.L.deserialize_from_file(C.byref(B1), f1)          # product reads the reference's file
+    R.lib.ref_deserialize_from_file(C.byref(B2), f2)    # reference reads the product's file
+    rp, cc, _ = O.coo_to_csr(nrow, rows, cols)
+    for B, arr in ((B1, F.arr), (B2, R.arr)):
+        assert (B.nrow, B.ncol, B.nnz) == (nrow, ncol, len(rows))
+        assert np.array_equal(arr(B.row_ptr, nrow + 1, np.int32), rp) and np.array_equal(arr(B.cols, len(rows), np.int32), cc)
