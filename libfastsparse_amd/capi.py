@@ -53,8 +53,13 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise FastsparseError(f"{LIB_PATH} is missing: build it first (libfastsparse_amd._build.build()); "
-                              "there is no CPU fallback")
+        # a fresh checkout: compile the HIP sources in-tree (hipcc cross-compiles gfx950 without a GPU)
+        try:
+            from . import _build
+            _build.build()
+        except Exception as ex:
+            raise FastsparseError(f"{LIB_PATH} is missing and could not be built ({ex!r}); "
+                                  "there is no CPU fallback") from ex
     L = C.CDLL(LIB_PATH)   # RTLD_LOCAL: the reference-named symbols must not interpose other libraries
     L.fs_version.restype = C.c_char_p
     L.fs_last_error.restype = C.c_char_p
