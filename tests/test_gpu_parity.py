@@ -312,3 +312,67 @@ def test_dropin_cache_invalidation(hip):
     f(y.ctypes.data_as(hip.dp), C.byref(A), x.ctypes.data_as(hip.dp))
     assert np.array_equal(y, O.coo_mul(c.nrow, rows, cols, None, x))
     be.L.fs_release_all()
+
+
+def test_cbcsr_lds_staging_paths(hip):
+    """cbcsr kernel with the x tile staged in LDS (forced), read from L2 (forced) and by the heuristic: same bits"""
+    from libfastsparse_amd import capi
+    be = hip.HipDeviceBackend()
+    c = BY_NAME["syn_u16_2048"]
+    x = c.xs["bench"]
+    nb, rp, cc = O.coo_to_cbcsr(512, c.nrow, c.ncol, c.rows, c.cols)
+    ref = O.cbcsr_mul(c.nrow, nb, rp, cc, x)
+    for mode in (4, 5, 0):
+        capi.set_option("spmv_kernel", mode)
+        try:
+            y = be.cbcsr_mul(c.nrow, c.ncol, c.rows, c.cols, 512, x)
+        finally:
+            capi.set_option("spmv_kernel", 0)
+        assert np.array_equal(y, ref), mode       # cell sums added block by block: the one-thread CPU order
+
+
+def test_csr_create_variants(hip):
+    """fs_csr_create: host arrays, device copy, device borrow, and a borrow request on mis-aligned device
+    arrays (falls back to a copy) all give the same product"""
+    import torch
+    from libfastsparse_amd import capi
+    c = BY_NAME["syn_dup_1024"]
+    rp, cc, vv = O.coo_to_csr(c.nrow, c.rows, c.cols, c.vals)
+    x = c.xs["int"]
+    ref = O.csr_mul(c.nrow, rp, cc, vv, x)
+    xd = torch.from_numpy(x).cuda()
+    drp, dcc, dvv = (torch.from_numpy(a).cuda() for a in (rp, cc, vv))
+    pad_c = torch.empty(len(cc) + 1, dtype=torch.int32, device="cuda")
+    pad_v = torch.empty(len(vv) + 1, dtype=torch.float64, device="cuda")
+    pad_c[1:] = dcc
+    pad_v[1:] = dvv
+    variants = [capi.Matrix.from_csr(c.nrow, c.ncol, rp, cc, vv),                       # host arrays
+                capi.Matrix.from_csr(c.nrow, c.ncol, drp, dcc, dvv),                    # device, copied
+                capi.Matrix.from_csr(c.nrow, c.ncol, drp, dcc, dvv, borrow=True),       # device, in place
+                capi.Matrix.from_csr(c.nrow, c.ncol, drp, pad_c[1:], pad_v[1:], borrow=True)]   # 4-byte aligned cols
+    capi.set_option("strict_order", 1)
+    try:
+        for m in variants:
+            y = torch.full((c.nrow,), -1.0, dtype=torch.float64, device="cuda")
+            m.spmv(y, xd, capi.current_stream())
+            assert np.array_equal(y.cpu().numpy(), ref)
+    finally:
+        capi.set_option("strict_order", 0)
+    assert variants[0].algorithmic_bytes() == 12 * len(cc) + 4 * (c.nrow + 1) + 8 * c.nrow + 8 * c.ncol
+
+
+def test_error_paths_return_codes(hip):
+    """the device layer reports, it does not crash: NULL handles, k < 1, transpose not built"""
+    import torch
+    from libfastsparse_amd import capi
+    L = capi.lib()
+    c = BY_NAME["kat_sdm_6x4"]
+    rp, cc, vv = O.coo_to_csr(c.nrow, c.rows, c.cols, c.vals)
+    m = capi.Matrix.from_csr(c.nrow, c.ncol, rp, cc, vv)
+    y = torch.zeros(c.ncol, dtype=torch.float64, device="cuda")
+    x = torch.zeros(c.nrow, dtype=torch.float64, device="cuda")
+    assert L.fs_spmv_t(m.h, y.data_ptr(), x.data_ptr(), None) == -4 and b"build_transpose" in L.fs_last_error()
+    assert L.fs_spmv(None, y.data_ptr(), x.data_ptr(), None) == -2
+    assert L.fs_spmm(m.h, y.data_ptr(), x.data_ptr(), 0, None) == -2
+    assert L.fs_set_option(b"no_such_option", 1) == -2
+    assert not L.fs_csr_create(-1, 1, 0, rp.ctypes.data, cc.ctypes.data, None, 0, 0)
