@@ -54,8 +54,15 @@ const char *fs_version(void);
 const char *fs_last_error(void);
 int  fs_device_count(void);
 int  fs_set_device(int device);
-/* option names: "strict_order" (0/1: thread-per-row sequential sums, bit-identical to the
- * strict-IEEE CPU order for arbitrary x), "spmv_kernel" (0 = auto) */
+/* option names: "strict_order" (0/1: storage-order sums, bit-identical to the strict-IEEE CPU order for
+ * arbitrary x), "spmv_kernel" (0 = auto, 1 streaming, 2 lanes-per-row, 6 tiled), "tiling" (0 never build the
+ * L2-tiled copy, 1 auto, 2 always; read when a matrix is created), "tile_rows" / "tile_cols" (0 = auto).
+ * Options are process-wide.
+ *
+ * Threads and streams: every entry point may be called from several host threads.  Products on ONE handle from
+ * several streams at once are safe with the tiled kernel and the multi-column kernels; the chunk-streaming
+ * kernel keeps per-handle scratch for rows that cross chunks, so overlapping launches of it on one handle must
+ * be ordered by the caller (or use one handle per stream). */
 int  fs_set_option(const char *name, int value);
 int  fs_get_option(const char *name);
 

@@ -7,6 +7,10 @@
 // (0.17 flop/B), the spare multiply issue slot costs nothing.
 //
 // Kernels
+//   spmv_tiled_kernel    y = A x on the L2-tiled copy (row panels x column bands): the default for matrices
+//                        whose x does not fit a CU's L1 many times over.  One 1024-thread workgroup per CU;
+//                        producer waves stream the entries and gather x inside the current band, consumer
+//                        waves reduce the staged products into the panel's y slice in LDS.
 //   spmv_stream_kernel   y = A x, CSR or pattern-only CSR.  One 256-thread workgroup streams a
 //                        fixed 2048-non-zero chunk of cols/vals with 16-byte loads, gathers x,
 //                        parks the products in LDS and reduces them per row.  Work per
