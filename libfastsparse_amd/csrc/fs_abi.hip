@@ -297,6 +297,18 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
   if (!rc && hipMemcpy(&last, M->row_ptr + ncell, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = FS_ERR_HIP;
   M->nnz = last;
   if (!rc) rc = fs::to_device(&M->cols, cols, (size_t)M->nnz, space);
+  // big enough to pay for a temporary of cell sums: run the cells through the chunk-streaming kernel
+  if (!rc && M->nnz >= (1 << 20) && ncell < (size_t)0x7fffffff) {
+    fs::DeviceCsr &c = M->cells;
+    c.nrow = (int)ncell; c.ncol = ncol; c.nnz = M->nnz;
+    c.row_ptr = M->row_ptr; c.cols = M->cols; c.vals = nullptr; c.owns = false;
+    const int tiling = fs::options().tiling;
+    fs::options().tiling = 0;              // the cell view is only ever streamed
+    rc = fs::build_schedule(c, nullptr);
+    fs::options().tiling = tiling;
+    if (!rc && hipMalloc(&M->cell_sums, sizeof(double) * (ncell ? ncell : 1)) != hipSuccess) rc = FS_ERR_HIP;
+    M->use_cells = !rc;
+  }
   if (rc) { fs_cbcsr_destroy(M); return nullptr; }
   return M;
 }
@@ -304,6 +316,8 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
 void fs_cbcsr_destroy(fs_cbcsr_t A)
 {
   if (!A) return;
+  fs::free_csr(A->cells);        // borrowed arrays: frees the schedule only
+  if (A->cell_sums) (void)hipFree(A->cell_sums);
   if (A->row_ptr) (void)hipFree(A->row_ptr);
   if (A->cols) (void)hipFree(A->cols);
   delete A;

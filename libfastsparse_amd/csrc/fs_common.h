@@ -78,6 +78,12 @@ struct fs_cbcsr_s {
   int *row_ptr = nullptr;      // nblocks*nrow + 1, cell = block*nrow + row
   int *cols = nullptr;
   int device = 0;
+  // large matrices: the cell array IS a pattern-only CSR with nblocks*nrow rows; `cells` views it (borrowed
+  // arrays + chunk schedule) so that the chunk-streaming kernel produces the cell sums, which are then added
+  // block by block per row
+  fs::DeviceCsr cells;
+  double *cell_sums = nullptr;  // nblocks*nrow
+  bool use_cells = false;
 };
 
 namespace fs {

@@ -602,9 +602,33 @@ int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream
   return FS_OK;
 }
 
+// y[r] = 0 + sum over column blocks, in block order, of the cell sums (cbcsr.h:96-103 with one thread)
+__global__ __launch_bounds__(kBlock) void cbcsr_combine_kernel(int nrow, int nblocks, const double *__restrict__ cell,
+                                                              double *__restrict__ y)
+{
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nrow) return;
+  double tot = 0.0;
+  for (int b = 0; b < nblocks; ++b) tot += cell[(int64_t)b * nrow + r];
+  y[r] = 0.0 + tot;
+}
+
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
+  // large matrices: cell sums by the chunk-streaming kernel over the (block, row) cells, then one pass that
+  // adds each row's cells block by block.  spmv_kernel 4 / 5 force the one-thread-per-row kernels below.
+  if (A.use_cells && options().spmv_kernel != 4 && options().spmv_kernel != 5) {
+    const int keep = options().spmv_kernel;
+    options().spmv_kernel = 1;
+    const int rc = launch_spmv(A.cells, A.cell_sums, x, s);
+    options().spmv_kernel = keep;
+    if (rc) return rc;
+    hipLaunchKernelGGL(cbcsr_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       A.nrow, A.nblocks, A.cell_sums, y);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+  }
   const unsigned grid = (unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock);
   // stage the x tile in LDS when it fits and a workgroup's cells of one block hold enough
   // entries to amortise the copy (one tile read per workgroup per block)

@@ -376,3 +376,36 @@ def test_error_paths_return_codes(hip):
     assert L.fs_spmm(m.h, y.data_ptr(), x.data_ptr(), 0, None) == -2
     assert L.fs_set_option(b"no_such_option", 1) == -2
     assert not L.fs_csr_create(-1, 1, 0, rp.ctypes.data, cc.ctypes.data, None, 0, 0)
+
+
+def test_cbcsr_large_uses_cell_streaming(hip):
+    """>= 1 M entries: cell sums by the streaming kernel + block-order combine; equals the one-thread-per-row
+    kernels bit for bit with integer x, and the oracle's one-thread order under strict_order"""
+    import torch
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    nrow, ncol, per, cbs = 200_000, 300_000, 12, 65536
+    rp, cc, _ = pysynth.uniform(nrow, ncol, per, 77, valued=False)
+    rows = np.repeat(np.arange(nrow, dtype=np.int32), per)
+    nb, crp, ccc = O.coo_to_cbcsr(cbs, nrow, ncol, rows, cc)
+    m = capi.ColBlockMatrix(nrow, ncol, nb, cbs, torch.from_numpy(crp).cuda(), torch.from_numpy(ccc).cuda())
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    xi = S.x_int(3, ncol)
+    ref = O.cbcsr_mul(nrow, nb, crp, ccc, xi)
+    for mode in (0, 5, 4):
+        capi.set_option("spmv_kernel", mode)
+        try:
+            m.spmv(y, torch.from_numpy(xi).cuda(), capi.current_stream())
+        finally:
+            capi.set_option("spmv_kernel", 0)
+        assert np.array_equal(y.cpu().numpy(), ref), mode
+    xs = S.x_sin(ncol)
+    ref = O.cbcsr_mul(nrow, nb, crp, ccc, xs)
+    m.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+    assert np.max(np.abs(y.cpu().numpy() - ref)) <= TOL * per * 1.0
+    capi.set_option("strict_order", 1)
+    try:
+        m.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+    finally:
+        capi.set_option("strict_order", 0)
+    assert np.array_equal(y.cpu().numpy(), ref)

@@ -130,6 +130,29 @@ def main():
             report(out, f"c2_spmm_k{k}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
             del X, Y
         del A, rp, cc, vv
+    if "cbcsr" in what:
+        # column-blocked binary CSR (cbcsr.h): 2 M x 1 M, 64 per row, 4 column blocks of 262144
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _hipbackend as H
+        from oracle import pysynth
+        nr, nc, per, cbs = 2_000_000, 1_000_000, 64, 262144
+        rp, cc, _ = pysynth.uniform(nr, nc, per, 0x5EED0003, valued=False)
+        rows = np.repeat(np.arange(nr, dtype=np.int32), per)
+        F = H.HostFormats()
+        t0 = time.time()
+        K = F.cbcsr(cbs, nr, nc, rows, cc)
+        print("host new_cbcsr s", time.time() - t0, flush=True)
+        crp = F.arr(K.row_ptr, K.nblocks * nr + 1, np.int32)
+        ccc = F.arr(K.cols, len(cc), np.int32)
+        m = capi.ColBlockMatrix(nr, nc, K.nblocks, cbs, torch.from_numpy(crp).cuda(), torch.from_numpy(ccc).cuda())
+        x = torch.randint(-1000, 1001, (nc,), device="cuda").to(torch.float64)
+        y = torch.empty(nr, dtype=torch.float64, device="cuda")
+        B = 4 * len(cc) + 4 * (K.nblocks * nr + 1) + 8 * nr + 8 * nc
+        for mode, label in ((0, "cells_streamed"), (5, "thread_per_row"), (4, "thread_per_row_lds_x")):
+            capi.set_option("spmv_kernel", mode)
+            report(out, f"cbcsr_2Mx1M_64_{label}", B, timeit(lambda: m.spmv(y, x, st), iters=5, warm=1))
+        capi.set_option("spmv_kernel", 0)
     if "cg" in what:
         # the consumer of the path (cg.h): (A'A + 5 I) x = b on the config-2 pattern, vectors resident in HBM
         import ctypes as C
