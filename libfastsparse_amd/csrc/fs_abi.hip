@@ -90,6 +90,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "tiling")) { fs::options().tiling = value; return FS_OK; }
   if (!strcmp(name, "tile_rows")) { fs::options().tile_rows = value; return FS_OK; }
   if (!strcmp(name, "tile_cols")) { fs::options().tile_cols = value; return FS_OK; }
+  if (!strcmp(name, "tile_split")) { fs::options().tile_split = value; return FS_OK; }
   if (!strcmp(name, "tiled_flags")) { fs::options().tiled_flags = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;

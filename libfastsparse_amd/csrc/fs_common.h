@@ -59,6 +59,12 @@ struct TiledCsr {
   int4 *items = nullptr;       // nitems: {first entry, count, band, 0}
   int *item_ptr = nullptr;     // P + 1
   int nitems = 0;
+  int *panel_row = nullptr;    // P + 1: first (virtual) row of every panel
+  // rows longer than `split` entries are cut into virtual rows of at most `split` consecutive entries
+  int split = 0;               // 0: no row was cut, virtual rows = rows
+  int nvrow = 0;               // number of virtual rows
+  int *vfirst = nullptr;       // nrow + 1: first virtual row of every row (only when split > 0)
+  double *yv = nullptr;        // nvrow: sums of the virtual rows, combined per row after the kernel
   int slots = 256;             // workgroups resident together (1 per CU)
 };
 
@@ -104,6 +110,7 @@ struct Options {
   int tiling = 1;        // 1: build the L2-tiled copy when the heuristic says it pays, 2: always, 0: never
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
+  int tile_split = 0;    // rows longer than this are cut into virtual rows (0 = 256)
   int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
 };
 Options &options();

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -37,6 +38,9 @@ static void free_tiled(DeviceCsr &A)
   if (A.tiled->vals) (void)hipFree(A.tiled->vals);
   if (A.tiled->items) (void)hipFree(A.tiled->items);
   if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
+  if (A.tiled->panel_row) (void)hipFree(A.tiled->panel_row);
+  if (A.tiled->vfirst) (void)hipFree(A.tiled->vfirst);
+  if (A.tiled->yv) (void)hipFree(A.tiled->yv);
   delete A.tiled;
   A.tiled = nullptr;
 }
@@ -208,34 +212,64 @@ int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
 }
 
 // ---- L2-tiled copy ---------------------------------------------------------------------------------
-// key of entry e = panel(row) * J + band(col); a stable sort by key starting from CSR order leaves every
-// (panel, band) tile ordered by row and, inside a row, in CSR storage order.
-__global__ void tile_key_kernel(int nrow, int64_t nnz, int R, int W, int J, const int *__restrict__ row_ptr,
-                                const int *__restrict__ cols, int *__restrict__ rows, unsigned *__restrict__ keys)
+// Long rows are cut into pieces of at most `split` consecutive entries ("virtual rows"): the tiled kernel then
+// never meets a row that dwarfs a panel or a run that one lane has to walk for long, and the pieces' sums are
+// added per row, in storage order, by a combine pass.  A matrix without long rows is its own virtual matrix.
+__global__ void piece_count_kernel(int nrow, int split, const int *__restrict__ row_ptr, int *__restrict__ cnt)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrow) return;
+  if (r == nrow) { cnt[r] = 0; return; }
+  const int len = row_ptr[r + 1] - row_ptr[r];
+  cnt[r] = len <= split ? 1 : (len + split - 1) / split;
+}
+
+__global__ void vrow_fill_kernel(int nrow, int split, const int *__restrict__ row_ptr, const int *__restrict__ vfirst,
+                                 int *__restrict__ vrow_ptr)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrow) return;
+  if (r == nrow) { vrow_ptr[vfirst[nrow]] = row_ptr[nrow]; return; }
+  const int a = row_ptr[r], v0 = vfirst[r], k = vfirst[r + 1] - v0;
+  for (int i = 0; i < k; ++i) vrow_ptr[v0 + i] = a + i * split;
+}
+
+// last index i in [0, n] with a[i] <= key (a non-decreasing, a[0] <= key)
+__device__ __forceinline__ int last_le(const int *__restrict__ a, int n, int64_t key)
+{
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    if ((int64_t)a[mid] <= key) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// key of entry e = panel(virtual row) * J + band(col); a stable sort by key starting from CSR order leaves every
+// (panel, band) tile ordered by virtual row and, inside a row, in CSR storage order.
+__global__ void tile_key_kernel(int nvrow, int64_t nnz, int P, int W, int J, const int *__restrict__ vrow_ptr,
+                                const int *__restrict__ panel_row, const int *__restrict__ cols,
+                                int *__restrict__ vrows, unsigned *__restrict__ keys)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
-  int lo = 0, hi = nrow;  // last r with row_ptr[r] <= i
-  while (lo < hi) {
-    const int mid = lo + ((hi - lo + 1) >> 1);
-    if ((int64_t)row_ptr[mid] <= i) lo = mid; else hi = mid - 1;
-  }
-  rows[i] = lo;
-  keys[i] = (unsigned)(lo / R) * (unsigned)J + (unsigned)(cols[i] / W);
+  const int v = last_le(vrow_ptr, nvrow, i);      // empty virtual rows share a start: take the last, non-empty one
+  vrows[i] = v;
+  const int p = last_le(panel_row, P, v);
+  keys[i] = (unsigned)p * (unsigned)J + (unsigned)(cols[i] / W);
 }
 
-__global__ void tile_pack_kernel(int64_t nnz, int R, int W, int J, int lcol_bits, const unsigned *__restrict__ skeys,
-                                 const unsigned *__restrict__ perm, const int *__restrict__ rows,
-                                 const int *__restrict__ cols, const double *__restrict__ vals,
-                                 unsigned *__restrict__ pk, double *__restrict__ vals_out)
+__global__ void tile_pack_kernel(int64_t nnz, int W, int J, int lcol_bits, const unsigned *__restrict__ skeys,
+                                 const unsigned *__restrict__ perm, const int *__restrict__ vrows,
+                                 const int *__restrict__ panel_row, const int *__restrict__ cols,
+                                 const double *__restrict__ vals, unsigned *__restrict__ pk, double *__restrict__ vals_out)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
   const unsigned src = perm[i];
   const unsigned key = skeys[i];
-  const int r = rows[src], c = cols[src];
   const unsigned p = key / (unsigned)J, j = key % (unsigned)J;
-  const unsigned lrow = (unsigned)(r - (int)p * R), lcol = (unsigned)(c - (int)j * W);
+  const unsigned lrow = (unsigned)(vrows[src] - panel_row[p]), lcol = (unsigned)(cols[src] - (int)j * W);
   pk[i] = (lrow << lcol_bits) | lcol;
   if (vals) vals_out[i] = vals[src];
 }
@@ -283,21 +317,93 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
   const int slots = (ncu > 8 ? ncu : 256) / 8 * 8;  // one workgroup per CU, a multiple of the 8 XCDs
-  // panel height: P a multiple of the resident workgroup count where the matrix is tall enough
+  const double per_row = (double)A.nnz / A.nrow;
+
+  // ---- cheap rejections first (auto mode) ----------------------------------------------------------
+  const int64_t x_bytes = (int64_t)A.ncol * 8;
+  if (o.tiling == 1) {
+    // pays when x does not fit the 32 KiB L1 of a CU many times over ...
+    // (measured, config-2 rows and non-zeros: x of 0.5-2 MB 0.75-0.82 ms tiled vs 0.92 ms streaming -- narrow
+    // bands are L1 resident; x of 4-80 MB 0.70-1.06 ms vs 1.07-2.99 ms; x of 64 KB 1.3 ms vs 0.8 ms)
+    if (x_bytes <= (256 << 10) || A.nnz < (4 << 20)) return FS_OK;
+  }
+
+  // ---- virtual rows ------------------------------------------------------------------------------------
+  int max_len = 0;
+  {
+    Scratch<int> mx;
+    FS_HIP(mx.alloc(1));
+    FS_HIP(hipMemsetAsync(mx, 0, sizeof(int), s));
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(A.nrow)), dim3(256), 0, s, A.nrow, A.row_ptr, mx.p);
+    FS_HIP(hipMemcpyAsync(&max_len, mx, sizeof(int), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+  }
+  int split = o.tile_split > 0 ? o.tile_split : 256;
+  const bool virt = max_len > split;
+  TiledCsr *T = new TiledCsr();
+  A.tiled = T;
+  T->slots = slots; T->lcol_bits = kTiledColBits; T->split = virt ? split : 0;
+  Scratch<int> vrow_ptr_own;
+  const int *vrow_ptr = A.row_ptr;
+  int nvrow = A.nrow;
+  if (virt) {
+    Scratch<int> cnt;
+    Scratch<char> tmp;
+    size_t tmp_bytes = 0;
+    FS_HIP(cnt.alloc((size_t)A.nrow + 1));
+    FS_HIP(hipMalloc(&T->vfirst, sizeof(int) * ((size_t)A.nrow + 1)));
+    hipLaunchKernelGGL(piece_count_kernel, dim3(grid_for((int64_t)A.nrow + 1)), dim3(256), 0, s, A.nrow, split, A.row_ptr,
+                       cnt.p);
+    FS_HIP(hipGetLastError());
+    FS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.p, T->vfirst, 0, (size_t)A.nrow + 1, rocprim::plus<int>(), s));
+    FS_HIP(tmp.alloc(tmp_bytes));
+    FS_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, cnt.p, T->vfirst, 0, (size_t)A.nrow + 1, rocprim::plus<int>(), s));
+    FS_HIP(hipMemcpyAsync(&nvrow, T->vfirst + A.nrow, sizeof(int), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    FS_HIP(vrow_ptr_own.alloc((size_t)nvrow + 1));
+    hipLaunchKernelGGL(vrow_fill_kernel, dim3(grid_for((int64_t)A.nrow + 1)), dim3(256), 0, s, A.nrow, split, A.row_ptr,
+                       T->vfirst, vrow_ptr_own.p);
+    FS_HIP(hipGetLastError());
+    vrow_ptr = vrow_ptr_own.p;
+    FS_HIP(hipMalloc(&T->yv, sizeof(double) * (size_t)nvrow));
+  }
+  T->nvrow = nvrow;
+
+  // ---- panels: at most R virtual rows; with cut rows, panels of EQUAL non-zero count (0.8x what R average
+  // rows hold, so that nearly every panel is bounded by non-zeros, not by rows): the band sweep stays in step
+  // only if all workgroups of a generation carry the same work -------------------------------------------
   int R = o.tile_rows;
   if (R <= 0) {
-    const int64_t g = ((int64_t)A.nrow + (int64_t)slots * kTiledRowsMax - 1) / ((int64_t)slots * kTiledRowsMax);
-    R = (int)(((int64_t)A.nrow + slots * g - 1) / (slots * g));
-    if (R < 256) R = A.nrow < 256 ? A.nrow : 256;
+    const int64_t g = ((int64_t)nvrow + (int64_t)slots * kTiledRowsMax - 1) / ((int64_t)slots * kTiledRowsMax);
+    R = (int)(((int64_t)nvrow + slots * g - 1) / (slots * g));
+    if (R < 256) R = nvrow < 256 ? nvrow : 256;
   }
   if (R > kTiledRowsMax) R = kTiledRowsMax;
-  const int P = (A.nrow + R - 1) / R;
-  // band width: tiles of about 0.9 work items on average (full 8-entries-per-thread items amortise the
-  // two barriers per item), at most 2 MiB of x
+  std::vector<int> panel_row;
+  if (!virt) {
+    for (int r = 0; r < nvrow; r += R) panel_row.push_back(r);
+  } else {
+    std::vector<int> vp((size_t)nvrow + 1);
+    FS_HIP(hipMemcpyAsync(vp.data(), vrow_ptr, sizeof(int) * vp.size(), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    const int64_t cap = (int64_t)(0.8 * (double)A.nnz * R / nvrow) + split;
+    for (int r = 0; r < nvrow;) {
+      panel_row.push_back(r);
+      int e = (r + R < nvrow) ? r + R : nvrow;
+      if ((int64_t)vp[e] - vp[r] > cap) {  // largest e with nnz(r..e) <= cap, at least one row
+        e = (int)(std::upper_bound(vp.begin() + r + 1, vp.begin() + e + 1, (int)(vp[r] + cap)) - vp.begin()) - 1;
+        if (e <= r) e = r + 1;
+      }
+      r = e;
+    }
+  }
+  const int P = (int)panel_row.size();
+  panel_row.push_back(nvrow);
+
+  // ---- band width: tiles of about 0.9 work items on average, at most 2 MiB of x ---------------------------
   int W = o.tile_cols;
   if (W <= 0) {
-    const double per_row = (double)A.nnz / A.nrow;
-    double w = 0.9 * kTiledItem * (double)A.ncol / (per_row * R);
+    double w = 0.9 * kTiledItem * (double)A.ncol * P / (double)A.nnz;
     if (w < 4096) w = 4096;
     if (w > (1 << kTiledColBits)) w = (1 << kTiledColBits);
     W = (int)w;
@@ -307,40 +413,30 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   const int J = (A.ncol + W - 1) / W;
   const int64_t ntiles = (int64_t)P * J;
   if (o.tiling == 1) {
-    // pays when x does not fit the 32 KiB L1 of a CU many times over and tiles are not hopelessly thin ...
-    // (measured, config-2 rows and non-zeros: x of 0.5-2 MB 0.75-0.82 ms tiled vs 0.92 ms streaming -- narrow
-    // bands are L1 resident; x of 4-80 MB 0.70-1.06 ms vs 1.07-2.99 ms; x of 64 KB 1.3 ms vs 0.8 ms)
-    const int64_t x_bytes = (int64_t)A.ncol * 8;
-    if (x_bytes <= (256 << 10) || A.nnz < (4 << 20) || (double)A.nnz / ntiles < 256.0) return FS_OK;
-    // ... and while re-reading x once per XCD and per generation of resident workgroups costs less than the
-    // L2 misses it saves.  Measured rates: tiled ~150 G entries/s plus x refills at ~5 TB/s; streaming kernel
-    // ~172 G entries/s while x stays L2 resident, ~53 G entries/s once every gather misses.
+    // tiles must not be hopelessly thin, and re-reading x once per generation of resident workgroups must
+    // cost less than the L2 misses it saves.  Measured: tiled ~150 G entries/s; one generation's sweep of x
+    // costs ~x_bytes / 2.7 TB/s (the XCDs sweep in step, so a band leaves HBM once and the other seven L2s are
+    // filled from the Infinity Cache: 10 M rows x 16, x of 80 / 160 / 320 / 800 MB: 1.06 / 1.22 / 1.52 / 1.96 ms);
+    // streaming kernel ~172 G entries/s while x stays L2 resident, ~53 G entries/s once every gather misses.
+    if ((double)A.nnz / ntiles < 256.0) return FS_OK;
     const double gens = (double)((P + slots - 1) / slots);
-    const double t_tiled = (double)A.nnz / 150e9 + gens * 8.0 * (double)A.ncol * 8.0 / 5e12;
+    const double t_tiled = (double)A.nnz / 150e9 + gens * (double)x_bytes / 2.7e12;
     const double t_stream = (double)A.nnz / (x_bytes <= (3 << 20) ? 172e9 : 53e9);
     if (t_tiled > 0.95 * t_stream) return FS_OK;
-    // ... and the matrix has no very long rows: a row's entries inside one tile are summed by one lane, and
-    // a panel that holds a dense row falls behind the band sweep.  Heavy-tailed matrices (BASELINE config 5)
-    // stay on the chunk-streaming kernel, whose work per workgroup does not depend on row lengths.
-    Scratch<int> mx;
-    int max_len = 0;
-    FS_HIP(mx.alloc(1));
-    FS_HIP(hipMemsetAsync(mx, 0, sizeof(int), s));
-    hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(A.nrow)), dim3(256), 0, s, A.nrow, A.row_ptr, mx.p);
-    FS_HIP(hipMemcpyAsync(&max_len, mx, sizeof(int), hipMemcpyDeviceToHost, s));
-    FS_HIP(hipStreamSynchronize(s));
-    if ((double)max_len * W / A.ncol > 64.0 || (double)max_len > 16.0 * A.nnz / A.nrow + 4096.0) return FS_OK;
   }
   if (ntiles >= (1ll << 31)) return FS_OK;
-  TiledCsr *T = new TiledCsr();
-  T->R = R; T->W = W; T->P = P; T->J = J; T->lcol_bits = kTiledColBits;
-  A.tiled = T;
+  (void)per_row;
+  T->R = R; T->W = W; T->P = P; T->J = J;
+  FS_HIP(hipMalloc(&T->panel_row, sizeof(int) * panel_row.size()));
+  FS_HIP(hipMemcpyAsync(T->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
+
+  // ---- sort the entries by (panel, band), pack them, cut the work items -----------------------------------
   const size_t n = (size_t)A.nnz;
-  Scratch<int> rows, tile_ptr;
+  Scratch<int> vrows, tile_ptr;
   Scratch<unsigned> keys, skeys, idx_in, idx_out;
   Scratch<char> tmp;
   size_t tmp_bytes = 0;
-  FS_HIP(rows.alloc(n));
+  FS_HIP(vrows.alloc(n));
   FS_HIP(keys.alloc(n));
   FS_HIP(skeys.alloc(n));
   FS_HIP(idx_in.alloc(n));
@@ -348,8 +444,8 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(tile_ptr.alloc((size_t)ntiles + 1));
   FS_HIP(hipMalloc(&T->pk, sizeof(unsigned) * n));
   if (A.vals) FS_HIP(hipMalloc(&T->vals, sizeof(double) * n));
-  hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, R, W, J, A.row_ptr, A.cols,
-                     rows.p, keys.p);
+  hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, nvrow, A.nnz, P, W, J, vrow_ptr, T->panel_row,
+                     A.cols, vrows.p, keys.p);
   hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
   FS_HIP(hipGetLastError());
   int bits = 1;
@@ -357,8 +453,8 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
   FS_HIP(tmp.alloc(tmp_bytes));
   FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, R, W, J, T->lcol_bits, skeys.p,
-                     idx_out.p, rows.p, A.cols, A.vals, T->pk, T->vals);
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, W, J, T->lcol_bits, skeys.p, idx_out.p,
+                     vrows.p, T->panel_row, A.cols, A.vals, T->pk, T->vals);
   hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, s, ntiles, A.nnz, skeys.p, tile_ptr.p);
   FS_HIP(hipGetLastError());
   // work items are cut on the host from the tile pointers (P*J ints)
@@ -385,7 +481,6 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMalloc(&T->item_ptr, sizeof(int) * item_ptr.size()));
   if (!items.empty()) FS_HIP(hipMemcpy(T->items, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
-  T->slots = slots;
   T->built = true;
   return FS_OK;
 }

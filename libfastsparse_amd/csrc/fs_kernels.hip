@@ -313,9 +313,9 @@ __device__ __forceinline__ void tiled_reduce(double *__restrict__ ytile, const d
 // and the loads are needed one phase earlier than the gathers issued with them.
 template <bool VALUED, bool NT, bool DEBUG = false>
 __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
-    int nrow, int R, int W, int lcol_bits, const int4 *__restrict__ items, const int *__restrict__ item_ptr,
-    const unsigned *__restrict__ pk, const double *__restrict__ vals, const double *__restrict__ x,
-    double *__restrict__ y, int xs, int ys, long long *__restrict__ dbg_time = nullptr,
+    const int *__restrict__ panel_row, int W, int lcol_bits, const int4 *__restrict__ items,
+    const int *__restrict__ item_ptr, const unsigned *__restrict__ pk, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y, int xs, int ys, long long *__restrict__ dbg_time = nullptr,
     int *__restrict__ dbg_xcc = nullptr)
 {
   __shared__ double ytile[kTiledRowsMax];
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
   const bool producer = t < kTiledProd;      // wave-uniform: waves 0-7
   const int tr = producer ? t : t - kTiledProd;  // index inside the role
   const int p = blockIdx.x;
-  const int row0 = p * R;
-  const int nr = (nrow - row0 < R) ? nrow - row0 : R;
+  const int row0 = panel_row[p];
+  const int nr = panel_row[p + 1] - row0;
   for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
   const unsigned cmask = (1u << lcol_bits) - 1u;
   const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
@@ -497,17 +497,36 @@ static int ceil_log2(int v)
   return lg;
 }
 
+// y[r] = sum of the virtual rows of row r, in storage order (rows that were not cut: a copy)
+__global__ __launch_bounds__(kBlock) void tiled_combine_kernel(int nrow, const int *__restrict__ vfirst,
+                                                              const double *__restrict__ yv, double *__restrict__ y, int ys)
+{
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nrow) return;
+  const int a = vfirst[r], b = vfirst[r + 1];
+  double acc = yv[a];
+  for (int v = a + 1; v < b; ++v) acc += yv[v];
+  y[r * ys] = acc;
+}
+
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys)
 {
   const TiledCsr &T = *A.tiled;
   const bool nt = !(options().tiled_flags & 1);  // bit 0: cached (not nt) entry loads
-#define FS_TILED(V, N)                                                                                          \
-  hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W, T.lcol_bits, \
-                     T.items, T.item_ptr, T.pk, T.vals, x, y, xs, ys)
+  double *out = T.split ? T.yv : y;              // cut rows: virtual sums first, combined below
+  const int os = T.split ? 1 : ys;
+#define FS_TILED(V, N)                                                                                         \
+  hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, \
+                     T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os)
   if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
   else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
 #undef FS_TILED
   FS_HIP(hipGetLastError());
+  if (T.split) {
+    hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       A.nrow, T.vfirst, T.yv, y, ys);
+    FS_HIP(hipGetLastError());
+  }
   return FS_OK;
 }
 
@@ -517,12 +536,13 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
                             hipStream_t s)
 {
   const TiledCsr &T = *A.tiled;
+  double *out = T.split ? T.yv : y;
   if (A.vals)
-    hipLaunchKernelGGL((spmv_tiled_kernel<true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, 1, 1, times_dev, xcc_dev);
+    hipLaunchKernelGGL((spmv_tiled_kernel<true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W,
+                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, out, 1, 1, times_dev, xcc_dev);
   else
-    hipLaunchKernelGGL((spmv_tiled_kernel<false, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, A.nrow, T.R, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, y, 1, 1, times_dev, xcc_dev);
+    hipLaunchKernelGGL((spmv_tiled_kernel<false, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W,
+                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, out, 1, 1, times_dev, xcc_dev);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -18,12 +18,13 @@ ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--tile-rows", type=int, default=0)
 ap.add_argument("--tile-cols", type=int, default=0)
 ap.add_argument("--out", default="gpurun_out/trace_tiled.npz")
+ap.add_argument("--powerlaw", action="store_true")
 ap.add_argument("--gate-kb", type=int, default=8192)
 a = ap.parse_args()
 capi.set_option("tile_rows", a.tile_rows)
 capi.set_option("tile_cols", a.tile_cols)
 n = a.rows
-rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+rp, cc, vv = (capi.synth_powerlaw(n, n, 2.3, 1_000_000, 0x5EED0005) if a.powerlaw else capi.synth_uniform(n, n, 16, 0x5EED0002))
 A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
 L = capi.lib()
 geo = (C.c_int * 6)()
