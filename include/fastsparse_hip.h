@@ -59,10 +59,11 @@ int  fs_set_device(int device);
  * L2-tiled copy, 1 auto, 2 always; read when a matrix is created), "tile_rows" / "tile_cols" (0 = auto).
  * Options are process-wide.
  *
- * Threads and streams: every entry point may be called from several host threads.  Products on ONE handle from
- * several streams at once are safe with the tiled kernel and the multi-column kernels; the chunk-streaming
- * kernel keeps per-handle scratch for rows that cross chunks, so overlapping launches of it on one handle must
- * be ordered by the caller (or use one handle per stream). */
+ * Threads and streams: every entry point may be called from several host threads.  A handle keeps scratch
+ * vectors for some kernels (rows that cross chunks in the streaming kernel, sums of cut rows in the tiled
+ * kernel), so SpMV launches on ONE handle must not overlap in time on different streams: order them, or use
+ * one handle per stream.  The multi-column products (k >= 3) and distinct handles are unrestricted.
+ * "tile_split": rows longer than this are cut into virtual rows in the tiled copy (0 = 256). */
 int  fs_set_option(const char *name, int value);
 int  fs_get_option(const char *name);
 
