@@ -225,13 +225,14 @@ def main():
         out.write(json.dumps(rec) + "\n")
     if "c5" in what:
         nrow = n
-        rp, cc, vv = capi.synth_powerlaw(nrow, nrow, 2.3, 1_000_000, 0x5EED0005)
-        A = capi.Matrix.from_csr(nrow, nrow, rp, cc, vv, borrow=True)
-        x = torch.sin(7.0 * torch.arange(nrow, device="cuda", dtype=torch.float64) + 0.3)
+        c5cols = (args.ncols[0] if args.ncols else nrow)
+        rp, cc, vv = capi.synth_powerlaw(nrow, c5cols, 2.3, 1_000_000, 0x5EED0005)
+        A = capi.Matrix.from_csr(nrow, c5cols, rp, cc, vv, borrow=True)
+        x = torch.sin(7.0 * torch.arange(c5cols, device="cuda", dtype=torch.float64) + 0.3)
         y = torch.empty(nrow, dtype=torch.float64, device="cuda")
         for kern, label in ((6, "tiled"), (1, "stream_nt"), (2, "vector")):
             capi.set_option("spmv_kernel", kern)
-            report(out, f"c5shard_powerlaw_{label}_nnz{A.nnz}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            report(out, f"c5shard_powerlaw_ncol{c5cols}_{label}_nnz{A.nnz}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
 
 
