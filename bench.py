@@ -60,6 +60,39 @@ def cpu_baseline(rows, ncol, per_row, reps=10):
                       "repeats, OpenMP schedule(dynamic,256), gcc -O3 -march=native -ffast-math" % (rows, ncol, per_row, reps)}
 
 
+def cpu_reference_serial(rows, ncol, per_row, reps=3):
+    """The REAL reference's csr_A_mul_B (oracle/_ref/libfsref.so, compiled from the reference's own headers in the
+    build container, without OpenMP -- see oracle/ref_shim.c) on the first `rows` rows of the config-2 matrix:
+    one host core.  Present only when the prebuilt library travelled with the repo."""
+    import ctypes as C
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "_ref", "libfsref.so")
+    if not os.path.exists(so):
+        return None
+    from oracle import pysynth
+    lib = C.CDLL(so)
+    rp, cc, vv = pysynth.uniform(rows, ncol, per_row, SEED)
+
+    class CSR(C.Structure):      # csr.h:358-366
+        _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_long), ("row_ptr", C.c_void_p),
+                    ("cols", C.c_void_p), ("vals", C.c_void_p)]
+    A = CSR(rows, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, vv.ctypes.data)
+    x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
+    y = np.empty(rows)
+    f = lib.csr_A_mul_B
+    f.restype = None
+    args = (C.c_void_p(y.ctypes.data), C.byref(A), C.c_void_p(x.ctypes.data))
+    f(*args)
+    t0 = time.time()
+    for _ in range(reps):
+        f(*args)
+    dt = (time.time() - t0) / reps
+    nbytes = 12 * rows * per_row + 4 * (rows + 1) + 8 * rows + 8 * ncol
+    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference", "ms_per_product": dt * 1e3,
+            "sample": "reference csr_A_mul_B (csr.h:425, serial build) on the first %d rows of the config-2 matrix, "
+                      "x over all %d columns, 1 warm-up + mean of %d" % (rows, ncol, reps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +257,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 rec["cpu_baseline"] = cpu_baseline(n_local, ncol, per)
+                ref1 = cpu_reference_serial(min(n_local, 2_000_000), ncol, per)
+                if ref1:
+                    rec["cpu_baseline"]["reference_serial"] = ref1
             except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
                 rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(rec), flush=True)
