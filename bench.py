@@ -35,13 +35,38 @@ SEED = 0x5EED0002
 METRIC = "fp64 CSR SpMV effective GB/s (% HBM3E peak)"
 
 
+def host_cpus():
+    """CPUs this job may actually use: the affinity mask, cut down to the cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(rows, ncol, per_row, reps=10):
     """csr_A_mul_B restated (oracle/fs_oracle.c: fso_csr_mul, omp parallel for schedule(dynamic,256) as csr.h:429),
     built here with the reference's flags (-O3 -march=native -fopenmp -ffast-math), on the same config-2 matrix."""
     import numpy as np
     from oracle import pyoracle, pysynth
+    import ctypes as C
     out = os.path.join("/tmp", "liboracle_fast_%d.so" % os.getpid())
     fast = pyoracle.load(pyoracle.build_fast(out))
+    # one OpenMP thread per host CPU this process may run on (the box gives a GPU job a share of the host's cores;
+    # libgomp's default would be every core of the machine)
+    ncpu = host_cpus()
+    C.CDLL("libgomp.so.1").omp_set_num_threads(ncpu)
     rp, cc, vv = pysynth.uniform(rows, ncol, per_row, SEED)
     x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
     y = np.empty(rows)
@@ -55,6 +80,7 @@ def cpu_baseline(rows, ncol, per_row, reps=10):
     strict = pyoracle.load()
     os.remove(out)
     return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": int(strict.fso_threads()), "kind": "port",
+            "host_cpus_available": ncpu,
             "ms_per_product": dt * 1e3,
             "sample": "csr_A_mul_B on the full config-2 matrix (%d x %d, %d nnz/row), 1 warm-up + mean of %d "
                       "repeats, OpenMP schedule(dynamic,256), gcc -O3 -march=native -ffast-math" % (rows, ncol, per_row, reps)}
