@@ -303,10 +303,7 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
     fs::DeviceCsr &c = M->cells;
     c.nrow = (int)ncell; c.ncol = ncol; c.nnz = M->nnz;
     c.row_ptr = M->row_ptr; c.cols = M->cols; c.vals = nullptr; c.owns = false;
-    const int tiling = fs::options().tiling;
-    fs::options().tiling = 0;              // the cell view is only ever streamed
-    rc = fs::build_schedule(c, nullptr);
-    fs::options().tiling = tiling;
+    rc = fs::build_schedule(c, nullptr, /*allow_tiled=*/false);  // the cell view is only ever streamed
     if (!rc && hipMalloc(&M->cell_sums, sizeof(double) * (ncell ? ncell : 1)) != hipSuccess) rc = FS_ERR_HIP;
     M->use_cells = !rc;
   }

@@ -116,12 +116,12 @@ struct Options {
 Options &options();
 
 // ---- launchers implemented in fs_kernels.hip --------------------------------------------
-int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s);
+int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
 int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
-int build_schedule(DeviceCsr &A, hipStream_t s);
+int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,

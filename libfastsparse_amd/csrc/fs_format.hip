@@ -90,7 +90,7 @@ __global__ void count_spanning_kernel(int nchunks, int64_t nnz, const int *__res
   if ((int64_t)row_ptr[r1] > e) atomicAdd(count, 1);
 }
 
-int build_schedule(DeviceCsr &A, hipStream_t s)
+int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
 {
   A.nchunks = (int)((A.nnz + kChunk - 1) / kChunk);
   if (A.nchunks < 1) A.nchunks = 1;
@@ -111,7 +111,7 @@ int build_schedule(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipGetLastError());
   FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
-  return build_tiled(A, s);
+  return allow_tiled ? build_tiled(A, s) : FS_OK;
 }
 
 // ---- stable COO -> CSR -----------------------------------------------------------------------

@@ -547,10 +547,11 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
   return FS_OK;
 }
 
-int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
+int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream)
 {
   if (A.nrow == 0) return FS_OK;
-  const Options &o = options();
+  Options o = options();
+  if (force_stream) o.spmv_kernel = 1;
   const bool valued = A.vals != nullptr;
   // auto: the L2-tiled copy when it was built (format builder decided it pays) and the caller did not
   // ask for storage-order sums
@@ -639,11 +640,7 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
   // large matrices: cell sums by the chunk-streaming kernel over the (block, row) cells, then one pass that
   // adds each row's cells block by block.  spmv_kernel 4 / 5 force the one-thread-per-row kernels below.
   if (A.use_cells && options().spmv_kernel != 4 && options().spmv_kernel != 5) {
-    const int keep = options().spmv_kernel;
-    options().spmv_kernel = 1;
-    const int rc = launch_spmv(A.cells, A.cell_sums, x, s);
-    options().spmv_kernel = keep;
-    if (rc) return rc;
+    if (int rc = launch_spmv(A.cells, A.cell_sums, x, s, /*force_stream=*/true)) return rc;
     hipLaunchKernelGGL(cbcsr_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                        A.nrow, A.nblocks, A.cell_sums, y);
     FS_HIP(hipGetLastError());
