@@ -434,3 +434,40 @@ def test_cbcsr_large_uses_cell_streaming(hip):
     finally:
         capi.set_option("strict_order", 0)
     assert np.array_equal(y.cpu().numpy(), ref)
+
+
+def test_tiled_auto_on_extreme_row_lengths(hip):
+    """automatic tiling on matrices the format builder has to cut up: one row holding almost everything, and a
+    heavy-tailed matrix with many empty rows; every row against the oracle (row-scaled bound), integer x exact"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(5)
+    # (a) 1000 rows, row 7 has 5 M entries, the others 0-3
+    ncol = 2_000_000
+    lens = rng.integers(0, 4, 1000)
+    lens[7] = 5_000_000
+    rp = np.zeros(1001, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    cc = rng.integers(0, ncol, int(rp[-1])).astype(np.int32)
+    vv = rng.uniform(-1, 1, int(rp[-1]))
+    # (b) 400 k rows, 30 % empty, Pareto lengths up to 200 k
+    n2, ncol2 = 400_000, 3_000_000
+    l2 = np.minimum((2.0 / rng.uniform(1e-6, 1, n2)).astype(np.int64), 200_000)
+    l2[rng.uniform(size=n2) < 0.3] = 0
+    rp2 = np.zeros(n2 + 1, np.int64)
+    np.cumsum(l2, out=rp2[1:])
+    rp2 = rp2.astype(np.int32)
+    cc2 = rng.integers(0, ncol2, int(rp2[-1])).astype(np.int32)
+    for (nrow, nc, r_, c_, v_) in ((1000, ncol, rp, cc, vv), (n2, ncol2, rp2, cc2, None)):
+        A = capi.Matrix.from_csr(nrow, nc, r_, c_, v_)
+        y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        for x in (S.x_sin(nc), S.x_int(2, nc)):
+            A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
+            ref = O.csr_mul(nrow, r_, c_, v_, x)
+            got = y.cpu().numpy()
+            if v_ is None and np.all(x == np.round(x)):
+                assert np.array_equal(got, ref)
+            else:
+                scale = O.csr_abs_scale(nrow, r_, c_, v_, x)
+                assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300))
