@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "hilbert.h"
+#include "quickSortD.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -39,6 +42,9 @@ struct SparseDoubleMatrix* new_sdm(long nrow, long ncol, long nnz, int* rows, in
 void sdm_transpose(struct SparseDoubleMatrix* A);                              /* dsparse.h:33 */
 struct SparseDoubleMatrix* read_sdm(const char* filename);                     /* dsparse.h:64 */
 struct BlockedSDM* new_bsdm(struct SparseDoubleMatrix* A, int block_size);     /* dsparse.h:132 */
+
+void sort_sdm(struct SparseDoubleMatrix* A);                                   /* Hilbert order (host), dsparse.h:96 */
+void sort_bsdm(struct BlockedSDM* B);                                          /* per-block Hilbert order, dsparse.h:193 */
 
 void sdm_A_mul_B(double* y, struct SparseDoubleMatrix* A, double* x);          /* y[nrow] = A x,  dsparse.h:43 */
 void sdm_At_mul_B(double* y, struct SparseDoubleMatrix* A, double* x);         /* y[ncol] = A' x, dsparse.h:54 */

@@ -12,13 +12,16 @@
  * device pointers (used in place).  The matrix is uploaded on first use and cached per host
  * struct; after changing a matrix's arrays in place call fs_invalidate(A) (fastsparse_hip.h).
  *
- * Out of scope here: Hilbert/row sorters, RNG helpers.
+ * Out of scope here: the RNG helpers (exprand, randexp, randsubseq).
  */
 #ifndef SPARSE_H
 #define SPARSE_H
 
 #include <stdio.h>
 #include <stdlib.h>
+
+#include "hilbert.h"
+#include "quickSort.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -53,6 +56,11 @@ void transpose(struct SparseBinaryMatrix* A);                                   
 struct SparseBinaryMatrix* read_sbm(const char* filename);                                /* sparse.h:112 */
 struct BlockedSBM* new_bsbm(struct SparseBinaryMatrix* A, int block_size);                /* sparse.h:175 */
 long read_long(FILE* fh);                                                                 /* utils.h:4 */
+
+/* locality re-orderings (host; they permute the entries in place and drop the cached device copy) */
+void sort_sbm(struct SparseBinaryMatrix* A);                                              /* Hilbert order, sparse.h:142 */
+void sort_bsbm(struct BlockedSBM* B);                                                     /* per-block Hilbert order, sparse.h:215 */
+void sort_bsbm_byrow(struct BlockedSBM* B);                                               /* per-block (row, col) order, sparse.h:238 */
 
 /* products (GPU) */
 void A_mul_B(double* y, struct SparseBinaryMatrix* A, double* x);      /* y[nrow] = A x,  sparse.h:58 */

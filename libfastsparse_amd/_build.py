@@ -11,9 +11,9 @@ LIB = os.path.join(HERE, "libfastsparse_hip.so")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["fs_kernels.hip", "fs_format.hip", "fs_abi.hip", "fs_dropin.hip", "fs_cg.hip"]
-C_SOURCES = ["fs_host.c"]
+C_SOURCES = ["fs_host.c", "fs_sort.c"]
 HEADERS = [os.path.join(CSRC, "fs_common.h")] + [os.path.join(ROOT, "include", h) for h in
-                                                 ("fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h")]
+                                                 ("fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h", "hilbert.h", "quickSort.h", "quickSortD.h")]
 
 
 def _hipcc():

@@ -39,6 +39,9 @@ REFERENCE_API = [
     "new_cbcsr", "cbcsr_from_sbm", "cbcsr_A_mul_B",
     # cg.h, linalg.h
     "bsbm_AtA", "bsbm_cg", "bsbm_cg2", "dist", "pnormsq", "pnormsq2", "pouter2", "pdot", "pdot2sym", "solve2sym",
+    # hilbert.h, quickSort.h, quickSortD.h and the sorters of sparse.h / dsparse.h
+    "ceilPower2", "xy2d", "d2xy", "rot", "row_xy2d", "row_d2xy", "quickSort", "quickSortD",
+    "sort_sbm", "sort_bsbm", "sort_bsbm_byrow", "sort_sdm", "sort_bsdm",
 ]
 
 

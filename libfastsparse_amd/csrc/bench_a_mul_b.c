@@ -9,10 +9,9 @@
  *     -c  (conjugate gradient: out of scope on this build, reported as skipped)
  *     -d  keep x / y in HBM (device pointers): times the kernels without the PCIe copies
  *
- * Differences, all stated in the output: the "[sort]" family re-orders the COO by (row, col) instead
- * of along a Hilbert curve (the sorters are CPU-cache helpers outside the GPU path; an entry re-order
- * only changes the per-row summation order); an extra "[csr-f64]" section runs read_sdm -> new_csr ->
- * csr_A_mul_B / csr_At_mul_B when the file carries values (BASELINE config 1).
+ * Differences: an extra "[csr-f64]" section runs read_sdm -> new_csr -> csr_A_mul_B / csr_At_mul_B when the
+ * file carries values (BASELINE config 1); -c reports the CG solve as one line instead of the reference's
+ * residual trace.
  */
 #include <math.h>
 #include <pthread.h>
@@ -24,6 +23,7 @@
 #include <sys/time.h>
 #include <unistd.h>
 
+#include "cg.h"
 #include "csr.h"
 #include "dsparse.h"
 #include "fastsparse_hip.h"
@@ -67,23 +67,6 @@ static double fx2(long i) { return (i & 1) ? sin(11.0 * (i / 2) - 0.2) : sin(7.0
 static double fx4(long i) { return sin(7.0 * (i / 4) + 17.0 * (i % 4) + 0.3); }
 static double fx8(long i) { return sin(7.0 * (i / 8) + 17.0 * (i % 8) + 0.3); }
 
-struct pair { int r, c; };
-static int by_row_col(const void *a, const void *b)
-{
-  const struct pair *p = (const struct pair *)a, *q = (const struct pair *)b;
-  if (p->r != q->r) return p->r < q->r ? -1 : 1;
-  return (p->c > q->c) - (p->c < q->c);
-}
-
-static void sort_rowcol(int *rows, int *cols, long nnz)
-{
-  struct pair *t = (struct pair *)malloc(sizeof(struct pair) * (nnz ? nnz : 1));
-  for (long i = 0; i < nnz; i++) { t[i].r = rows[i]; t[i].c = cols[i]; }
-  qsort(t, nnz, sizeof(struct pair), by_row_col);
-  for (long i = 0; i < nnz; i++) { rows[i] = t[i].r; cols[i] = t[i].c; }
-  free(t);
-}
-
 struct mul2_job { double *Y, *X; struct BlockedSBM *B, *Bt; int reps; };
 static void *mul2_thread(void *arg)
 {
@@ -123,8 +106,7 @@ int main(int argc, char **argv)
   A_mul_B(y, A, x); /* uploads the matrix; not timed, like the reference's warm-up calls */
   tic(); for (int i = 0; i < nrepeats; i++) A_mul_B(y, A, x); toc("unsorted", nrepeats);
 
-  sort_rowcol(A->rows, A->cols, A->nnz); /* (row, col) order; see header */
-  fs_invalidate(A);
+  sort_sbm(A); /* Hilbert order, in place; drops the cached device copy */
   A_mul_B(y, A, x);
   tic(); for (int i = 0; i < nrepeats; i++) A_mul_B(y, A, x); toc("sort", nrepeats);
 
@@ -157,12 +139,24 @@ int main(int argc, char **argv)
     free_bcsr(&csr);
     free_bcsr(&csrt);
   }
-  if (cgflag) printf("[cg solver]\tskipped: bsbm_cg2 is outside the A_mul_B path of this build\n");
+  if (cgflag) { /* bench_a_mul_b.c:332-360: two right-hand sides, (A'A + 0.5 I) X = B */
+    int iters = 0;
+    double *Bh = (double *)malloc(sizeof(double) * 2 * A->ncol), *Xh = (double *)malloc(sizeof(double) * 2 * A->ncol);
+    for (long i = 0; i < 2L * A->ncol; i++) Bh[i] = fx2(i);
+    tic();
+    bsbm_cg2(Xh, B, Bt, Bh, 0.5, 1e-6, &iters);
+    toc("cg solver", 1);
+    printf("  bsbm_cg2: %d iterations\n", iters);
+    free(Bh); free(Xh);
+  }
 
   bsbm_A_mul_B4(Y4, B, X4);
   tic(); for (int i = 0; i < nrepeats; i++) bsbm_A_mul_B4(Y4, B, X4); toc("4xblock", nrepeats);
-  /* the reference re-orders each block (Hilbert, then by row) here; block contents are row-grouped already */
+  sort_bsbm(B);
+  bsbm_A_mul_B(y, B, x);
   tic(); for (int i = 0; i < nrepeats; i++) bsbm_A_mul_B(y, B, x); toc("sort+block", nrepeats);
+  sort_bsbm_byrow(B);
+  bsbm_A_mul_B(y, B, x);
   tic(); for (int i = 0; i < nrepeats; i++) bsbm_A_mul_B(y, B, x); toc("rowsort+block", nrepeats);
 
   { /* two host threads multiplying at once on shared matrices (reference: nested OpenMP, bench_a_mul_b.c:401-421) */

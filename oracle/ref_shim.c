@@ -43,3 +43,8 @@ void ref_cbcsr_from_sbm(struct ColBinaryCSR *A, struct SparseBinaryMatrix *sbm, 
 /* static in csr.h:97,117 */
 void ref_serialize_to_file(const struct BinaryCSR *b, const char *fn) { serialize_to_file(b, fn); }
 void ref_deserialize_from_file(struct BinaryCSR *b, const char *fn) { deserialize_from_file(b, fn); }
+
+/* static in sparse.h:142,215,238 */
+void ref_sort_sbm(struct SparseBinaryMatrix *A) { sort_sbm(A); }
+void ref_sort_bsbm(struct BlockedSBM *B) { sort_bsbm(B); }
+void ref_sort_bsbm_byrow(struct BlockedSBM *B) { sort_bsbm_byrow(B); }

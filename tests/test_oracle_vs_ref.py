@@ -104,3 +104,60 @@ def test_bcsr_file_format_interoperates_with_reference(tmp_path):
     for B, arr in ((B1, F.arr), (B2, R.arr)):
         assert (B.nrow, B.ncol, B.nnz) == (nrow, ncol, len(rows))
         assert np.array_equal(arr(B.row_ptr, nrow + 1, np.int32), rp) and np.array_equal(arr(B.cols, len(rows), np.int32), cc)
+
+
+def test_locality_sorters_match_reference():
+    """8f-3: sort_sbm / sort_sdm (Hilbert order), sort_bsbm / sort_bsdm (per-block Hilbert order), sort_bsbm_byrow and
+    the curve helpers give the entry order the reference gives (matrices without repeated (row, col) pairs: array
+    for array)"""
+    import _hipbackend as H
+    R = _refbind.Ref()
+    F = H.HostFormats()
+    L, RL = F.L, R.lib
+    for f in ("xy2d", "row_xy2d"):
+        getattr(L, f).restype = C.c_long
+        getattr(RL, f).restype = C.c_long
+    for n, x, y in ((8, 3, 5), (1024, 1000, 17), (128, 0, 127), (64, 63, 63)):
+        assert L.xy2d(n, x, y) == RL.xy2d(n, x, y)
+        assert L.row_xy2d(n, x % n, y * 7) == RL.row_xy2d(n, x % n, y * 7)
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.d2xy(n, C.c_long(L.xy2d(n, x, y)), C.byref(a), C.byref(b))
+        assert (a.value, b.value) == (x, y)
+        L.row_d2xy(n, C.c_long(L.row_xy2d(n, x % n, y * 7)), C.byref(c), C.byref(d))
+        assert (c.value, d.value) == (x % n, y * 7)
+    assert [L.ceilPower2(v) for v in (1, 2, 3, 100, 1024, 1025)] == [RL.ceilPower2(v) for v in (1, 2, 3, 100, 1024, 1025)]
+
+    nrow, ncol, rows, cols, vals = S.fixture_sdm()       # distinct (row, col) pairs
+    # whole-matrix Hilbert order
+    a, b = F.sbm(nrow, ncol, rows, cols), R.sbm(nrow, ncol, rows, cols)
+    L.sort_sbm(C.byref(a)); RL.ref_sort_sbm(C.byref(b))
+    assert np.array_equal(F.arr(a.rows, len(rows), np.int32), R.arr(b.rows, len(rows), np.int32))
+    assert np.array_equal(F.arr(a.cols, len(rows), np.int32), R.arr(b.cols, len(rows), np.int32))
+    d1, d2 = F.sdm(nrow, ncol, rows, cols, vals), R.sdm(nrow, ncol, rows, cols, vals)
+    L.sort_sdm(C.byref(d1)); RL.sort_sdm(C.byref(d2))
+    for fld, dt in (("rows", np.int32), ("cols", np.int32), ("vals", np.float64)):
+        assert np.array_equal(F.arr(getattr(d1, fld), len(rows), dt), R.arr(getattr(d2, fld), len(rows), dt)), fld
+    # per-block orders
+    for own_sort, ref_sort in ((L.sort_bsbm, RL.ref_sort_bsbm), (L.sort_bsbm_byrow, RL.ref_sort_bsbm_byrow)):
+        B1 = L.new_bsbm(C.byref(F.sbm(nrow, ncol, rows, cols)), 8)
+        B2 = RL.new_bsbm(C.byref(R.sbm(nrow, ncol, rows, cols)), 8)
+        own_sort(B1); ref_sort(B2)
+        for blk in range(B1.contents.nblocks):
+            n = B1.contents.nnz[blk]
+            assert np.array_equal(F.arr(B1.contents.rows[blk], n, np.int32), R.arr(B2.contents.rows[blk], n, np.int32))
+            assert np.array_equal(F.arr(B1.contents.cols[blk], n, np.int32), R.arr(B2.contents.cols[blk], n, np.int32))
+    E1 = L.new_bsdm(C.byref(F.sdm(nrow, ncol, rows, cols, vals)), 8)
+    E2 = RL.new_bsdm(C.byref(R.sdm(nrow, ncol, rows, cols, vals)), 8)
+    L.sort_bsdm(E1); RL.sort_bsdm(E2)
+    for blk in range(E1.contents.nblocks):
+        n = E1.contents.nnz[blk]
+        assert np.array_equal(F.arr(E1.contents.rows[blk], n, np.int32), R.arr(E2.contents.rows[blk], n, np.int32))
+        assert np.array_equal(F.arr(E1.contents.vals[blk], n, np.float64), R.arr(E2.contents.vals[blk], n, np.float64))
+    # quickSort / quickSortD
+    rng = np.random.default_rng(1)
+    k = rng.integers(-10**12, 10**12, 5000).astype(np.int64)
+    v = rng.uniform(size=5000)
+    k1, v1 = k.copy(), v.copy()
+    L.quickSortD(k1.ctypes.data_as(C.POINTER(C.c_long)), C.c_long(0), C.c_long(4999), v1.ctypes.data_as(C.POINTER(C.c_double)))
+    o = np.argsort(k, kind="stable")
+    assert np.array_equal(k1, k[o]) and np.array_equal(v1, v[o])
