@@ -11,8 +11,6 @@
  * x and y may be host pointers (copied through, the call returns when y is complete) or
  * device pointers (used in place).  The matrix is uploaded on first use and cached per host
  * struct; after changing a matrix's arrays in place call fs_invalidate(A) (fastsparse_hip.h).
- *
- * Out of scope here: the RNG helpers (exprand, randexp, randsubseq).
  */
 #ifndef SPARSE_H
 #define SPARSE_H
@@ -20,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "utils.h"
 #include "hilbert.h"
 #include "quickSort.h"
 
@@ -55,7 +54,11 @@ struct SparseBinaryMatrix* new_transpose(struct SparseBinaryMatrix* A);         
 void transpose(struct SparseBinaryMatrix* A);                                             /* swaps in place, sparse.h:48 */
 struct SparseBinaryMatrix* read_sbm(const char* filename);                                /* sparse.h:112 */
 struct BlockedSBM* new_bsbm(struct SparseBinaryMatrix* A, int block_size);                /* sparse.h:175 */
-long read_long(FILE* fh);                                                                 /* utils.h:4 */
+
+/* samplers over drand48 (host; same draws as the reference for the same srand48 seed) */
+double exprand(void);                                                                     /* sparse.h:77 */
+double randexp(void);                                                                     /* sparse.h:83 */
+long randsubseq(long N, long max_samples, double p, long* samples);                       /* sparse.h:92 */
 
 /* locality re-orderings (host; they permute the entries in place and drop the cached device copy) */
 void sort_sbm(struct SparseBinaryMatrix* A);                                              /* Hilbert order, sparse.h:142 */

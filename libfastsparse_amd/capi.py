@@ -42,6 +42,8 @@ REFERENCE_API = [
     # hilbert.h, quickSort.h, quickSortD.h and the sorters of sparse.h / dsparse.h
     "ceilPower2", "xy2d", "d2xy", "rot", "row_xy2d", "row_d2xy", "quickSort", "quickSortD",
     "sort_sbm", "sort_bsbm", "sort_bsbm_byrow", "sort_sdm", "sort_bsdm",
+    # samplers of sparse.h, timing.h, omp_util.h
+    "exprand", "randexp", "randsubseq", "timing", "thread_num", "nthreads", "thread_limit", "threads_init",
 ]
 
 

@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
+#include <sys/time.h>
 
 #include "cbcsr.h"
 #include "csr.h"
@@ -85,6 +87,43 @@ FS_EXPORT void sdm_transpose(struct SparseDoubleMatrix *A)
   int *r = A->rows; A->rows = A->cols; A->cols = r;
   int n = A->nrow; A->nrow = A->ncol; A->ncol = n;
 }
+
+/* ---- small helpers of sparse.h / timing.h / omp_util.h (host, off the product path) ----------
+ * The samplers draw from drand48 exactly as the reference's do (sparse.h:77-110), so a caller that
+ * seeds with srand48 sees the same sequence. */
+FS_EXPORT double exprand(void) { return log1p(1.0 - drand48()); }
+FS_EXPORT double randexp(void) { return -log(1.0 - drand48()); }
+
+FS_EXPORT long randsubseq(long N, long max_samples, double p, long *samples)
+{
+  /* geometric gaps between kept indices: gap = ceil(Exp(1) * scale), scale = -1/log(1-p) */
+  const double scale = -1.0 / log1p(-p);
+  long last = -1, count = 0;
+  for (;;) {
+    double gap = randexp() * scale;
+    if (gap + last >= N - 1) break;
+    last += (long)ceil(gap);
+    samples[count++] = last;
+    if (count >= max_samples) break;
+  }
+  return count;
+}
+
+FS_EXPORT void timing(double *wcTime, double *cpuTime)
+{
+  struct timeval now;
+  struct rusage use;
+  gettimeofday(&now, NULL);
+  getrusage(RUSAGE_SELF, &use);
+  *wcTime = now.tv_sec + now.tv_usec * 1e-6;
+  *cpuTime = use.ru_utime.tv_sec + use.ru_utime.tv_usec * 1e-6;
+}
+
+/* the products run on the GPU: the calling thread is the only host thread the library uses */
+FS_EXPORT int thread_num(void) { return 0; }
+FS_EXPORT int nthreads(void) { return 1; }
+FS_EXPORT int thread_limit(void) { return 1; }
+FS_EXPORT void threads_init(void) { }
 
 /* ---- fixture files: 3 x int64 header, int32 rows, int32 cols, [float64 vals], 1-based ------ */
 FS_EXPORT long read_long(FILE *fh)

@@ -28,7 +28,7 @@ def _declared_functions(header):
 
 
 @pytest.mark.parametrize("header", ["fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h", "hilbert.h",
-                                    "quickSort.h", "quickSortD.h"])
+                                    "quickSort.h", "quickSortD.h", "utils.h", "timing.h", "omp_util.h"])
 def test_library_exports_every_declared_symbol(header):
     L = capi.lib()
     names = _declared_functions(header)
@@ -39,7 +39,8 @@ def test_library_exports_every_declared_symbol(header):
 
 def test_binding_lists_match_headers():
     declared = set()
-    for h in ("sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h", "hilbert.h", "quickSort.h", "quickSortD.h"):
+    for h in ("sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h", "hilbert.h", "quickSort.h", "quickSortD.h", "utils.h", "timing.h",
+              "omp_util.h"):
         declared |= set(_declared_functions(h))
     assert declared == set(capi.REFERENCE_API)
     assert set(_declared_functions("fastsparse_hip.h")) == set(capi.DEVICE_API)

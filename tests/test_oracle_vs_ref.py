@@ -161,3 +161,29 @@ def test_locality_sorters_match_reference():
     L.quickSortD(k1.ctypes.data_as(C.POINTER(C.c_long)), C.c_long(0), C.c_long(4999), v1.ctypes.data_as(C.POINTER(C.c_double)))
     o = np.argsort(k, kind="stable")
     assert np.array_equal(k1, k[o]) and np.array_equal(v1, v[o])
+
+
+def test_samplers_match_reference():
+    """exprand / randexp / randsubseq draw from drand48 as the reference's do: same seed, same samples"""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    L = capi.lib()
+    R = _refbind.Ref().lib
+    libc = C.CDLL(None)
+    libc.srand48.argtypes = [C.c_long]
+    for lib_ in (L, R):
+        lib_.exprand.restype = C.c_double
+        lib_.randexp.restype = C.c_double
+        lib_.randsubseq.restype = C.c_long
+        lib_.randsubseq.argtypes = [C.c_long, C.c_long, C.c_double, C.POINTER(C.c_long)]
+
+    def draw(lib_, seed, N, cap, p):
+        libc.srand48(seed)
+        buf = (C.c_long * cap)()
+        n = lib_.randsubseq(N, cap, p, buf)
+        return list(buf[:n]), lib_.exprand(), lib_.randexp()
+
+    for seed, N, cap, p in [(1234567890, 10000, 1000, 0.05), (7, 50, 100, 0.5), (3, 1000, 5, 0.3), (11, 1, 4, 0.9)]:
+        got, want = draw(L, seed, N, cap, p), draw(R, seed, N, cap, p)
+        assert got == want
+        assert all(0 <= v < N for v in got[0]) and len(got[0]) <= cap
