@@ -13,12 +13,12 @@ all-gather of the y shards, and z = A' u is the local transposed product of the 
 of u followed by an RCCL all-reduce (sum) of the 80 MB partial results.  The two products of a step are
 independent, so each exchange is started asynchronously and overlaps the next local product.
 
-One step = y = A x  then  z = A' u  (two launches of the L2-tiled SpMV kernel per rank, plus one all-gather
-and one all-reduce when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
+One step = y = A x  then  z = A' u  (two products per rank -- each one launch of the expand kernel and one of
+the reduce kernel of the two-pass SpMV -- plus one all-gather and one all-reduce when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
 Algorithmic bytes per product: 12*nnz + 4*(nrow+1) + 8*nrow + 8*ncol.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = spmv_tiled_kernel, HIP-event timed
-inside the timed region) and, at N = 1, `cpu_baseline` (the oracle's OpenMP restatement of csr_A_mul_B,
+Prints ONE JSON line on rank 0 with `roofline` (one product = spmv_expand_kernel + spmv_reduce_kernel, HIP-event
+timed inside the timed region; "launch" below means one product, i.e. that pair) and, at N = 1, `cpu_baseline` (the oracle's OpenMP restatement of csr_A_mul_B,
 built with the reference's flags, timed on this box's host cores on the same matrix).
 """
 import argparse
@@ -225,7 +225,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-launch durations of the dominant kernel inside the timed region (HIP events on the launch stream)
+    # per-product durations inside the timed region (HIP events on the launch stream); a product is the kernel
+    # pair expand + reduce of the two-pass SpMV (or one launch of the tiled / streaming kernel if the format
+    # builder chose those)
     ka = [e[0].elapsed_time(e[1]) for e in evs]
     kt = [e[2].elapsed_time(e[3]) for e in evs]
     launches = 2 * args.steps
@@ -254,7 +256,10 @@ def main():
 
     if rank == 0:
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_tiled.json")
+        kname = A.kernel_name()
+        klabel = {"two-pass": "fs::spmv_expand_kernel<valued> + fs::spmv_reduce_kernel (one product)",
+                  "tiled": "fs::spmv_tiled_kernel<valued>", "stream": "fs::spmv_stream_kernel<valued>"}.get(kname, kname)
+        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_%s.json" % kname.replace("-", "_"))
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
@@ -275,7 +280,7 @@ def main():
                        "stream_read_GBs_measured": stream_gbs,
                        "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
                        "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt)},
-            "roofline": {"bound": "hbm", "kernel": "fs::spmv_tiled_kernel<valued>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": klabel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "launches_timed": launches},

@@ -55,13 +55,17 @@ const char *fs_last_error(void);
 int  fs_device_count(void);
 int  fs_set_device(int device);
 /* option names: "strict_order" (0/1: storage-order sums, bit-identical to the strict-IEEE CPU order for
- * arbitrary x), "spmv_kernel" (0 = auto, 1 streaming, 2 lanes-per-row, 6 tiled), "tiling" (0 never build the
- * L2-tiled copy, 1 auto, 2 always; read when a matrix is created), "tile_rows" / "tile_cols" (0 = auto).
+ * arbitrary x), "spmv_kernel" (0 = auto, 1 streaming, 2 lanes-per-row, 6 tiled, 7 two-pass), "tiling" (0 never
+ * build the L2-tiled copy, 1 auto, 2 always; read when a matrix is created), "tile_rows" / "tile_cols" (0 = auto),
+ * "binning" (the same three values for the two-pass copy), "reproducible" (0/1, default 0: with 1 only kernels whose
+ * sums are bit-identical from run to run are used -- the two-pass kernels add a row's terms with LDS atomics in
+ * arrival order, so their last bits can differ between runs for non-integer data; read when a matrix is created
+ * and at every product).
  * Options are process-wide.
  *
  * Threads and streams: every entry point may be called from several host threads.  A handle keeps scratch
  * vectors for some kernels (rows that cross chunks in the streaming kernel, sums of cut rows in the tiled
- * kernel), so SpMV launches on ONE handle must not overlap in time on different streams: order them, or use
+ * kernel, products of the two-pass kernels), so SpMV launches on ONE handle must not overlap in time on different streams: order them, or use
  * one handle per stream.  The multi-column products (k >= 3) and distinct handles are unrestricted.
  * "tile_split": rows longer than this are cut into virtual rows in the tiled copy (0 = 256). */
 int  fs_set_option(const char *name, int value);
@@ -91,6 +95,9 @@ void fs_matrix_destroy(fs_matrix_t A);
 /* builds and caches the stably column-ordered CSR of A' (needed by *_t products) */
 int  fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream);
 int  fs_matrix_has_transpose(fs_matrix_t A);
+/* which kernel fs_spmv (or fs_spmv_t) runs on this matrix under the current options: 1 chunk-streaming,
+ * 2 lanes-per-row, 6 L2-tiled, 7 two-pass; the choice is made by the format builder when the matrix is created */
+int  fs_matrix_spmv_kernel(fs_matrix_t A, int transposed);
 int  fs_matrix_nrow(fs_matrix_t A);
 int  fs_matrix_ncol(fs_matrix_t A);
 int64_t fs_matrix_nnz(fs_matrix_t A);

@@ -92,6 +92,9 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "tile_cols")) { fs::options().tile_cols = value; return FS_OK; }
   if (!strcmp(name, "tile_split")) { fs::options().tile_split = value; return FS_OK; }
   if (!strcmp(name, "tiled_flags")) { fs::options().tiled_flags = value; return FS_OK; }
+  if (!strcmp(name, "reproducible")) { fs::options().reproducible = value; return FS_OK; }
+  if (!strcmp(name, "bin_rows")) { fs::options().bin_rows = value; return FS_OK; }
+  if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
 }
@@ -103,6 +106,9 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "tiling")) return fs::options().tiling;
   if (name && !strcmp(name, "tile_rows")) return fs::options().tile_rows;
   if (name && !strcmp(name, "tile_cols")) return fs::options().tile_cols;
+  if (name && !strcmp(name, "tile_split")) return fs::options().tile_split;
+  if (name && !strcmp(name, "binning")) return fs::options().binning;
+  if (name && !strcmp(name, "reproducible")) return fs::options().reproducible;
   return FS_ERR_ARG;
 }
 
@@ -183,6 +189,17 @@ int fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream)
 }
 
 int fs_matrix_has_transpose(fs_matrix_t A) { return A && A->has_t; }
+
+int fs_matrix_spmv_kernel(fs_matrix_t A, int transposed)
+{
+  if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  const fs::Options &o = fs::options();
+  if (!o.strict_order && !o.reproducible && a.binned && a.binned->built && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
+  if (!o.strict_order && a.tiled && a.tiled->built && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
+  return o.spmv_kernel == 2 ? 2 : 1;
+}
+
 int fs_matrix_nrow(fs_matrix_t A) { return A ? A->a.nrow : FS_ERR_ARG; }
 int fs_matrix_ncol(fs_matrix_t A) { return A ? A->a.ncol : FS_ERR_ARG; }
 int64_t fs_matrix_nnz(fs_matrix_t A) { return A ? A->a.nnz : FS_ERR_ARG; }

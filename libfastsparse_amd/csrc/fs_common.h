@@ -18,6 +18,7 @@ constexpr int kChunk = 2048;           // non-zeros one workgroup streams throug
 constexpr int kPerThread = kChunk / kBlock;
 
 struct TiledCsr;
+struct BinnedCsr;
 
 // One CSR in HBM plus the chunk schedule of the streaming SpMV kernel.
 struct DeviceCsr {
@@ -35,6 +36,7 @@ struct DeviceCsr {
   double *tail = nullptr;      // nchunks: sum of the chunk's trailing non-zeros of a row that ends later
   int spanning = 0;            // number of rows that cross a chunk boundary (0 => no fix-up launch)
   TiledCsr *tiled = nullptr;  // optional L2-tiled copy (owned)
+  BinnedCsr *binned = nullptr;  // optional two-pass copy (owned)
 };
 
 // L2-tiled copy of a CSR for the column-band kernel (see DESIGN.md "spmv_tiled_kernel").
@@ -66,6 +68,42 @@ struct TiledCsr {
   int *vfirst = nullptr;       // nrow + 1: first virtual row of every row (only when split > 0)
   double *yv = nullptr;        // nvrow: sums of the virtual rows, combined per row after the kernel
   int slots = 256;             // workgroups resident together (1 per CU)
+};
+
+// Two-pass copy of a CSR ("expand, then reduce"; see DESIGN.md "spmv_expand_kernel / spmv_reduce_kernel").
+// Columns are cut into bands of kBinCols columns (the x slice of a band lives in LDS), (virtual) rows into panels
+// of at most kBinRowsMax rows (the y slice of a panel lives in LDS).  A RUN is the set of entries of one
+// (band, panel) pair, kept in CSR storage order and padded to a multiple of kBinGroup entries.
+//   pass 1 streams the runs in (band, panel) order: local column ids in, products out -- each group of kBinGroup
+//          products goes to the place of its run in (panel, band) order (gdst), i.e. whole 128-byte lines;
+//   pass 2 streams the products of one panel, which are now contiguous, with their local row ids, and adds them
+//          into the y slice.
+// No access of either pass leaves LDS except the two sequential streams.
+constexpr int kBinBlock = 1024;        // threads per workgroup, both passes
+constexpr int kBinCols = 16384;        // columns per band: 128 KiB of x in LDS, one pass-1 workgroup per CU
+constexpr int kBinRowsMax = 16384;     // rows per panel: 128 KiB of y in LDS, one pass-2 workgroup per CU (measured equal to
+                                       // 8192 rows x two workgroups; larger panels mean longer runs, less padding)
+constexpr int kBinGroupLog = 4;
+constexpr int kBinGroup = 1 << kBinGroupLog;  // entries per group = one 128-byte L2 line of products (runs that start on half
+                                               // lines were measured 19 % slower in pass 1: 0.459 vs 0.386 ms)
+constexpr int kBinShareMin = 8192;     // a pass-1 workgroup streams at least this many entries
+
+struct BinnedCsr {
+  bool built = false;
+  int B = 0, P = 0;            // bands, panels
+  int64_t n = 0;               // padded entry count (multiple of kBinGroup)
+  uint16_t *lcol = nullptr;    // n, pass-1 order: column - band*kBinCols; padding = kBinCols (a zero slot)
+  double *vals = nullptr;      // n, pass-1 order (nullptr: pattern-only); padding = 0
+  unsigned *gdst = nullptr;    // n / kBinGroup: pass-2 group index of every pass-1 group
+  uint16_t *lrow = nullptr;    // n, pass-2 order: (virtual) row - first row of the panel; padding = 0
+  double *prod = nullptr;      // n, pass-2 order: written by pass 1, read by pass 2
+  unsigned *band_ptr = nullptr;  // B + 1: first pass-1 group of every band
+  int nwg1 = 0;                // pass-1 workgroups (persistent, one per CU)
+  unsigned *bin_ptr = nullptr; // P + 1: first pass-2 group of every panel
+  int *panel_row = nullptr;    // P + 1: first (virtual) row of every panel
+  int split = 0, nvrow = 0;    // virtual rows, as in TiledCsr
+  int *vfirst = nullptr;
+  double *yv = nullptr;
 };
 
 }  // namespace fs
@@ -106,12 +144,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 struct Options {
   int strict_order = 0;
-  int spmv_kernel = 0;   // 0 auto, 1 stream (nt loads), 2 lanes-per-row, 3 stream (cached loads), 6 tiled
+  int spmv_kernel = 0;   // 0 auto, 1 stream (nt loads), 2 lanes-per-row, 3 stream (cached loads), 6 tiled, 7 two-pass
   int tiling = 1;        // 1: build the L2-tiled copy when the heuristic says it pays, 2: always, 0: never
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
   int tile_split = 0;    // rows longer than this are cut into virtual rows (0 = 256)
   int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
+  int reproducible = 0;  // 1: only kernels whose sums are bit-identical run to run (the two-pass kernels add with LDS
+                         // atomics in arrival order); read when a matrix is created and at every product
+  int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
+  int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
 };
 Options &options();
 
@@ -124,6 +166,8 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
+int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heuristic ask for it
+int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
                             hipStream_t s);
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,

@@ -7,6 +7,11 @@
 // (0.17 flop/B), the spare multiply issue slot costs nothing.
 //
 // Kernels
+//   spmv_expand_kernel / spmv_reduce_kernel
+//                        y = A x in two streaming passes on the two-pass copy (column bands x row panels): the
+//                        default for large matrices.  Pass 1 keeps a band of x in LDS and writes the products,
+//                        regrouped by row panel, to HBM; pass 2 keeps a panel of y in LDS and adds them up.
+//                        Neither pass gathers from L2 or HBM.
 //   spmv_tiled_kernel    y = A x on the L2-tiled copy (row panels x column bands): the default for matrices
 //                        whose x does not fit a CU's L1 many times over.  One 1024-thread workgroup per CU;
 //                        producer waves stream the entries and gather x inside the current band, consumer
@@ -488,6 +493,109 @@ __global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int n
 }
 
 // ------------------------------------------------------------------------------------------
+// y = A x in two streaming passes (BinnedCsr in fs_common.h).  Same callers as the kernels above.
+//
+// Why: with 16 entries per row and a vector x of tens of MB, a gather kernel is bound by the rate at which
+// L2 answers 8-byte requests (measured 240 G/s when every request hits, 53 G/s when every one goes to HBM),
+// not by bytes.  Here every random access is an LDS access: pass 1 gathers x from a 128 KiB band held in LDS,
+// pass 2 scatters into a 128 KiB slice of y held in LDS, and what travels between them is a sequential stream
+// of products laid out so that each pass reads and writes whole lines.  20.5 bytes per entry at stream speed
+// beat 4 bytes per entry at gather speed.
+//
+// Sum order: a row's terms are added band by band, and inside a band by LDS atomics in no fixed order --
+// the result is exact for pattern matrices with integer-valued x and within the usual rounding bound
+// otherwise; strict_order keeps the chunk-streaming kernel.
+// ------------------------------------------------------------------------------------------
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// pass 1: persistent workgroups, one per CU; workgroup w streams the w-th equal share of the (band, panel)-ordered
+// groups and reloads its x band when the share crosses into the next band (every band is loaded once, plus once
+// per share boundary: cutting bands into many small workgroups instead re-reads x several times over)
+template <bool VALUED>
+__global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
+    int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
+    const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
+    double *__restrict__ prod)
+{
+  __shared__ double xband[kBinCols + 8];   // slot kBinCols is the zero the padding entries point at
+  const int t = threadIdx.x;
+  const uint64_t groups = band_ptr[B];
+  const unsigned g0 = (unsigned)(groups * blockIdx.x / gridDim.x), g1 = (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
+  if (g0 >= g1) return;
+  // band of the first group: last b with band_ptr[b] <= g0
+  int b;
+  {
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo + 1) >> 1);
+      if (band_ptr[mid] <= g0) lo = mid; else hi = mid - 1;
+    }
+    b = lo;
+  }
+  constexpr unsigned kPad = (unsigned)kBinCols | ((unsigned)kBinCols << 16);
+  for (unsigned g = g0; g < g1; ++b) {
+    const unsigned gb = band_ptr[b + 1] < g1 ? band_ptr[b + 1] : g1;   // end of this band's part of the share
+    if (gb <= g) continue;                                               // empty band
+    const int c0 = b * kBinCols;
+    const int w = (ncol - c0 < kBinCols) ? ncol - c0 : kBinCols;
+    __syncthreads();                                                     // everyone is done with the previous band
+    for (int i = t; i < kBinCols + 8; i += kBinBlock)
+      xband[i] = (i < w) ? __builtin_nontemporal_load(x + (int64_t)(c0 + i) * xs) : 0.0;
+    __syncthreads();
+    const int64_t e0 = (int64_t)g * kBinGroup, e1 = (int64_t)gb * kBinGroup;
+    // a lane takes 2 consecutive entries per step, so a wave's stores are 1 KiB of consecutive products; 4 steps in flight
+    for (int64_t o = e0 + 2 * t; o < e1; o += 8 * kBinBlock) {
+      unsigned a[4], d[4];
+      v2d v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t e = o + (int64_t)k * 2 * kBinBlock;
+        const bool ok = e < e1;
+        a[k] = ok ? __builtin_nontemporal_load((const unsigned *)(lcol + e)) : kPad;
+        d[k] = ok ? __builtin_nontemporal_load(gdst + (e >> kBinGroupLog)) : 0u;
+        if (VALUED) v[k] = ok ? __builtin_nontemporal_load((const v2d *)(vals + e)) : v2d{0.0, 0.0};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t e = o + (int64_t)k * 2 * kBinBlock;
+        v2d p = {xband[a[k] & 0xffffu], xband[a[k] >> 16]};
+        if (VALUED) { p.x *= v[k].x; p.y *= v[k].y; }
+        if (e < e1) __builtin_nontemporal_store(p, (v2d *)(prod + (int64_t)d[k] * kBinGroup + (e & (kBinGroup - 1))));
+      }
+    }
+    g = gb;
+  }
+}
+
+// pass 2: workgroup = one row panel; its products are contiguous
+__global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
+    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
+    const double *__restrict__ prod, double *__restrict__ y, int ys)
+{
+  __shared__ double ytile[kBinRowsMax];
+  const int t = threadIdx.x;
+  const int r0 = panel_row[blockIdx.x], nr = panel_row[blockIdx.x + 1] - r0;
+  for (int i = t; i < nr; i += kBinBlock) ytile[i] = 0.0;
+  __syncthreads();
+  const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * kBinGroup, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * kBinGroup;
+  for (int64_t e = e0 + 8 * t; e < e1; e += 8 * kBinBlock) {   // 8 entries (64 bytes of products) per lane and step
+    const v4u a = __builtin_nontemporal_load((const v4u *)(lrow + e));
+    const v2d p0 = __builtin_nontemporal_load((const v2d *)(prod + e));
+    const v2d p1 = __builtin_nontemporal_load((const v2d *)(prod + e + 2));
+    const v2d p2 = __builtin_nontemporal_load((const v2d *)(prod + e + 4));
+    const v2d p3 = __builtin_nontemporal_load((const v2d *)(prod + e + 6));
+#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    FS_ADD(a.x & 0xffffu, p0.x); FS_ADD(a.x >> 16, p0.y);
+    FS_ADD(a.y & 0xffffu, p1.x); FS_ADD(a.y >> 16, p1.y);
+    FS_ADD(a.z & 0xffffu, p2.x); FS_ADD(a.z >> 16, p2.y);
+    FS_ADD(a.w & 0xffffu, p3.x); FS_ADD(a.w >> 16, p3.y);
+#undef FS_ADD
+  }
+  __syncthreads();
+  for (int i = t; i < nr; i += kBinBlock) y[(int64_t)(r0 + i) * ys] = ytile[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static int ceil_log2(int v)
@@ -530,6 +638,30 @@ int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_
   return FS_OK;
 }
 
+int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys)
+{
+  const BinnedCsr &N = *A.binned;
+  double *out = N.split ? N.yv : y;              // cut rows: virtual sums first, combined below
+  const int os = N.split ? 1 : ys;
+  if (N.nwg1 > 0) {
+    if (A.vals)
+      hipLaunchKernelGGL(spmv_expand_kernel<true>, dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol,
+                         N.vals, N.gdst, x, xs, N.prod);
+    else
+      hipLaunchKernelGGL(spmv_expand_kernel<false>, dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol,
+                         N.vals, N.gdst, x, xs, N.prod);
+    FS_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(spmv_reduce_kernel, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+  FS_HIP(hipGetLastError());
+  if (N.split) {
+    hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       A.nrow, N.vfirst, N.yv, y, ys);
+    FS_HIP(hipGetLastError());
+  }
+  return FS_OK;
+}
+
 // diagnostic: one launch of the tiled kernel that also records, per work item, the start time
 // (100 MHz wall clock) and, per panel, the XCD that ran it
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
@@ -555,6 +687,8 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
   const bool valued = A.vals != nullptr;
   // auto: the L2-tiled copy when it was built (format builder decided it pays) and the caller did not
   // ask for storage-order sums
+  if (A.binned && A.binned->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7))
+    return launch_spmv_binned(A, y, x, s);
   if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6))
     return launch_spmv_tiled(A, y, x, s);
   if (o.spmv_kernel == 2) {
@@ -604,6 +738,12 @@ int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream
   // two right-hand sides (the block-CG case, bsbm_A_mul_B2 / bcsr_A_mul_B2) on a matrix with an L2-tiled copy:
   // one tiled sweep per column of the
   // row-major X / Y (strided gathers and stores) beats the row kernel, whose every X-row gather misses L2
+  if (k <= 2 && A.binned && A.binned->built && !options().strict_order && !options().reproducible &&
+      (options().spmv_kernel == 0 || options().spmv_kernel == 7)) {
+    for (int j = 0; j < k; ++j)
+      if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
+    return FS_OK;
+  }
   if (k <= 2 && A.tiled && A.tiled->built && !options().strict_order &&
       (options().spmv_kernel == 0 || options().spmv_kernel == 6)) {
     for (int j = 0; j < k; ++j)

@@ -474,3 +474,98 @@ def test_tiled_auto_on_extreme_row_lengths(hip):
             else:
                 scale = O.csr_abs_scale(nrow, r_, c_, v_, x)
                 assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300))
+
+
+@pytest.mark.parametrize("bin_rows", [0, 64, 1000])
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_two_pass_kernels_vs_reference_golden(hip, case, bin_rows):
+    """the two-pass (expand, then reduce) kernels, forced on: every entry point of every golden case, within the
+    fp64 bar and bit-exact for pattern-only integer products; small panels so that the cases span many of them"""
+    from libfastsparse_amd import capi
+    capi.set_option("binning", 2)
+    capi.set_option("bin_rows", bin_rows)
+    capi.set_option("tile_split", 37 if bin_rows == 64 else 0)
+    try:
+        gold = np.load(os.path.join(S.GOLDEN, case.name + ".npz"))
+        out = _cases.run_case(hip.HipDeviceBackend(), case, light=True)
+        _check(out, gold, case.name, exact=False)
+    finally:
+        capi.set_option("binning", 1)
+        capi.set_option("bin_rows", 0)
+        capi.set_option("tile_split", 0)
+
+
+@pytest.mark.parametrize("valued", [False, True])
+def test_two_pass_kernels_many_bands_and_panels(hip, valued):
+    """several column bands (the last one partial), hundreds of panels, ragged rows (0..60 entries, some cut into
+    virtual rows), SpMV, the transposed product and two right-hand sides: every row against the oracle"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(17)
+    nrow, ncol = 50_000, 100_000          # 100000 = 6 x 16384 + 1696
+    lens = rng.integers(0, 61, nrow)
+    lens[rng.uniform(size=nrow) < 0.1] = 0
+    lens[123] = 5000
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    cc[:50] = ncol - 1                      # the last column of the partial band
+    vv = rng.uniform(-1, 1, nnz) if valued else None
+    capi.set_option("binning", 2)
+    capi.set_option("bin_rows", 500)
+    capi.set_option("tile_split", 40)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+        A.build_transpose(capi.current_stream())
+        y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        for x in (S.x_sin(ncol), S.x_int(4, ncol)):
+            A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
+            ref = O.csr_mul(nrow, rp, cc, vv, x)
+            got = y.cpu().numpy()
+            if not valued and np.all(x == np.round(x)):
+                assert np.array_equal(got, ref)
+            else:
+                scale = O.csr_abs_scale(nrow, rp, cc, vv, x)
+                assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300))
+        X = S.X_sin(ncol, 2)
+        Y = torch.full((nrow, 2), -1.0, dtype=torch.float64, device="cuda")
+        A.spmm(Y, torch.from_numpy(X).cuda(), 2, capi.current_stream())
+        Yref = O.csr_mul_n(nrow, rp, cc, vv, X, 2)
+        for j in range(2):
+            sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X[:, j]))
+            assert np.all(np.abs(Y.cpu().numpy()[:, j] - Yref[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
+        z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+        xt = S.x_sin(nrow, 11.0, -0.2)
+        A.spmv(z, torch.from_numpy(xt).cuda(), capi.current_stream(), transposed=True)
+        rows = np.repeat(np.arange(nrow, dtype=np.int32), lens)
+        zref = O.coo_tmul(ncol, rows, cc, vv, xt)
+        zscale = O.coo_tmul(ncol, rows, cc, None if vv is None else np.abs(vv), np.abs(xt))
+        assert np.all(np.abs(z.cpu().numpy() - zref) <= TOL * np.maximum(zscale, 1e-300))
+    finally:
+        capi.set_option("binning", 1)
+        capi.set_option("bin_rows", 0)
+        capi.set_option("tile_split", 0)
+
+
+def test_two_pass_auto_on_large_uniform(hip):
+    """a matrix large enough for the format builder to choose the two-pass copy by itself (40 M non-zeros, x of
+    32 MB): SpMV against the oracle on every row, integer x bit-exact, and the choice itself"""
+    import torch
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    nrow, ncol, per = 2_500_000, 4_000_000, 16
+    rp, cc, _ = capi.synth_uniform(nrow, ncol, per, 0x51, valued=False)
+    A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+    assert A.kernel_name() == "two-pass"
+    hrp, hcc, _ = pysynth.uniform(nrow, ncol, per, 0x51, valued=False)
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    xi = S.x_int(9, ncol)
+    A.spmv(y, torch.from_numpy(xi).cuda(), capi.current_stream())
+    assert np.array_equal(y.cpu().numpy(), O.csr_mul(nrow, hrp, hcc, None, xi))
+    xs = S.x_sin(ncol)
+    A.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+    ref = O.csr_mul(nrow, hrp, hcc, None, xs)
+    scale = O.csr_abs_scale(nrow, hrp, hcc, None, xs)
+    assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(scale, 1e-300))

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--tiling", type=int, default=1)
     ap.add_argument("--ncols", type=int, nargs="*", default=None)
     ap.add_argument("--gate-kb", type=int, default=8192)
+    ap.add_argument("--bin-rows", type=int, default=0)
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     out = open(args.out, "a")
@@ -70,6 +71,31 @@ def main():
                    timeit(lambda: torch.index_select(table, 0, idx), iters=5, warm=1))
             del idx
         del a
+    if "bin" in what:
+        # two-pass kernels against the tiled kernel on the config-2 shape (valued and pattern-only), k = 1, 2, A'
+        capi.set_option("bin_rows", args.bin_rows)
+        capi.set_option("tiling", 2)
+        ncol = args.ncols[0] if args.ncols else n
+        for valued in (True, False):
+            rp, cc, vv = capi.synth_uniform(n, ncol, 16, 0x5EED0002, valued=valued)
+            t0 = time.time()
+            A = capi.Matrix.from_csr(n, ncol, rp, cc, vv, borrow=True)
+            torch.cuda.synchronize()
+            print("build s", time.time() - t0, "kernel", A.kernel_name(), flush=True)
+            x = torch.sin(7.0 * torch.arange(ncol, device="cuda", dtype=torch.float64) + 0.3)
+            y = torch.empty(n, dtype=torch.float64, device="cuda")
+            tag = "f64" if valued else "pattern"
+            for kern, label in ((7, "two_pass"), (6, "tiled")):
+                capi.set_option("spmv_kernel", kern)
+                report(out, f"c2_{tag}_ncol{ncol}_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            capi.set_option("spmv_kernel", 0)
+            if valued:
+                X = torch.sin(torch.arange(ncol * 2, device="cuda", dtype=torch.float64)).reshape(ncol, 2)
+                Y = torch.empty(n, 2, dtype=torch.float64, device="cuda")
+                report(out, f"c2_{tag}_spmm_k2_auto", A.algorithmic_bytes(2), timeit(lambda: A.spmm(Y, X, 2, st), iters=5, warm=1))
+                del X, Y
+            del A, rp, cc, vv
+        capi.set_option("tiling", args.tiling)
     if "c2" in what:
         rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
         A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
