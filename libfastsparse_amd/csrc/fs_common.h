@@ -167,6 +167,7 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
 int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
 int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heuristic ask for it
+int choose_copy(DeviceCsr &A, hipStream_t s);       // times the candidates and keeps the fastest copy
 int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
                             hipStream_t s);

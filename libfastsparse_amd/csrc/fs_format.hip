@@ -124,10 +124,9 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
   FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
   if (!allow_tiled) return FS_OK;
-  // the two-pass copy serves every product the tiled copy serves and is faster wherever it is built
   if (int rc = build_binned(A, s)) return rc;
-  if (A.binned && A.binned->built && options().tiling != 2) return FS_OK;
-  return build_tiled(A, s);
+  if (int rc = build_tiled(A, s)) return rc;
+  return choose_copy(A, s);
 }
 
 // ---- stable COO -> CSR -----------------------------------------------------------------------
@@ -716,9 +715,7 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
     const double x_bytes = (double)A.ncol * 8;
     const double t_bin = ((double)N->n * (A.vals ? 28.5 : 20.5) + (double)(B + ncu) * kBinCols * 8 + (double)nvrow * 8) / 4.6e12;
     const double t_stream = (double)A.nnz / (x_bytes <= (3 << 20) ? 172e9 : 53e9);
-    const double gens = (double)((nvrow / kTiledRowsMax + 256) / 256);
-    const double t_tiled = (double)A.nnz / 150e9 + gens * x_bytes / 2.7e12;
-    if (t_bin > 0.95 * (t_stream < t_tiled ? t_stream : t_tiled)) return FS_OK;
+    if (t_bin > 0.95 * t_stream) return FS_OK;   // hopeless; between the survivors choose_copy measures
   }
 
   // ---- lay out both orders ------------------------------------------------------------------------------------
@@ -745,6 +742,58 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   }
   FS_HIP(hipStreamSynchronize(s));
   N->built = true;
+  return FS_OK;
+}
+
+// ---- which copy to keep ---------------------------------------------------------------------------------
+// The estimates in the builders only weed out hopeless candidates.  Between the survivors (and the chunk-streaming
+// kernel, which needs no copy) the choice is measured: every candidate runs the product on a zero vector -- same
+// addresses and traffic as any x -- and the fastest keeps its copy; the others are released.  The tiled kernel
+// adds in a fixed order, the two-pass kernels do not, so the latter have to win by a margin.
+template <typename F>
+static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *best)
+{
+  *best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {   // the first run also warms the instruction cache and the TLB
+    FS_HIP(hipEventRecord(e0, s));
+    if (int rc = launch()) return rc;
+    FS_HIP(hipEventRecord(e1, s));
+    FS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < *best) *best = ms;
+  }
+  return FS_OK;
+}
+
+int choose_copy(DeviceCsr &A, hipStream_t s)
+{
+  const Options &o = options();
+  const bool hb = A.binned && A.binned->built, ht = A.tiled && A.tiled->built;
+  if ((!hb && !ht) || o.tiling == 2 || o.binning == 2) return FS_OK;   // nothing to choose, or the caller chose
+  Scratch<double> x, y;
+  if (x.alloc((size_t)A.ncol) != hipSuccess || y.alloc((size_t)A.nrow) != hipSuccess) {
+    (void)hipGetLastError();
+    return FS_OK;                                                       // no room to measure: keep the estimate's order
+  }
+  FS_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)A.ncol, s));
+  hipEvent_t e0, e1;
+  FS_HIP(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return FS_OK; }
+  float t_stream = 1e30f, t_tiled = 1e30f, t_bin = 1e30f;
+  int rc = time_product([&] { return launch_spmv(A, y, x, s, true); }, s, e0, e1, &t_stream);
+  if (rc == FS_OK && ht) rc = time_product([&] { return launch_spmv_tiled(A, y, x, s); }, s, e0, e1, &t_tiled);
+  if (rc == FS_OK && hb) rc = time_product([&] { return launch_spmv_binned(A, y, x, s); }, s, e0, e1, &t_bin);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != FS_OK) return rc;
+  const float t_fixed = t_tiled < t_stream ? t_tiled : t_stream;        // best kernel with a fixed order of additions
+  if (hb && t_bin < 0.97f * t_fixed) {
+    free_tiled(A);
+  } else {
+    free_binned(A);
+    if (ht && t_stream <= t_tiled) free_tiled(A);
+  }
   return FS_OK;
 }
 

@@ -549,23 +549,31 @@ def test_two_pass_kernels_many_bands_and_panels(hip, valued):
         capi.set_option("tile_split", 0)
 
 
-def test_two_pass_auto_on_large_uniform(hip):
-    """a matrix large enough for the format builder to choose the two-pass copy by itself (40 M non-zeros, x of
-    32 MB): SpMV against the oracle on every row, integer x bit-exact, and the choice itself"""
+def test_two_pass_on_thousands_of_bands(hip):
+    """x of 480 MB (3663 column bands, the last one partial), 40 M non-zeros: the format builder's own measured
+    choice and the two-pass copy forced, both against the oracle on every row, integer x bit-exact"""
     import torch
     from libfastsparse_amd import capi
     from oracle import pysynth
-    nrow, ncol, per = 2_500_000, 4_000_000, 16
+    nrow, ncol, per = 1_000_000, 60_000_000, 40
     rp, cc, _ = capi.synth_uniform(nrow, ncol, per, 0x51, valued=False)
-    A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
-    assert A.kernel_name() == "two-pass"
     hrp, hcc, _ = pysynth.uniform(nrow, ncol, per, 0x51, valued=False)
-    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
-    xi = S.x_int(9, ncol)
-    A.spmv(y, torch.from_numpy(xi).cuda(), capi.current_stream())
-    assert np.array_equal(y.cpu().numpy(), O.csr_mul(nrow, hrp, hcc, None, xi))
-    xs = S.x_sin(ncol)
-    A.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
-    ref = O.csr_mul(nrow, hrp, hcc, None, xs)
+    xi, xs = S.x_int(9, ncol), S.x_sin(ncol)
+    ref_i = O.csr_mul(nrow, hrp, hcc, None, xi)
+    ref_s = O.csr_mul(nrow, hrp, hcc, None, xs)
     scale = O.csr_abs_scale(nrow, hrp, hcc, None, xs)
-    assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(scale, 1e-300))
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    chosen = []
+    for binning in (1, 2):
+        capi.set_option("binning", binning)
+        try:
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+        finally:
+            capi.set_option("binning", 1)
+        chosen.append(A.kernel_name())
+        A.spmv(y, torch.from_numpy(xi).cuda(), capi.current_stream())
+        assert np.array_equal(y.cpu().numpy(), ref_i), chosen
+        A.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+        assert np.all(np.abs(y.cpu().numpy() - ref_s) <= TOL * np.maximum(scale, 1e-300)), chosen
+        del A
+    assert chosen[0] in ("two-pass", "tiled", "stream") and chosen[1] == "two-pass", chosen

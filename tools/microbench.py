@@ -102,7 +102,7 @@ def main():
         x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         B = A.algorithmic_bytes()
-        for kern, label in ((6, "tiled"), (1, "stream_nt"), (2, "vector")):
+        for kern, label in ((0, "auto:" + A.kernel_name()), (1, "stream_nt"), (2, "vector")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c2_csr_f64_{label}", B, timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
@@ -130,7 +130,7 @@ def main():
         A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
         x = torch.randint(-1000, 1001, (ncol,), device="cuda").to(torch.float64)
         y = torch.empty(nrow, dtype=torch.float64, device="cuda")
-        for kern, label in ((6, "tiled"), (1, "stream_nt")):
+        for kern, label in ((0, "auto:" + A.kernel_name()), (1, "stream_nt")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
@@ -256,7 +256,7 @@ def main():
         A = capi.Matrix.from_csr(nrow, c5cols, rp, cc, vv, borrow=True)
         x = torch.sin(7.0 * torch.arange(c5cols, device="cuda", dtype=torch.float64) + 0.3)
         y = torch.empty(nrow, dtype=torch.float64, device="cuda")
-        for kern, label in ((6, "tiled"), (1, "stream_nt"), (2, "vector")):
+        for kern, label in ((0, "auto:" + A.kernel_name()), (1, "stream_nt")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c5shard_powerlaw_ncol{c5cols}_{label}_nnz{A.nnz}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
