@@ -93,6 +93,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "tile_split")) { fs::options().tile_split = value; return FS_OK; }
   if (!strcmp(name, "tiled_flags")) { fs::options().tiled_flags = value; return FS_OK; }
   if (!strcmp(name, "reproducible")) { fs::options().reproducible = value; return FS_OK; }
+  if (!strcmp(name, "bin_flags")) { fs::options().bin_flags = value; return FS_OK; }
   if (!strcmp(name, "bin_rows")) { fs::options().bin_rows = value; return FS_OK; }
   if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);

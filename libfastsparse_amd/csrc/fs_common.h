@@ -152,6 +152,7 @@ struct Options {
   int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
   int reproducible = 0;  // 1: only kernels whose sums are bit-identical run to run (the two-pass kernels add with LDS
                          // atomics in arrival order); read when a matrix is created and at every product
+  int bin_flags = 0;     // tuning switches of the two-pass kernels (see launch_spmv_binned)
   int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
   int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
 };

@@ -511,7 +511,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // pass 1: persistent workgroups, one per CU; workgroup w streams the w-th equal share of the (band, panel)-ordered
 // groups and reloads its x band when the share crosses into the next band (every band is loaded once, plus once
 // per share boundary: cutting bands into many small workgroups instead re-reads x several times over)
-template <bool VALUED>
+template <bool VALUED, int U>
 __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
     int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
     const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
@@ -543,12 +543,12 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
       xband[i] = (i < w) ? __builtin_nontemporal_load(x + (int64_t)(c0 + i) * xs) : 0.0;
     __syncthreads();
     const int64_t e0 = (int64_t)g * kBinGroup, e1 = (int64_t)gb * kBinGroup;
-    // a lane takes 2 consecutive entries per step, so a wave's stores are 1 KiB of consecutive products; 4 steps in flight
-    for (int64_t o = e0 + 2 * t; o < e1; o += 8 * kBinBlock) {
-      unsigned a[4], d[4];
-      v2d v[4];
+    // a lane takes 2 consecutive entries per step, so a wave's stores are 1 KiB of consecutive products; U steps in flight
+    for (int64_t o = e0 + 2 * t; o < e1; o += 2 * U * kBinBlock) {
+      unsigned a[U], d[U];
+      v2d v[U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < U; ++k) {
         const int64_t e = o + (int64_t)k * 2 * kBinBlock;
         const bool ok = e < e1;
         a[k] = ok ? __builtin_nontemporal_load((const unsigned *)(lcol + e)) : kPad;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
         if (VALUED) v[k] = ok ? __builtin_nontemporal_load((const v2d *)(vals + e)) : v2d{0.0, 0.0};
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < U; ++k) {
         const int64_t e = o + (int64_t)k * 2 * kBinBlock;
         v2d p = {xband[a[k] & 0xffffu], xband[a[k] >> 16]};
         if (VALUED) { p.x *= v[k].x; p.y *= v[k].y; }
@@ -644,12 +644,13 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   double *out = N.split ? N.yv : y;              // cut rows: virtual sums first, combined below
   const int os = N.split ? 1 : ys;
   if (N.nwg1 > 0) {
-    if (A.vals)
-      hipLaunchKernelGGL(spmv_expand_kernel<true>, dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol,
-                         N.vals, N.gdst, x, xs, N.prod);
-    else
-      hipLaunchKernelGGL(spmv_expand_kernel<false>, dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol,
-                         N.vals, N.gdst, x, xs, N.prod);
+    const int flags = options().bin_flags;   // tuning switches: bits 0-1 select the pass-1 unroll (0: default)
+#define FS_EXPAND(V, U)                                                                                            \
+  hipLaunchKernelGGL((spmv_expand_kernel<V, U>), dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol, \
+                     N.vals, N.gdst, x, xs, N.prod)
+    if (A.vals) { if ((flags & 3) == 1) FS_EXPAND(true, 8); else if ((flags & 3) == 2) FS_EXPAND(true, 2); else FS_EXPAND(true, 4); }
+    else        { if ((flags & 3) == 1) FS_EXPAND(false, 8); else if ((flags & 3) == 2) FS_EXPAND(false, 2); else FS_EXPAND(false, 4); }
+#undef FS_EXPAND
     FS_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(spmv_reduce_kernel, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);

@@ -85,9 +85,11 @@ def main():
             x = torch.sin(7.0 * torch.arange(ncol, device="cuda", dtype=torch.float64) + 0.3)
             y = torch.empty(n, dtype=torch.float64, device="cuda")
             tag = "f64" if valued else "pattern"
-            for kern, label in ((7, "two_pass"), (6, "tiled")):
+            for kern, label, fl in ((7, "two_pass", 0), (6, "tiled", 0), (7, "two_pass_u8", 1), (7, "two_pass_u2", 2), (7, "two_pass", 0)):
                 capi.set_option("spmv_kernel", kern)
+                capi.set_option("bin_flags", fl)
                 report(out, f"c2_{tag}_ncol{ncol}_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            capi.set_option("bin_flags", 0)
             capi.set_option("spmv_kernel", 0)
             if valued:
                 X = torch.sin(torch.arange(ncol * 2, device="cuda", dtype=torch.float64)).reshape(ncol, 2)
