@@ -164,7 +164,7 @@ class Matrix:
     def kernel_name(self, transposed=False):
         """the SpMV kernel the format builder chose for this matrix (under the current options)"""
         code = lib().fs_matrix_spmv_kernel(self.h, int(transposed))
-        return {1: "stream", 2: "vector", 6: "tiled", 7: "two-pass"}.get(code, str(code))
+        return {1: "stream", 2: "vector", 6: "tiled", 7: "two-pass", 8: "lds-staged"}.get(code, str(code))
 
     def build_transpose(self, stream=None):
         check(lib().fs_matrix_build_transpose(self.h, stream), "fs_matrix_build_transpose")

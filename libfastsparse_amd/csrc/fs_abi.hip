@@ -95,6 +95,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "reproducible")) { fs::options().reproducible = value; return FS_OK; }
   if (!strcmp(name, "bin_flags")) { fs::options().bin_flags = value; return FS_OK; }
   if (!strcmp(name, "bin_rows")) { fs::options().bin_rows = value; return FS_OK; }
+  if (!strcmp(name, "ldsx")) { fs::options().ldsx = value; return FS_OK; }
   if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
@@ -109,6 +110,7 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "tile_cols")) return fs::options().tile_cols;
   if (name && !strcmp(name, "tile_split")) return fs::options().tile_split;
   if (name && !strcmp(name, "binning")) return fs::options().binning;
+  if (name && !strcmp(name, "ldsx")) return fs::options().ldsx;
   if (name && !strcmp(name, "reproducible")) return fs::options().reproducible;
   return FS_ERR_ARG;
 }
@@ -197,6 +199,7 @@ int fs_matrix_spmv_kernel(fs_matrix_t A, int transposed)
   const fs::DeviceCsr &a = transposed ? A->at : A->a;
   const fs::Options &o = fs::options();
   if (!o.strict_order && !o.reproducible && a.binned && a.binned->built && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
+  if (!o.strict_order && !o.reproducible && a.tiledx && a.tiledx->built && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
   if (!o.strict_order && a.tiled && a.tiled->built && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
   return o.spmv_kernel == 2 ? 2 : 1;
 }

@@ -36,6 +36,7 @@ struct DeviceCsr {
   double *tail = nullptr;      // nchunks: sum of the chunk's trailing non-zeros of a row that ends later
   int spanning = 0;            // number of rows that cross a chunk boundary (0 => no fix-up launch)
   TiledCsr *tiled = nullptr;  // optional L2-tiled copy (owned)
+  TiledCsr *tiledx = nullptr; // optional copy in the same layout with the LDS-staged kernel's geometry (owned)
   BinnedCsr *binned = nullptr;  // optional two-pass copy (owned)
 };
 
@@ -53,8 +54,12 @@ constexpr int kTiledItem = 2048;       // entries per work item (4 per producer 
 constexpr int kTiledRowsMax = 13056;   // R <= this: 102 KiB of y per workgroup
 constexpr int kTiledColBits = 18;      // W <= 262144 columns (2 MiB of x); the other 14 bits are the local row
 
+constexpr int kLdsxRows = 15360;       // LDS-staged kernel: rows per panel (120 KiB of y in LDS)
+constexpr int kLdsxCols = 2048;        //                    columns per band: one 16 KiB slice of x, two slices in LDS
+
 struct TiledCsr {
   bool built = false;
+  bool ldsx = false;           // geometry of the LDS-staged kernel (W <= kLdsxCols, R <= kLdsxRows)
   int R = 0, W = 0, P = 0, J = 0, lcol_bits = kTiledColBits;
   unsigned *pk = nullptr;      // nnz packed (local row, local col)
   double *vals = nullptr;      // nnz permuted values (nullptr: pattern-only)
@@ -144,7 +149,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 struct Options {
   int strict_order = 0;
-  int spmv_kernel = 0;   // 0 auto, 1 stream (nt loads), 2 lanes-per-row, 3 stream (cached loads), 6 tiled, 7 two-pass
+  int spmv_kernel = 0;   // 0 auto, 1 stream (nt loads), 2 lanes-per-row, 3 stream (cached loads), 6 tiled, 7 two-pass,
+                         // 8 LDS-staged tiled
   int tiling = 1;        // 1: build the L2-tiled copy when the heuristic says it pays, 2: always, 0: never
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
@@ -154,6 +160,7 @@ struct Options {
                          // atomics in arrival order); read when a matrix is created and at every product
   int bin_flags = 0;     // tuning switches of the two-pass kernels (see launch_spmv_binned)
   int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
+  int ldsx = 1;          // the copy for the LDS-staged kernel: 1 when the estimates do not rule it out, 2 always, 0 never
   int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
 };
 Options &options();
@@ -166,7 +173,9 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
-int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
+int build_tiledx(DeviceCsr &A, hipStream_t s);      // the same for the LDS-staged kernel's geometry
+int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs = 1,
+                      int ys = 1);                  // T.ldsx selects the LDS-staged kernel
 int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heuristic ask for it
 int choose_copy(DeviceCsr &A, hipStream_t s);       // times the candidates and keeps the fastest copy
 int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);

@@ -31,19 +31,18 @@ struct Scratch {
   operator T *() const { return p; }
 };
 
-static void free_tiled(DeviceCsr &A)
+static void free_tiled_slot(TiledCsr *&T)
 {
-  if (!A.tiled) return;
-  if (A.tiled->pk) (void)hipFree(A.tiled->pk);
-  if (A.tiled->vals) (void)hipFree(A.tiled->vals);
-  if (A.tiled->items) (void)hipFree(A.tiled->items);
-  if (A.tiled->item_ptr) (void)hipFree(A.tiled->item_ptr);
-  if (A.tiled->panel_row) (void)hipFree(A.tiled->panel_row);
-  if (A.tiled->vfirst) (void)hipFree(A.tiled->vfirst);
-  if (A.tiled->yv) (void)hipFree(A.tiled->yv);
-  delete A.tiled;
-  A.tiled = nullptr;
+  if (!T) return;
+  void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv};
+  for (void *q : owned)
+    if (q) (void)hipFree(q);
+  delete T;
+  T = nullptr;
 }
+
+static void free_tiled(DeviceCsr &A) { free_tiled_slot(A.tiled); }
+static void free_tiledx(DeviceCsr &A) { free_tiled_slot(A.tiledx); }
 
 static void free_binned(DeviceCsr &A)
 {
@@ -67,6 +66,7 @@ void free_csr(DeviceCsr &A)
   if (A.head) (void)hipFree(A.head);
   if (A.tail) (void)hipFree(A.tail);
   free_tiled(A);
+  free_tiledx(A);
   free_binned(A);
   A = DeviceCsr();
 }
@@ -126,6 +126,7 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
   if (!allow_tiled) return FS_OK;
   if (int rc = build_binned(A, s)) return rc;
   if (int rc = build_tiled(A, s)) return rc;
+  if (int rc = build_tiledx(A, s)) return rc;
   return choose_copy(A, s);
 }
 
@@ -352,13 +353,13 @@ static int max_row_len(const DeviceCsr &A, hipStream_t s, int *out)
   return FS_OK;
 }
 
-static int build_tiled_impl(DeviceCsr &A, hipStream_t s);
+static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool ldsx);
 
-// The tiled copy is an optimisation: if building it fails (typically: not enough HBM for the second copy) the
-// matrix stays usable on the chunk-streaming kernel.
+// The tiled copies are optimisations: if building one fails (typically: not enough HBM for another copy) the
+// matrix stays usable on the other kernels.
 int build_tiled(DeviceCsr &A, hipStream_t s)
 {
-  const int rc = build_tiled_impl(A, s);
+  const int rc = build_tiled_impl(A, s, A.tiled, false);
   if (rc != FS_OK || (A.tiled && !A.tiled->built)) {
     free_tiled(A);
     (void)hipGetLastError();
@@ -366,19 +367,32 @@ int build_tiled(DeviceCsr &A, hipStream_t s)
   return FS_OK;
 }
 
-static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
+// the same layout with the geometry of the LDS-staged kernel (x slices of kLdsxCols columns)
+int build_tiledx(DeviceCsr &A, hipStream_t s)
+{
+  const int rc = build_tiled_impl(A, s, A.tiledx, true);
+  if (rc != FS_OK || (A.tiledx && !A.tiledx->built)) {
+    free_tiledx(A);
+    (void)hipGetLastError();
+  }
+  return FS_OK;
+}
+
+static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool ldsx)
 {
   const Options &o = options();
-  if (o.tiling == 0 || A.nrow == 0 || A.nnz == 0) return FS_OK;
+  const int mode = ldsx ? o.ldsx : o.tiling;   // 0 never, 1 when the estimates do not rule it out, 2 always
+  if (mode == 0 || A.nrow == 0 || A.nnz == 0) return FS_OK;
+  if (ldsx && o.reproducible) return FS_OK;    // the LDS-staged kernel adds with atomics in arrival order
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
   const int slots = (ncu > 8 ? ncu : 256) / 8 * 8;  // one workgroup per CU, a multiple of the 8 XCDs
-  const double per_row = (double)A.nnz / A.nrow;
+  const int rows_max = ldsx ? kLdsxRows : kTiledRowsMax;
 
   // ---- cheap rejections first (auto mode) ----------------------------------------------------------
   const int64_t x_bytes = (int64_t)A.ncol * 8;
-  if (o.tiling == 1) {
+  if (mode == 1) {
     // pays when x does not fit the 32 KiB L1 of a CU many times over ...
     // (measured, config-2 rows and non-zeros: x of 0.5-2 MB 0.75-0.82 ms tiled vs 0.92 ms streaming -- narrow
     // bands are L1 resident; x of 4-80 MB 0.70-1.06 ms vs 1.07-2.99 ms; x of 64 KB 1.3 ms vs 0.8 ms)
@@ -391,7 +405,8 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   int split = o.tile_split > 0 ? o.tile_split : 256;
   const bool virt = max_len > split;
   TiledCsr *T = new TiledCsr();
-  A.tiled = T;
+  slot = T;
+  T->ldsx = ldsx;
   T->slots = slots; T->lcol_bits = kTiledColBits; T->split = virt ? split : 0;
   Scratch<int> vrow_ptr_own;
   const int *vrow_ptr = A.row_ptr;
@@ -407,11 +422,11 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   // only if all workgroups of a generation carry the same work -------------------------------------------
   int R = o.tile_rows;
   if (R <= 0) {
-    const int64_t g = ((int64_t)nvrow + (int64_t)slots * kTiledRowsMax - 1) / ((int64_t)slots * kTiledRowsMax);
+    const int64_t g = ((int64_t)nvrow + (int64_t)slots * rows_max - 1) / ((int64_t)slots * rows_max);
     R = (int)(((int64_t)nvrow + slots * g - 1) / (slots * g));
     if (R < 256) R = nvrow < 256 ? nvrow : 256;
   }
-  if (R > kTiledRowsMax) R = kTiledRowsMax;
+  if (R > rows_max) R = rows_max;
   std::vector<int> panel_row;
   if (!virt) {
     for (int r = 0; r < nvrow; r += R) panel_row.push_back(r);
@@ -433,19 +448,27 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
   const int P = (int)panel_row.size();
   panel_row.push_back(nvrow);
 
-  // ---- band width: tiles of about 0.9 work items on average, at most 2 MiB of x ---------------------------
+  // ---- band width: tiles of about 0.9 work items on average, at most 2 MiB of x (L2-resident bands) or one
+  // LDS slice (LDS-staged kernel) -----------------------------------------------------------------------
+  const int w_max = ldsx ? kLdsxCols : (1 << kTiledColBits);
   int W = o.tile_cols;
   if (W <= 0) {
-    double w = 0.9 * kTiledItem * (double)A.ncol * P / (double)A.nnz;
-    if (w < 4096) w = 4096;
-    if (w > (1 << kTiledColBits)) w = (1 << kTiledColBits);
+    double w = (ldsx ? 0.85 : 0.9) * kTiledItem * (double)A.ncol * P / (double)A.nnz;
+    if (w < (ldsx ? 256 : 4096)) w = ldsx ? 256 : 4096;
+    if (w > w_max) w = w_max;
     W = (int)w;
   }
-  if (W > (1 << kTiledColBits)) W = 1 << kTiledColBits;
+  if (W > w_max) W = w_max;
   if (W > A.ncol) W = A.ncol;
   const int J = (A.ncol + W - 1) / W;
   const int64_t ntiles = (int64_t)P * J;
-  if (o.tiling == 1) {
+  if (mode == 1 && ldsx) {
+    // every tile costs one barrier phase and one slice of x from L2: worth it only when the tiles are reasonably
+    // full (config 3, 10 M x 1 M x 64 per row: 1 700 entries per tile; config 2: 43).  Beyond that the choice is
+    // measured (choose_copy).
+    if ((double)A.nnz / ntiles < 600.0) return FS_OK;
+  }
+  if (mode == 1 && !ldsx) {
     // tiles must not be hopelessly thin, and re-reading x once per generation of resident workgroups must
     // cost less than the L2 misses it saves.  Measured: tiled ~150 G entries/s; one generation's sweep of x
     // costs ~x_bytes / 2.7 TB/s (the XCDs sweep in step, so a band leaves HBM once and the other seven L2s are
@@ -458,7 +481,6 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s)
     if (t_tiled > 0.95 * t_stream) return FS_OK;
   }
   if (ntiles >= (1ll << 31)) return FS_OK;
-  (void)per_row;
   T->R = R; T->W = W; T->P = P; T->J = J;
   FS_HIP(hipMalloc(&T->panel_row, sizeof(int) * panel_row.size()));
   FS_HIP(hipMemcpyAsync(T->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
@@ -771,8 +793,14 @@ static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, f
 int choose_copy(DeviceCsr &A, hipStream_t s)
 {
   const Options &o = options();
-  const bool hb = A.binned && A.binned->built, ht = A.tiled && A.tiled->built;
-  if ((!hb && !ht) || o.tiling == 2 || o.binning == 2) return FS_OK;   // nothing to choose, or the caller chose
+  const bool hb = A.binned && A.binned->built, ht = A.tiled && A.tiled->built, hx = A.tiledx && A.tiledx->built;
+  if (!hb && !ht && !hx) return FS_OK;
+  if (o.tiling == 2 || o.binning == 2 || o.ldsx == 2) {   // the caller chose: keep what was asked for, nothing else
+    if (o.binning != 2) free_binned(A);
+    if (o.ldsx != 2) free_tiledx(A);
+    if (o.tiling != 2) free_tiled(A);
+    return FS_OK;
+  }
   Scratch<double> x, y;
   if (x.alloc((size_t)A.ncol) != hipSuccess || y.alloc((size_t)A.nrow) != hipSuccess) {
     (void)hipGetLastError();
@@ -782,20 +810,21 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   hipEvent_t e0, e1;
   FS_HIP(hipEventCreate(&e0));
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return FS_OK; }
-  float t_stream = 1e30f, t_tiled = 1e30f, t_bin = 1e30f;
+  float t_stream = 1e30f, t_tiled = 1e30f, t_bin = 1e30f, t_ldsx = 1e30f;
   int rc = time_product([&] { return launch_spmv(A, y, x, s, true); }, s, e0, e1, &t_stream);
-  if (rc == FS_OK && ht) rc = time_product([&] { return launch_spmv_tiled(A, y, x, s); }, s, e0, e1, &t_tiled);
+  if (rc == FS_OK && ht) rc = time_product([&] { return launch_spmv_tiled(A, *A.tiled, y, x, s); }, s, e0, e1, &t_tiled);
+  if (rc == FS_OK && hx) rc = time_product([&] { return launch_spmv_tiled(A, *A.tiledx, y, x, s); }, s, e0, e1, &t_ldsx);
   if (rc == FS_OK && hb) rc = time_product([&] { return launch_spmv_binned(A, y, x, s); }, s, e0, e1, &t_bin);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc != FS_OK) return rc;
-  const float t_fixed = t_tiled < t_stream ? t_tiled : t_stream;        // best kernel with a fixed order of additions
-  if (hb && t_bin < t_fixed) {
-    free_tiled(A);
-  } else {
-    free_binned(A);
-    if (ht && t_stream <= t_tiled) free_tiled(A);
-  }
+  float best = t_stream;
+  if (t_tiled < best) best = t_tiled;
+  if (t_ldsx < best) best = t_ldsx;
+  if (t_bin < best) best = t_bin;
+  if (!(hb && t_bin == best)) free_binned(A);
+  if (!(hx && t_ldsx == best) || A.binned) free_tiledx(A);
+  if (!(ht && t_tiled == best) || A.binned || A.tiledx) free_tiled(A);
   return FS_OK;
 }
 

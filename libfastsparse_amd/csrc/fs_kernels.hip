@@ -243,6 +243,11 @@ constexpr int kTiledPer = kTiledItem / kTiledProd;  // 4 entries per producer (a
 // Whole 512-entry slabs past the item's end are skipped (wave-uniform test); inside the last slab the
 // position is clamped to the last entry, so the loads themselves are unconditional and the clamped lanes
 // re-read one cached word.
+// Pattern-only: every load is unconditional and nothing touches its result before the phase that needs it -- a load
+// under a branch (or a select on its result) makes the compiler lose count of what is in flight and wait for more
+// than it has to (LDS-staged kernel below: 1.63 ms with skipped slabs, 1.08 ms with straight-line phases; here 0.85
+// -> 0.82 ms).  Valued: the kernel sits at the 128-register limit and the 512-entry slabs past an item's end are
+// still skipped (unconditional: 1.23 ms, skipped: 1.05 ms on config 2).
 template <bool VALUED, bool NT>
 __device__ __forceinline__ void tiled_load(const int4 d, int tp, const unsigned *__restrict__ pk,
                                            const double *__restrict__ vals, unsigned (&w)[kTiledPer],
@@ -251,7 +256,7 @@ __device__ __forceinline__ void tiled_load(const int4 d, int tp, const unsigned 
   const int last = d.y > 0 ? d.y - 1 : 0;
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q) {
-    if (q * kTiledProd < d.y || q == 0) {
+    if (!VALUED || q * kTiledProd < d.y || q == 0) {   // see above: slabs past the item's end are skipped when valued
       const int pos = q * kTiledProd + tp;
       const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
       w[q] = stream_load<NT>(pk + e);
@@ -261,13 +266,14 @@ __device__ __forceinline__ void tiled_load(const int4 d, int tp, const unsigned 
 }
 
 // x may be one column of a row-major k-column X: element c lives at x[c * xs] (xs = 1 for a plain vector)
+template <bool VALUED>
 __device__ __forceinline__ void tiled_gather(const int4 d, int W, unsigned cmask, const double *__restrict__ x, int xs,
                                              const unsigned (&w)[kTiledPer], double (&xv)[kTiledPer])
 {
   const double *xb = x + (int64_t)d.z * W * xs;
 #pragma unroll
   for (int q = 0; q < kTiledPer; ++q)
-    if (q * kTiledProd < d.y || q == 0) xv[q] = xb[(int64_t)(w[q] & cmask) * xs];
+    if (!VALUED || q * kTiledProd < d.y || q == 0) xv[q] = xb[(int64_t)(w[q] & cmask) * xs];
 }
 
 // products and packed words of one item into a stage buffer (entry i at spk[i + 1]; spk[0], spk[n + 1] guards)
@@ -335,50 +341,155 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
   for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
   const unsigned cmask = (1u << lcol_bits) - 1u;
   const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
-  const int4 none = make_int4(0, 0, 0, 0);  // an empty item: loads entry 0, contributes nothing
-#define FS_ITEM(i) ((i) < it1 ? items[(i)] : none)
+  const int4 none = make_int4(0, 0, 0, 0);
+  const int itl = it1 > it0 ? it1 - 1 : it0;  // descriptor reads outside the panel are clamped to its items ...
+  auto item_at = [&](int i) {
+    int4 d = items[i < it0 ? it0 : (i < itl ? i : itl)];
+    if (i < it0 || i >= it1) d.y = 0;          // ... and emptied: one entry is loaded and gathered, nothing is staged
+    return d;
+  };
+#define FS_ITEM(i) item_at(i)
   if (DEBUG && t == 0) {  // diagnostic build only: which XCD runs this panel, and when each item starts
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     dbg_xcc[p] = (int)(xcc & 0xf);
   }
+  // There is no separate prologue: the sweep starts three phases early on empty items with zeroed register sets
+  // (local column 0 of band 0 is a valid address), so the pipeline fills through the same code that keeps it full
+  // and the compiler sees one steady state of loads in flight at the loop's back edge.
   int4 dA = none, dB = none, dC = none, dD = none;
-  unsigned wA[kTiledPer], wB[kTiledPer], wC[kTiledPer], wD[kTiledPer];
-  double vA[kTiledPer], vB[kTiledPer], vC[kTiledPer], vD[kTiledPer];
-  double xA[kTiledPer], xB[kTiledPer], xC[kTiledPer], xD[kTiledPer];
-  if (producer) {
-    dA = FS_ITEM(it0); dB = FS_ITEM(it0 + 1); dC = FS_ITEM(it0 + 2);
-    tiled_load<VALUED, NT>(dA, tr, pk, vals, wA, vA);
-    tiled_load<VALUED, NT>(dB, tr, pk, vals, wB, vB);
-    tiled_load<VALUED, NT>(dC, tr, pk, vals, wC, vC);
-    tiled_gather(dA, W, cmask, x, xs, wA, xA);
-    tiled_gather(dB, W, cmask, x, xs, wB, xB);
-  }
+  unsigned wA[kTiledPer] = {}, wB[kTiledPer] = {}, wC[kTiledPer] = {}, wD[kTiledPer] = {};
+  double vA[kTiledPer] = {}, vB[kTiledPer] = {}, vC[kTiledPer] = {}, vD[kTiledPer] = {};
+  double xA[kTiledPer] = {}, xB[kTiledPer] = {}, xC[kTiledPer] = {}, xD[kTiledPer] = {};
   __syncthreads();  // ytile zeroed
   // phase IT: producers stage item IT (register set 0) into buffer IT&1, then issue the loads of IT+3
   // (set 3) and the gathers of IT+2 (set 2); consumers reduce item IT-1 from the other buffer.
 #define FS_PHASE(IT, D0, W0, V0, X0, D2, W2, X2, D3, W3, V3)                                   \
   if (producer) {                                                                              \
-    if (DEBUG && t == 0 && (IT) < it1) dbg_time[(IT)] = (long long)wall_clock64();             \
-    if ((IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
+    if (DEBUG && t == 0 && (IT) >= it0 && (IT) < it1) dbg_time[(IT)] = (long long)wall_clock64(); \
+    if ((IT) >= it0 && (IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
     D3 = FS_ITEM((IT) + 3);                                                                    \
     tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                                          \
-    tiled_gather(D2, W, cmask, x, xs, W2, X2);                                                 \
-  } else if ((IT) > it0) {                                                                     \
+    tiled_gather<VALUED>(D2, W, cmask, x, xs, W2, X2);                                                 \
+  } else if ((IT) > it0 && (IT) <= it1) {                                                      \
     tiled_reduce(ytile, sprod[((IT) - 1) & 1], spk[((IT) - 1) & 1], tr, items[(IT) - 1].y, lcol_bits); \
   }                                                                                            \
   __syncthreads();
-  for (int it = it0; it <= it1; it += 4) {
+  // whole rounds of four phases (no early exit: a loop body with one way through is what lets the compiler count
+  // the loads in flight); phases past the last item stage and reduce nothing
+  for (int it = it0 - 3; it <= it1; it += 4) {
     FS_PHASE(it, dA, wA, vA, xA, dC, wC, xC, dD, wD, vD)
-    if (it + 1 > it1) break;
     FS_PHASE(it + 1, dB, wB, vB, xB, dD, wD, xD, dA, wA, vA)
-    if (it + 2 > it1) break;
     FS_PHASE(it + 2, dC, wC, vC, xC, dA, wA, xA, dB, wB, vB)
-    if (it + 3 > it1) break;
     FS_PHASE(it + 3, dD, wD, vD, xD, dB, wB, xB, dC, wC, vC)
   }
 #undef FS_ITEM
 #undef FS_PHASE
+  for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// y = A x on a tiled copy whose bands are narrow enough for the band's slice of x to live in LDS
+// (W <= kLdsxCols): the north_star's "LDS staging of the dense x tile".  For matrices whose tiles are
+// dense enough (config 3: 10 M x 1 M, 64 per row -> 1 700 entries per 13 021 x 2 048 tile) loading the
+// slice costs less than gathering from L2 entry by entry: a slice is 128 full lines from L2, the tile's
+// gathers would be 1 700 separate requests.
+//
+// ONE 1024-thread workgroup per CU and row panel, y slice (<= 120 KiB) and two x slices in LDS, all 16
+// waves in the same role.  Phase IT = work item IT (<= 2048 entries of one tile, 2 per thread): gather x from
+// the LDS slice of the item's band, multiply, ds_add_f64 into the y slice.  Memory runs three phases ahead
+// in registers (four register sets rotating by name): in phase IT the entries and the x slice of item IT+3
+// are requested, the slice of item IT+1 is copied from registers to the other LDS buffer, and one barrier
+// ends the phase.  Sum order: band-major, inside an item by LDS atomics in arrival order (see the two-pass
+// kernels above for what that means).
+// ------------------------------------------------------------------------------------------
+constexpr int kLdsxPer = kTiledItem / kTiledBlock;    // entries per thread and item (2)
+constexpr int kLdsxXPer = kLdsxCols / kTiledBlock;    // x values per thread and slice (2)
+
+// Every load of a phase is unconditional and its result is not touched before the phase that needs it (addresses
+// are clamped here, lanes outside the slice are masked when the slice is published): a load under a branch, or a
+// select on its result, makes the compiler wait for it on the spot and the pipeline collapses.
+template <bool VALUED>
+__device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, const unsigned *__restrict__ pk,
+                                          const double *__restrict__ vals, const double *__restrict__ x, int xs,
+                                          unsigned (&w)[kLdsxPer], double (&v)[kLdsxPer], double (&xr)[kLdsxXPer])
+{
+  // the slice first: it is needed one phase before the entries and vmcnt retires in order
+  const int c0 = d.z * W;
+#pragma unroll
+  for (int q = 0; q < kLdsxXPer; ++q) {
+    const int lc = q * kTiledBlock + t;
+    const int c = c0 + lc;
+    xr[q] = x[(int64_t)(c < ncol ? c : ncol - 1) * xs];
+  }
+  const int last = d.y > 0 ? d.y - 1 : 0;
+#pragma unroll
+  for (int q = 0; q < kLdsxPer; ++q) {
+    const int pos = q * kTiledBlock + t;
+    const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
+    w[q] = __builtin_nontemporal_load(pk + e);
+    if (VALUED) v[q] = __builtin_nontemporal_load(vals + e);
+  }
+}
+
+template <bool VALUED>
+__global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
+    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
+    const int *__restrict__ item_ptr, const unsigned *__restrict__ pk, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
+{
+  __shared__ double ytile[kLdsxRows];
+  __shared__ double xsl[2][kLdsxCols];
+  const int t = threadIdx.x;
+  const int p = blockIdx.x;
+  const int row0 = panel_row[p];
+  const int nr = panel_row[p + 1] - row0;
+  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
+  const unsigned cmask = (1u << lcol_bits) - 1u;
+  const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
+  const int itl = it1 > it0 ? it1 - 1 : it0;   // descriptor reads outside the panel are clamped to its items ...
+  auto item = [&](int i) {
+    int4 d = items[i < it0 ? it0 : (i < itl ? i : itl)];
+    if (i < it0 || i >= it1) d.y = 0;           // ... and emptied: loads one entry and one slice, contributes nothing
+    return d;
+  };
+  // no separate prologue: the sweep starts three phases early on empty items (see spmv_tiled_kernel)
+  int4 dA = item(it0 - 3), dB = dA, dC = dA, dD = dA, dN = item(it0);
+  unsigned wA[kLdsxPer] = {}, wB[kLdsxPer] = {}, wC[kLdsxPer] = {}, wD[kLdsxPer] = {};
+  double vA[kLdsxPer] = {}, vB[kLdsxPer] = {}, vC[kLdsxPer] = {}, vD[kLdsxPer] = {};
+  double xA[kLdsxXPer] = {}, xB[kLdsxXPer] = {}, xC[kLdsxXPer] = {}, xD[kLdsxXPer] = {};
+#define FS_PUBLISH(BUF, D, X)                                                                      \
+  _Pragma("unroll") for (int q = 0; q < kLdsxXPer; ++q) {                                         \
+    const int lc = q * kTiledBlock + t;                                                           \
+    xsl[(BUF) & 1][lc] = (lc < W && D.z * W + lc < ncol) ? X[q] : 0.0;                            \
+  }
+  __syncthreads();   // ytile zeroed
+  // phase IT: request item IT+3 (set 3; its descriptor was fetched a phase ago) and the descriptor of IT+4, consume
+  // item IT (set 0) from slice buffer IT&1, publish the slice of item IT+1 (set 1) in the other buffer
+#define FS_PHASE(IT, D0, W0, V0, D1, X1, D3, W3, V3, X3)                                          \
+  D3 = dN;                                                                                        \
+  dN = item((IT) + 4);                                                                            \
+  ldsx_load<VALUED>(D3, t, W, ncol, pk, vals, x, xs, W3, V3, X3);                                 \
+  _Pragma("unroll") for (int q = 0; q < kLdsxPer; ++q) {                                          \
+    const int pos = q * kTiledBlock + t;                                                          \
+    if (pos < D0.y) {                                                                             \
+      double pr = xsl[(IT) & 1][W0[q] & cmask];                                                   \
+      if (VALUED) pr *= V0[q];                                                                    \
+      __hip_atomic_fetch_add(&ytile[W0[q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    }                                                                                             \
+  }                                                                                               \
+  FS_PUBLISH((IT) + 1, D1, X1)                                                                    \
+  __syncthreads();
+  // whole rounds of four phases, no early exit (phases past the last item add nothing: their items are empty)
+  for (int it = it0 - 3; it < it1; it += 4) {
+    FS_PHASE(it, dA, wA, vA, dB, xB, dD, wD, vD, xD)
+    FS_PHASE(it + 1, dB, wB, vB, dC, xC, dA, wA, vA, xA)
+    FS_PHASE(it + 2, dC, wC, vC, dD, xD, dB, wB, vB, xB)
+    FS_PHASE(it + 3, dD, wD, vD, dA, xA, dC, wC, vC, xC)
+  }
+#undef FS_PHASE
+#undef FS_PUBLISH
+  __syncthreads();
   for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
 }
 
@@ -617,18 +728,26 @@ __global__ __launch_bounds__(kBlock) void tiled_combine_kernel(int nrow, const i
   y[r * ys] = acc;
 }
 
-int launch_spmv_tiled(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys)
+int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs, int ys)
 {
-  const TiledCsr &T = *A.tiled;
   const bool nt = !(options().tiled_flags & 1);  // bit 0: cached (not nt) entry loads
   double *out = T.split ? T.yv : y;              // cut rows: virtual sums first, combined below
   const int os = T.split ? 1 : ys;
+  if (T.ldsx) {
+    if (A.vals)
+      hipLaunchKernelGGL(spmv_ldsx_kernel<true>, dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, A.ncol,
+                         T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os);
+    else
+      hipLaunchKernelGGL(spmv_ldsx_kernel<false>, dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, A.ncol,
+                         T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os);
+  } else {
 #define FS_TILED(V, N)                                                                                         \
   hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, \
                      T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os)
-  if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
-  else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
+    if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
+    else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
 #undef FS_TILED
+  }
   FS_HIP(hipGetLastError());
   if (T.split) {
     hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
@@ -690,8 +809,10 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
   // ask for storage-order sums
   if (A.binned && A.binned->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7))
     return launch_spmv_binned(A, y, x, s);
+  if (A.tiledx && A.tiledx->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8))
+    return launch_spmv_tiled(A, *A.tiledx, y, x, s);
   if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6))
-    return launch_spmv_tiled(A, y, x, s);
+    return launch_spmv_tiled(A, *A.tiled, y, x, s);
   if (o.spmv_kernel == 2) {
     const double avg = A.nrow ? (double)A.nnz / A.nrow : 0.0;
     int lg = o.strict_order ? 0 : ceil_log2((int)(avg < 1 ? 1 : (avg > 64 ? 64 : avg)));
@@ -745,10 +866,16 @@ int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream
       if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
     return FS_OK;
   }
+  if (k <= 2 && A.tiledx && A.tiledx->built && !options().strict_order && !options().reproducible &&
+      (options().spmv_kernel == 0 || options().spmv_kernel == 8)) {
+    for (int j = 0; j < k; ++j)
+      if (int rc = launch_spmv_tiled(A, *A.tiledx, Y + j, X + j, s, k, k)) return rc;
+    return FS_OK;
+  }
   if (k <= 2 && A.tiled && A.tiled->built && !options().strict_order &&
       (options().spmv_kernel == 0 || options().spmv_kernel == 6)) {
     for (int j = 0; j < k; ++j)
-      if (int rc = launch_spmv_tiled(A, Y + j, X + j, s, k, k)) return rc;
+      if (int rc = launch_spmv_tiled(A, *A.tiled, Y + j, X + j, s, k, k)) return rc;
     return FS_OK;
   }
   int lg = ceil_log2(k > 64 ? 64 : k);

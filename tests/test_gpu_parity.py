@@ -577,3 +577,118 @@ def test_two_pass_on_thousands_of_bands(hip):
         assert np.all(np.abs(y.cpu().numpy() - ref_s) <= TOL * np.maximum(scale, 1e-300)), chosen
         del A
     assert chosen[0] in ("two-pass", "tiled", "stream") and chosen[1] == "two-pass", chosen
+
+
+def test_reproducible_option_and_tuning_switches(hip):
+    """`reproducible` keeps the format builder off the two-pass copy and repeated runs are then bit-identical;
+    the pass-1 unroll switches of the two-pass kernels change nothing but speed (pattern-only + integer x: exact)"""
+    import torch
+    from libfastsparse_amd import capi
+    nrow, ncol, per = 600_000, 5_000_000, 16
+    rp, cc, vv = capi.synth_uniform(nrow, ncol, per, 0x77, valued=True)
+    x = torch.from_numpy(S.x_sin(ncol)).cuda()
+    y1 = torch.empty(nrow, dtype=torch.float64, device="cuda")
+    y2 = torch.empty_like(y1)
+    capi.set_option("reproducible", 1)
+    capi.set_option("binning", 2)          # even when asked for, the two-pass copy is not built under `reproducible`
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+        assert A.kernel_name() in ("tiled", "stream")
+        A.spmv(y1, x, capi.current_stream())
+        A.spmv(y2, x, capi.current_stream())
+        assert torch.equal(y1, y2)
+        del A
+    finally:
+        capi.set_option("reproducible", 0)
+        capi.set_option("binning", 1)
+    capi.set_option("binning", 2)
+    try:
+        P = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+        assert P.kernel_name() == "two-pass"
+        xi = torch.from_numpy(S.x_int(3, ncol)).cuda()
+        P.spmv(y1, xi, capi.current_stream())
+        for flags in (1, 2):
+            capi.set_option("bin_flags", flags)
+            P.spmv(y2, xi, capi.current_stream())
+            assert torch.equal(y1, y2), flags
+        # with `reproducible` switched on later, an existing two-pass copy is bypassed (streaming kernel)
+        capi.set_option("bin_flags", 0)
+        capi.set_option("reproducible", 1)
+        assert P.kernel_name() == "stream"
+        P.spmv(y2, xi, capi.current_stream())
+        assert torch.equal(y1, y2)
+    finally:
+        capi.set_option("bin_flags", 0)
+        capi.set_option("binning", 1)
+        capi.set_option("reproducible", 0)
+
+
+@pytest.mark.parametrize("geometry", [(64, 128, 0), (7, 33, 0), (300, 2048, 5), (0, 0, 0)])
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_lds_staged_kernel_vs_reference_golden(hip, case, geometry):
+    """the LDS-staged tiled kernel (x slice of every band in LDS), forced on, with small panels/bands so that every
+    case spans many tiles and work items, and with rows cut into virtual rows: every entry point of every golden case"""
+    from libfastsparse_amd import capi
+    capi.set_option("ldsx", 2)
+    capi.set_option("tile_rows", geometry[0])
+    capi.set_option("tile_cols", geometry[1])
+    capi.set_option("tile_split", geometry[2])
+    try:
+        gold = np.load(os.path.join(S.GOLDEN, case.name + ".npz"))
+        out = _cases.run_case(hip.HipDeviceBackend(), case, light=True)
+        _check(out, gold, case.name, exact=False)
+    finally:
+        capi.set_option("ldsx", 1)
+        capi.set_option("tile_rows", 0)
+        capi.set_option("tile_cols", 0)
+        capi.set_option("tile_split", 0)
+
+
+@pytest.mark.parametrize("valued", [False, True])
+def test_lds_staged_kernel_dense_tiles(hip, valued):
+    """a matrix with config 3's density (64 per row over 100 k columns: 49 bands of 2048, the last one partial),
+    ragged rows, the kernel forced and chosen by the builder's own measurement: every row against the oracle; SpMV,
+    two right-hand sides and the transposed product"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(23)
+    nrow, ncol = 400_000, 100_000
+    lens = rng.integers(40, 90, nrow)
+    lens[rng.uniform(size=nrow) < 0.05] = 0
+    lens[777] = 30_000
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    cc[:64] = ncol - 1
+    vv = rng.uniform(-1, 1, nnz) if valued else None
+    xs_, xi_ = S.x_sin(ncol), S.x_int(4, ncol)
+    ref_s, ref_i = O.csr_mul(nrow, rp, cc, vv, xs_), O.csr_mul(nrow, rp, cc, vv, xi_)
+    sc_s, sc_i = O.csr_abs_scale(nrow, rp, cc, vv, xs_), O.csr_abs_scale(nrow, rp, cc, vv, xi_)
+    chosen = []
+    for forced in (2, 1):
+        capi.set_option("ldsx", forced)
+        try:
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+        finally:
+            capi.set_option("ldsx", 1)
+        chosen.append(A.kernel_name())
+        y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        A.spmv(y, torch.from_numpy(xs_).cuda(), capi.current_stream())
+        assert np.all(np.abs(y.cpu().numpy() - ref_s) <= TOL * np.maximum(sc_s, 1e-300)), chosen
+        A.spmv(y, torch.from_numpy(xi_).cuda(), capi.current_stream())
+        if valued:
+            assert np.all(np.abs(y.cpu().numpy() - ref_i) <= TOL * np.maximum(sc_i, 1e-300)), chosen
+        else:
+            assert np.array_equal(y.cpu().numpy(), ref_i), chosen
+        if forced == 2:
+            X = S.X_sin(ncol, 2)
+            Y = torch.full((nrow, 2), -1.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y, torch.from_numpy(X).cuda(), 2, capi.current_stream())
+            Yref = O.csr_mul_n(nrow, rp, cc, vv, X, 2)
+            for j in range(2):
+                sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X[:, j]))
+                assert np.all(np.abs(Y.cpu().numpy()[:, j] - Yref[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
+        del A
+    assert chosen[0] == "lds-staged", chosen

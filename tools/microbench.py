@@ -71,10 +71,22 @@ def main():
                    timeit(lambda: torch.index_select(table, 0, idx), iters=5, warm=1))
             del idx
         del a
+    if "tiledab" in what:
+        # the tiled kernel alone on the config-2 shape, valued and pattern-only (A/B runs of kernel changes)
+        capi.set_option("tiling", 2)
+        for valued in (True, False):
+            rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002, valued=valued)
+            A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+            x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+            y = torch.empty(n, dtype=torch.float64, device="cuda")
+            report(out, f"c2_{'f64' if valued else 'pattern'}_{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            del A, rp, cc, vv
+        capi.set_option("tiling", args.tiling)
     if "bin" in what:
         # two-pass kernels against the tiled kernel on the config-2 shape (valued and pattern-only), k = 1, 2, A'
         capi.set_option("bin_rows", args.bin_rows)
         capi.set_option("tiling", 2)
+        capi.set_option("binning", 2)
         ncol = args.ncols[0] if args.ncols else n
         for valued in (True, False):
             rp, cc, vv = capi.synth_uniform(n, ncol, 16, 0x5EED0002, valued=valued)
@@ -98,6 +110,7 @@ def main():
                 del X, Y
             del A, rp, cc, vv
         capi.set_option("tiling", args.tiling)
+        capi.set_option("binning", 1)
     if "c2" in what:
         rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
         A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
@@ -135,6 +148,14 @@ def main():
         for kern, label in ((0, "auto:" + A.kernel_name()), (1, "stream_nt")):
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        capi.set_option("spmv_kernel", 0)
+        del A
+        for opt, label in (("ldsx", "lds_staged"), ("tiling", "tiled"), ("binning", "two_pass")):
+            capi.set_option(opt, 2)
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+            capi.set_option(opt, 1)
+            report(out, f"c3_bcsr_forced_{label}:{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            del A
         capi.set_option("spmv_kernel", 0)
     if "cols" in what:
         # how the product behaves as x shrinks (column count), rows and non-zeros as config 2
