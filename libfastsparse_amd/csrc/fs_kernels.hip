@@ -643,36 +643,64 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
     }
     b = lo;
   }
-  constexpr unsigned kPad = (unsigned)kBinCols | ((unsigned)kBinCols << 16);
   for (unsigned g = g0; g < g1; ++b) {
     const unsigned gb = band_ptr[b + 1] < g1 ? band_ptr[b + 1] : g1;   // end of this band's part of the share
     if (gb <= g) continue;                                               // empty band
     const int c0 = b * kBinCols;
     const int w = (ncol - c0 < kBinCols) ? ncol - c0 : kBinCols;
     __syncthreads();                                                     // everyone is done with the previous band
-    for (int i = t; i < kBinCols + 8; i += kBinBlock)
-      xband[i] = (i < w) ? __builtin_nontemporal_load(x + (int64_t)(c0 + i) * xs) : 0.0;
+    {
+      // 16 loads per thread in flight together (clamped addresses, masking afterwards: a select next to the load
+      // would make every one of them wait for itself); slots kBinCols .. kBinCols+7 are the zero padding points at
+      double r[kBinCols / kBinBlock];
+#pragma unroll
+      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+        const int i = j * kBinBlock + t;
+        r[j] = __builtin_nontemporal_load(x + (int64_t)(c0 + (i < w ? i : w - 1)) * xs);
+      }
+#pragma unroll
+      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+        const int i = j * kBinBlock + t;
+        xband[i] = (i < w) ? r[j] : 0.0;
+      }
+      if (t < 8) xband[kBinCols + t] = 0.0;
+    }
     __syncthreads();
     const int64_t e0 = (int64_t)g * kBinGroup, e1 = (int64_t)gb * kBinGroup;
-    // a lane takes 2 consecutive entries per step, so a wave's stores are 1 KiB of consecutive products; U steps in flight
-    for (int64_t o = e0 + 2 * t; o < e1; o += 2 * U * kBinBlock) {
+    // a lane takes 2 consecutive entries per step, so a wave's stores are 1 KiB of consecutive products; U steps in
+    // flight.  Whole rounds (every step of every lane inside the segment) are straight-line code: all loads, a
+    // scheduling barrier, then gathers and stores -- with a guard anywhere in it the compiler sinks the loads of a
+    // step behind that step's guard and the steps run one after the other.  The last, partial round is guarded.
+    constexpr int64_t kRound = 2 * U * kBinBlock;
+    int64_t o = e0 + 2 * t;
+    for (; o - 2 * t + kRound <= e1; o += kRound) {
       unsigned a[U], d[U];
       v2d v[U];
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         const int64_t e = o + (int64_t)k * 2 * kBinBlock;
-        const bool ok = e < e1;
-        a[k] = ok ? __builtin_nontemporal_load((const unsigned *)(lcol + e)) : kPad;
-        d[k] = ok ? __builtin_nontemporal_load(gdst + (e >> kBinGroupLog)) : 0u;
-        if (VALUED) v[k] = ok ? __builtin_nontemporal_load((const v2d *)(vals + e)) : v2d{0.0, 0.0};
+        a[k] = __builtin_nontemporal_load((const unsigned *)(lcol + e));
+        d[k] = __builtin_nontemporal_load(gdst + (e >> kBinGroupLog));
+        if (VALUED) v[k] = __builtin_nontemporal_load((const v2d *)(vals + e));
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         const int64_t e = o + (int64_t)k * 2 * kBinBlock;
         v2d p = {xband[a[k] & 0xffffu], xband[a[k] >> 16]};
         if (VALUED) { p.x *= v[k].x; p.y *= v[k].y; }
-        if (e < e1) __builtin_nontemporal_store(p, (v2d *)(prod + (int64_t)d[k] * kBinGroup + (e & (kBinGroup - 1))));
+        __builtin_nontemporal_store(p, (v2d *)(prod + (int64_t)d[k] * kBinGroup + (e & (kBinGroup - 1))));
       }
+    }
+    for (; o < e1; o += 2 * kBinBlock) {
+      const unsigned a = __builtin_nontemporal_load((const unsigned *)(lcol + o));
+      const unsigned d = __builtin_nontemporal_load(gdst + (o >> kBinGroupLog));
+      v2d p = {xband[a & 0xffffu], xband[a >> 16]};
+      if (VALUED) {
+        const v2d v = __builtin_nontemporal_load((const v2d *)(vals + o));
+        p.x *= v.x; p.y *= v.y;
+      }
+      __builtin_nontemporal_store(p, (v2d *)(prod + (int64_t)d * kBinGroup + (o & (kBinGroup - 1))));
     }
     g = gb;
   }
@@ -689,19 +717,39 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
   for (int i = t; i < nr; i += kBinBlock) ytile[i] = 0.0;
   __syncthreads();
   const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * kBinGroup, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * kBinGroup;
-  for (int64_t e = e0 + 8 * t; e < e1; e += 8 * kBinBlock) {   // 8 entries (64 bytes of products) per lane and step
-    const v4u a = __builtin_nontemporal_load((const v4u *)(lrow + e));
-    const v2d p0 = __builtin_nontemporal_load((const v2d *)(prod + e));
-    const v2d p1 = __builtin_nontemporal_load((const v2d *)(prod + e + 2));
-    const v2d p2 = __builtin_nontemporal_load((const v2d *)(prod + e + 4));
-    const v2d p3 = __builtin_nontemporal_load((const v2d *)(prod + e + 6));
+  // 8 entries (64 bytes of products) per lane and step, two steps in flight in whole rounds (straight-line code:
+  // see spmv_expand_kernel); the last, partial round is guarded
 #define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-    FS_ADD(a.x & 0xffffu, p0.x); FS_ADD(a.x >> 16, p0.y);
-    FS_ADD(a.y & 0xffffu, p1.x); FS_ADD(a.y >> 16, p1.y);
-    FS_ADD(a.z & 0xffffu, p2.x); FS_ADD(a.z >> 16, p2.y);
-    FS_ADD(a.w & 0xffffu, p3.x); FS_ADD(a.w >> 16, p3.y);
-#undef FS_ADD
+#define FS_ADD8(A, P)                                                  \
+  FS_ADD(A.x & 0xffffu, P[0].x); FS_ADD(A.x >> 16, P[0].y);            \
+  FS_ADD(A.y & 0xffffu, P[1].x); FS_ADD(A.y >> 16, P[1].y);            \
+  FS_ADD(A.z & 0xffffu, P[2].x); FS_ADD(A.z >> 16, P[2].y);            \
+  FS_ADD(A.w & 0xffffu, P[3].x); FS_ADD(A.w >> 16, P[3].y);
+  constexpr int64_t kRound = 16 * kBinBlock;
+  int64_t e = e0 + 8 * t;
+  for (; e - 8 * t + kRound <= e1; e += kRound) {
+    v4u a[2];
+    v2d p[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t ek = e + (int64_t)k * 8 * kBinBlock;
+      a[k] = __builtin_nontemporal_load((const v4u *)(lrow + ek));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[k][j] = __builtin_nontemporal_load((const v2d *)(prod + ek + 2 * j));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    FS_ADD8(a[0], p[0])
+    FS_ADD8(a[1], p[1])
   }
+  for (; e < e1; e += 8 * kBinBlock) {
+    const v4u a = __builtin_nontemporal_load((const v4u *)(lrow + e));
+    v2d p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_nontemporal_load((const v2d *)(prod + e + 2 * j));
+    FS_ADD8(a, p)
+  }
+#undef FS_ADD8
+#undef FS_ADD
   __syncthreads();
   for (int i = t; i < nr; i += kBinBlock) y[(int64_t)(r0 + i) * ys] = ytile[i];
 }
