@@ -353,6 +353,43 @@ static int max_row_len(const DeviceCsr &A, hipStream_t s, int *out)
   return FS_OK;
 }
 
+// LDS-staged kernel only: inside a work item the order of the entries is free (the kernel adds with LDS atomics), so
+// every item is rearranged round-robin over the residue classes of the local row mod 32 -- the 32 lanes of a
+// half-wave then add into 32 different bank pairs of the y slice.  Entry with class c and rank r inside its class goes
+// to position  sum_c' min(count[c'], r) + #{c' < c : count[c'] > r}.
+__global__ __launch_bounds__(256) void ldsx_reorder_kernel(const int4 *__restrict__ items, int lcol_bits,
+                                                          unsigned *__restrict__ pk, double *__restrict__ vals)
+{
+  __shared__ unsigned w[kTiledItem];
+  __shared__ double v[kTiledItem];
+  __shared__ unsigned short rk[kTiledItem];
+  __shared__ int cnt[32];
+  const int4 d = items[blockIdx.x];
+  const int n = d.y, t = threadIdx.x;
+  if (t < 32) cnt[t] = 0;
+  for (int i = t; i < n; i += 256) {
+    w[i] = pk[(int64_t)d.x + i];
+    if (vals) v[i] = vals[(int64_t)d.x + i];
+  }
+  __syncthreads();
+  // ranks inside a class follow the stored order (one thread per class walks the item: 32 x 2048 steps, once per matrix)
+  if (t < 32) {
+    int c = 0;
+    for (int i = 0; i < n; ++i)
+      if ((int)((w[i] >> lcol_bits) & 31u) == t) rk[i] = (unsigned short)c++;
+    cnt[t] = c;
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 256) {
+    const int c = (int)((w[i] >> lcol_bits) & 31u), r = rk[i];
+    int pos = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) pos += (cnt[k] < r ? cnt[k] : r) + ((k < c && cnt[k] > r) ? 1 : 0);
+    pk[(int64_t)d.x + pos] = w[i];
+    if (vals) vals[(int64_t)d.x + pos] = v[i];
+  }
+}
+
 static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool ldsx);
 
 // The tiled copies are optimisations: if building one fails (typically: not enough HBM for another copy) the
@@ -536,6 +573,11 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   FS_HIP(hipMalloc(&T->item_ptr, sizeof(int) * item_ptr.size()));
   if (!items.empty()) FS_HIP(hipMemcpy(T->items, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
+  if (ldsx && T->nitems > 0) {
+    hipLaunchKernelGGL(ldsx_reorder_kernel, dim3(T->nitems), dim3(256), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipStreamSynchronize(s));
+  }
   T->built = true;
   return FS_OK;
 }

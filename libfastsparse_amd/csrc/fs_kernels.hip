@@ -401,7 +401,10 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
 // in registers (four register sets rotating by name): in phase IT the entries and the x slice of item IT+3
 // are requested, the slice of item IT+1 is copied from registers to the other LDS buffer, and one barrier
 // ends the phase.  Sum order: band-major, inside an item by LDS atomics in arrival order (see the two-pass
-// kernels above for what that means).
+// kernels above for what that means).  Because the order inside an item is free, the format builder arranges every
+// item so that the 32 lanes of a half-wave add into 32 different LDS bank pairs (local row mod 32, round-robin over
+// the residue classes): ds_add_f64 on random rows runs at 2.97 lanes per clock, conflict-free at 6.9, and the adds
+// are the largest share of the LDS time (config 3: 1.07 -> 0.87 ms with perfectly conflict-free rows).
 // ------------------------------------------------------------------------------------------
 constexpr int kLdsxPer = kTiledItem / kTiledBlock;    // entries per thread and item (2)
 constexpr int kLdsxXPer = kLdsxCols / kTiledBlock;    // x values per thread and slice (2)

@@ -71,6 +71,39 @@ def main():
                    timeit(lambda: torch.index_select(table, 0, idx), iters=5, warm=1))
             del idx
         del a
+    if "hybrid" in what:
+        # does the gather-bound tiled kernel overlap with the HBM-bound two-pass pair?  rows split in two handles,
+        # one forced tiled, one forced two-pass, products launched on two streams
+        frac = args.bin_rows / 100.0 if args.bin_rows else 0.5
+        capi.set_option("bin_rows", 0)
+        n1 = int(n * frac)
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        rp2 = (rp[n1:] - rp[n1]).contiguous()
+        capi.set_option("tiling", 2)
+        A1 = capi.Matrix.from_csr(n1, n, rp[:n1 + 1].contiguous(), cc[:n1 * 16], vv[:n1 * 16], borrow=True)
+        capi.set_option("tiling", 1)
+        capi.set_option("binning", 2)
+        A2 = capi.Matrix.from_csr(n - n1, n, rp2, cc[n1 * 16:], vv[n1 * 16:], borrow=True)
+        capi.set_option("binning", 1)
+        print("kernels", A1.kernel_name(), A2.kernel_name(), flush=True)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        B = 12 * n * 16 + 4 * (n + 1) + 16 * n
+
+        def both():
+            ev = torch.cuda.Event()
+            ev.record()
+            s1.wait_event(ev)
+            s2.wait_event(ev)
+            A1.spmv(y[:n1], x, s1.cuda_stream)
+            A2.spmv(y[n1:], x, s2.cuda_stream)
+            torch.cuda.current_stream().wait_stream(s1)
+            torch.cuda.current_stream().wait_stream(s2)
+        report(out, f"c2_hybrid_tiled{frac:.2f}_two_pass_concurrent", B, timeit(both))
+        report(out, f"c2_hybrid_tiled_part_alone", B, timeit(lambda: A1.spmv(y[:n1], x, st)))
+        report(out, f"c2_hybrid_two_pass_part_alone", B, timeit(lambda: A2.spmv(y[n1:], x, st)))
+        del A1, A2
     if "tiledab" in what:
         # the tiled kernel alone on the config-2 shape, valued and pattern-only (A/B runs of kernel changes)
         capi.set_option("tiling", 2)
@@ -149,6 +182,13 @@ def main():
             capi.set_option("spmv_kernel", kern)
             report(out, f"c3_bcsr_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
         capi.set_option("spmv_kernel", 0)
+        t0 = time.time()
+        A.build_transpose(st)
+        torch.cuda.synchronize()
+        print("c3 transpose build s", time.time() - t0, "kernel", A.kernel_name(True), flush=True)
+        u = torch.randint(-1000, 1001, (nrow,), device="cuda").to(torch.float64)
+        z = torch.empty(ncol, dtype=torch.float64, device="cuda")
+        report(out, f"c3_bcsr_At_mul_B_auto:{A.kernel_name(True)}", A.algorithmic_bytes(), timeit(lambda: A.spmv(z, u, st, transposed=True)))
         del A
         for opt, label in (("ldsx", "lds_staged"), ("tiling", "tiled"), ("binning", "two_pass")):
             capi.set_option(opt, 2)
