@@ -256,10 +256,14 @@ def main():
 
     if rank == 0:
         traffic = None
-        kname = A.kernel_name()
-        klabel = {"two-pass": "fs::spmv_expand_kernel<valued> + fs::spmv_reduce_kernel (one product)",
-                  "tiled": "fs::spmv_tiled_kernel<valued>", "stream": "fs::spmv_stream_kernel<valued>"}.get(kname, kname)
-        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_%s.json" % kname.replace("-", "_"))
+        kname, kname_t = A.kernel_name(), A.kernel_name(True)
+        labels = {"two-pass": "fs::spmv_expand_kernel<valued> + fs::spmv_reduce_kernel (one product)",
+                  "tiled": "fs::spmv_tiled_kernel<valued>", "lds-staged": "fs::spmv_ldsx_kernel<valued>",
+                  "stream": "fs::spmv_stream_kernel<valued>"}
+        klabel = labels.get(kname, kname)
+        if kname_t != kname:   # the format builder's timed choice may differ between A and A' (they are within a few %)
+            klabel = "A: %s; A': %s" % (klabel, labels.get(kname_t, kname_t))
+        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_%s.json" % kname.replace("-", "_")) if kname_t == kname else ""
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
@@ -279,7 +283,9 @@ def main():
                        "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
                        "stream_read_GBs_measured": stream_gbs,
                        "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
-                       "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt)},
+                       "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt),
+                       "kernel_A": A.kernel_name(), "kernel_At": A.kernel_name(True),
+                       "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": A.candidate_ms(True)},
             "roofline": {"bound": "hbm", "kernel": klabel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,

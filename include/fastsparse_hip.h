@@ -55,9 +55,10 @@ const char *fs_last_error(void);
 int  fs_device_count(void);
 int  fs_set_device(int device);
 /* option names: "strict_order" (0/1: storage-order sums, bit-identical to the strict-IEEE CPU order for
- * arbitrary x), "spmv_kernel" (0 = auto, 1 streaming, 2 lanes-per-row, 6 tiled, 7 two-pass), "tiling" (0 never
- * build the L2-tiled copy, 1 auto, 2 always; read when a matrix is created), "tile_rows" / "tile_cols" (0 = auto),
- * "binning" (the same three values for the two-pass copy), "reproducible" (0/1, default 0: with 1 only kernels whose
+ * arbitrary x), "spmv_kernel" (0 = auto, 1 streaming, 2 lanes-per-row, 6 tiled, 7 two-pass, 8 LDS-staged
+ * tiled), "tiling" (0 never build the L2-tiled copy, 1 build it when the estimates do not rule it out and let the
+ * builder's timing of the candidates decide, 2 always; read when a matrix is created), "tile_rows" / "tile_cols"
+ * (0 = auto), "binning" and "ldsx" (the same three values for the two-pass copy and the LDS-staged tiled copy), "reproducible" (0/1, default 0: with 1 only kernels whose
  * sums are bit-identical from run to run are used -- the two-pass kernels add a row's terms with LDS atomics in
  * arrival order, so their last bits can differ between runs for non-integer data; read when a matrix is created
  * and at every product).
@@ -96,8 +97,12 @@ void fs_matrix_destroy(fs_matrix_t A);
 int  fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream);
 int  fs_matrix_has_transpose(fs_matrix_t A);
 /* which kernel fs_spmv (or fs_spmv_t) runs on this matrix under the current options: 1 chunk-streaming,
- * 2 lanes-per-row, 6 L2-tiled, 7 two-pass; the choice is made by the format builder when the matrix is created */
+ * 2 lanes-per-row, 6 L2-tiled, 7 two-pass, 8 LDS-staged tiled; the choice is made by the format builder when the matrix is created */
 int  fs_matrix_spmv_kernel(fs_matrix_t A, int transposed);
+/* what the format builder measured when it made that choice: ms per product (median of 5 runs on a zero vector) of
+ * [0] the chunk-streaming kernel, [1] the L2-tiled kernel, [2] the LDS-staged tiled kernel, [3] the two-pass pair;
+ * 0 for a candidate that was not built (ruled out by the estimates, or the matrix is small) */
+int  fs_matrix_candidate_ms(fs_matrix_t A, int transposed, float *ms4);
 int  fs_matrix_nrow(fs_matrix_t A);
 int  fs_matrix_ncol(fs_matrix_t A);
 int64_t fs_matrix_nnz(fs_matrix_t A);

@@ -18,7 +18,7 @@ _lib = None
 DEVICE_API = [
     "fs_version", "fs_last_error", "fs_device_count", "fs_set_device", "fs_set_option", "fs_get_option",
     "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
-    "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel",
+    "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel", "fs_matrix_candidate_ms",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
     "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all",
@@ -79,6 +79,7 @@ def lib():
     L.fs_matrix_build_transpose.argtypes = [vp, vp]
     L.fs_matrix_has_transpose.argtypes = [vp]
     L.fs_matrix_spmv_kernel.argtypes = [vp, C.c_int]
+    L.fs_matrix_candidate_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.fs_matrix_nrow.argtypes = [vp]
     L.fs_matrix_ncol.argtypes = [vp]
     L.fs_matrix_nnz.argtypes = [vp]
@@ -165,6 +166,12 @@ class Matrix:
         """the SpMV kernel the format builder chose for this matrix (under the current options)"""
         code = lib().fs_matrix_spmv_kernel(self.h, int(transposed))
         return {1: "stream", 2: "vector", 6: "tiled", 7: "two-pass", 8: "lds-staged"}.get(code, str(code))
+
+    def candidate_ms(self, transposed=False):
+        """ms per product the format builder measured for every candidate kernel (0 = not built)"""
+        out = (C.c_float * 4)()
+        check(lib().fs_matrix_candidate_ms(self.h, int(transposed), out), "fs_matrix_candidate_ms")
+        return dict(zip(("stream", "tiled", "lds-staged", "two-pass"), (round(float(v), 4) for v in out)))
 
     def build_transpose(self, stream=None):
         check(lib().fs_matrix_build_transpose(self.h, stream), "fs_matrix_build_transpose")

@@ -204,6 +204,14 @@ int fs_matrix_spmv_kernel(fs_matrix_t A, int transposed)
   return o.spmv_kernel == 2 ? 2 : 1;
 }
 
+int fs_matrix_candidate_ms(fs_matrix_t A, int transposed, float *ms4)
+{
+  if (!A || !ms4 || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  for (int i = 0; i < 4; ++i) ms4[i] = a.candidate_ms[i];
+  return FS_OK;
+}
+
 int fs_matrix_nrow(fs_matrix_t A) { return A ? A->a.nrow : FS_ERR_ARG; }
 int fs_matrix_ncol(fs_matrix_t A) { return A ? A->a.ncol : FS_ERR_ARG; }
 int64_t fs_matrix_nnz(fs_matrix_t A) { return A ? A->a.nnz : FS_ERR_ARG; }

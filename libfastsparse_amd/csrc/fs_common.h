@@ -38,6 +38,9 @@ struct DeviceCsr {
   TiledCsr *tiled = nullptr;  // optional L2-tiled copy (owned)
   TiledCsr *tiledx = nullptr; // optional copy in the same layout with the LDS-staged kernel's geometry (owned)
   BinnedCsr *binned = nullptr;  // optional two-pass copy (owned)
+  // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
+  // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
+  float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
 };
 
 // L2-tiled copy of a CSR for the column-band kernel (see DESIGN.md "spmv_tiled_kernel").

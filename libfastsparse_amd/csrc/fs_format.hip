@@ -860,6 +860,10 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc != FS_OK) return rc;
+  A.candidate_ms[0] = t_stream;
+  A.candidate_ms[1] = ht ? t_tiled : 0.f;
+  A.candidate_ms[2] = hx ? t_ldsx : 0.f;
+  A.candidate_ms[3] = hb ? t_bin : 0.f;
   float best = t_stream;
   if (t_tiled < best) best = t_tiled;
   if (t_ldsx < best) best = t_ldsx;
