@@ -439,9 +439,11 @@ def test_cbcsr_large_uses_cell_streaming(hip):
     assert np.array_equal(y.cpu().numpy(), ref)
 
 
-def test_tiled_auto_on_extreme_row_lengths(hip):
-    """automatic tiling on matrices the format builder has to cut up: one row holding almost everything, and a
-    heavy-tailed matrix with many empty rows; every row against the oracle (row-scaled bound), integer x exact"""
+def test_every_copy_on_extreme_distributions(hip):
+    """matrices the format builder has to cut up -- one row holding almost everything, a heavy-tailed matrix with many
+    empty rows, and a matrix whose entries sit in one column band, most of them in one column -- with the builder's own
+    choice and with each copy forced (two-pass, LDS-staged, L2-tiled): every row against the oracle (row-scaled
+    bound), integer x exact"""
     import torch
     from libfastsparse_amd import capi
     rng = np.random.default_rng(5)
@@ -462,18 +464,35 @@ def test_tiled_auto_on_extreme_row_lengths(hip):
     np.cumsum(l2, out=rp2[1:])
     rp2 = rp2.astype(np.int32)
     cc2 = rng.integers(0, ncol2, int(rp2[-1])).astype(np.int32)
-    for (nrow, nc, r_, c_, v_) in ((1000, ncol, rp, cc, vv), (n2, ncol2, rp2, cc2, None)):
-        A = capi.Matrix.from_csr(nrow, nc, r_, c_, v_)
-        y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
-        for x in (S.x_sin(nc), S.x_int(2, nc)):
-            A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
-            ref = O.csr_mul(nrow, r_, c_, v_, x)
-            got = y.cpu().numpy()
-            if v_ is None and np.all(x == np.round(x)):
-                assert np.array_equal(got, ref)
-            else:
-                scale = O.csr_abs_scale(nrow, r_, c_, v_, x)
-                assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300))
+    # (c) every entry in ONE column band and most of them in one column (a hot feature), 300 k rows
+    n3, ncol3 = 300_000, 1_000_000
+    l3 = rng.integers(8, 40, n3)
+    rp3 = np.zeros(n3 + 1, np.int64)
+    np.cumsum(l3, out=rp3[1:])
+    rp3 = rp3.astype(np.int32)
+    cc3 = (500_000 + rng.integers(0, 3000, int(rp3[-1]))).astype(np.int32)
+    cc3[rng.uniform(size=cc3.size) < 0.6] = 501_234
+    vv3 = rng.uniform(-1, 1, int(rp3[-1]))
+    for forced in (None, "binning", "ldsx", "tiling"):
+        for (nrow, nc, r_, c_, v_) in ((1000, ncol, rp, cc, vv), (n2, ncol2, rp2, cc2, None), (n3, ncol3, rp3, cc3, vv3)):
+            if forced:
+                capi.set_option(forced, 2)
+            try:
+                A = capi.Matrix.from_csr(nrow, nc, r_, c_, v_)
+            finally:
+                if forced:
+                    capi.set_option(forced, 1)
+            y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+            for x in (S.x_sin(nc), S.x_int(2, nc)):
+                A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
+                ref = O.csr_mul(nrow, r_, c_, v_, x)
+                got = y.cpu().numpy()
+                if v_ is None and np.all(x == np.round(x)):
+                    assert np.array_equal(got, ref), (forced, A.kernel_name())
+                else:
+                    scale = O.csr_abs_scale(nrow, r_, c_, v_, x)
+                    assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300)), (forced, A.kernel_name())
+            del A
 
 
 @pytest.mark.parametrize("bin_rows", [0, 64, 1000])
