@@ -76,6 +76,13 @@ struct TiledCsr {
   int *vfirst = nullptr;       // nrow + 1: first virtual row of every row (only when split > 0)
   double *yv = nullptr;        // nvrow: sums of the virtual rows, combined per row after the kernel
   int slots = 256;             // workgroups resident together (1 per CU)
+  // LDS-staged kernel only: a workgroup takes a CHUNK = a contiguous range of one panel's work items.  Normally a
+  // panel is one chunk; a panel that holds far more than its share of the entries (few, long rows; a monster row) is
+  // cut into several, whose y slices are then added up in HBM.  Rows are never cut into virtual rows here.
+  int nchunks = 0;
+  int *chunk_panel = nullptr;  // nchunks: panel of the chunk; bit 31 set when the panel has more than one chunk
+  int *chunk_item = nullptr;   // nchunks + 1: first work item of every chunk
+  bool shared = false;         // some panel has more than one chunk: products go through the zeroed scratch vector yv
 };
 
 // Two-pass copy of a CSR ("expand, then reduce"; see DESIGN.md "spmv_expand_kernel / spmv_reduce_kernel").

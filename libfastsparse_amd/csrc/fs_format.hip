@@ -34,7 +34,7 @@ struct Scratch {
 static void free_tiled_slot(TiledCsr *&T)
 {
   if (!T) return;
-  void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv};
+  void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item};
   for (void *q : owned)
     if (q) (void)hipFree(q);
   delete T;
@@ -440,7 +440,7 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   int max_len = 0;
   if (int rc = max_row_len(A, s, &max_len)) return rc;
   int split = o.tile_split > 0 ? o.tile_split : 256;
-  const bool virt = max_len > split;
+  const bool virt = !ldsx && max_len > split;   // the LDS-staged kernel balances by chunks of work items instead
   TiledCsr *T = new TiledCsr();
   slot = T;
   T->ldsx = ldsx;
@@ -462,6 +462,8 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     const int64_t g = ((int64_t)nvrow + (int64_t)slots * rows_max - 1) / ((int64_t)slots * rows_max);
     R = (int)(((int64_t)nvrow + slots * g - 1) / (slots * g));
     if (R < 256) R = nvrow < 256 ? nvrow : 256;
+    // few rows: full-height panels (dense tiles), cut into chunks below so that every CU still has work
+    if (ldsx && (int64_t)nvrow < (int64_t)slots * rows_max / 2) R = rows_max;
   }
   if (R > rows_max) R = rows_max;
   std::vector<int> panel_row;
@@ -577,6 +579,54 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     hipLaunchKernelGGL(ldsx_reorder_kernel, dim3(T->nitems), dim3(256), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
     FS_HIP(hipGetLastError());
     FS_HIP(hipStreamSynchronize(s));
+  }
+  if (ldsx) {
+    // chunks: exactly `total` of them (a whole number of generations of resident workgroups: 264 equal chunks on 256
+    // CUs take as long as 512) with entry counts as equal as the panels allow; a panel gets its share, at least one,
+    // cut at item boundaries.  Measured on config 3 transposed (66 panels): 1 / 2 / 4 / 8 chunks per CU 3.7 / 3.7 /
+    // 2.3 / 1.9 ms with rounded shares.
+    const int64_t total = (P >= slots) ? P : 8 * (int64_t)slots;
+    std::vector<int64_t> nnz_p((size_t)P, 0);
+    std::vector<int> k_p((size_t)P, 1);
+    std::vector<std::pair<double, int>> frac;
+    int64_t given = 0;
+    for (int p = 0; p < P; ++p) {
+      for (int i = item_ptr[p]; i < item_ptr[p + 1]; ++i) nnz_p[p] += items[i].y;
+      const double share = (double)nnz_p[p] * (double)total / (double)A.nnz;
+      const int cap = item_ptr[p + 1] - item_ptr[p] > 0 ? item_ptr[p + 1] - item_ptr[p] : 1;
+      int k = (int)share;
+      if (k < 1) k = 1;
+      if (k > cap) k = cap;
+      k_p[p] = k;
+      given += k;
+      if (k < cap) frac.push_back(std::make_pair(share - (double)(int)share, p));
+    }
+    std::sort(frac.begin(), frac.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) {
+      return a.first > b.first || (a.first == b.first && a.second < b.second);
+    });
+    for (size_t f = 0; f < frac.size() && given < total; ++f, ++given) ++k_p[frac[f].second];
+    std::vector<int> chunk_panel, chunk_item;
+    for (int p = 0; p < P; ++p) {
+      const int i0 = item_ptr[p], i1 = item_ptr[p + 1], k = k_p[p];
+      const int flag = k > 1 ? (int)0x80000000u : 0;
+      if (k > 1) T->shared = true;
+      int i = i0;
+      int64_t done = 0;
+      for (int c = 0; c < k; ++c) {
+        chunk_panel.push_back(p | flag);
+        chunk_item.push_back(i);
+        const int64_t goal = nnz_p[p] * (c + 1) / k;
+        while (i < i1 && (done < goal || c == k - 1)) done += items[i++].y;
+      }
+    }
+    chunk_item.push_back((int)items.size());
+    T->nchunks = (int)chunk_panel.size();
+    FS_HIP(hipMalloc(&T->chunk_panel, sizeof(int) * (chunk_panel.size() ? chunk_panel.size() : 1)));
+    FS_HIP(hipMalloc(&T->chunk_item, sizeof(int) * chunk_item.size()));
+    if (!chunk_panel.empty())
+      FS_HIP(hipMemcpy(T->chunk_panel, chunk_panel.data(), sizeof(int) * chunk_panel.size(), hipMemcpyHostToDevice));
+    FS_HIP(hipMemcpy(T->chunk_item, chunk_item.data(), sizeof(int) * chunk_item.size(), hipMemcpyHostToDevice));
+    if (T->shared && !T->yv) FS_HIP(hipMalloc(&T->yv, sizeof(double) * (size_t)A.nrow));
   }
   T->built = true;
   return FS_OK;

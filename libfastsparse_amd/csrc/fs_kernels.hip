@@ -342,9 +342,12 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
   const unsigned cmask = (1u << lcol_bits) - 1u;
   const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
   const int4 none = make_int4(0, 0, 0, 0);
-  const int itl = it1 > it0 ? it1 - 1 : it0;  // descriptor reads outside the panel are clamped to its items ...
+  // descriptor reads outside the panel are clamped to its items (an empty panel reads the item in front of it; the
+  // array always holds at least one) ...
+  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
+  const int itf = it1 > it0 ? it0 : itl;
   auto item_at = [&](int i) {
-    int4 d = items[i < it0 ? it0 : (i < itl ? i : itl)];
+    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
     if (i < it0 || i >= it1) d.y = 0;          // ... and emptied: one entry is loaded and gathered, nothing is staged
     return d;
   };
@@ -435,24 +438,32 @@ __device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, 
   }
 }
 
+// A workgroup takes one CHUNK: a contiguous range of the work items of one panel (normally the whole panel; panels
+// that hold far more than their share of the entries are cut into several chunks, whose y slices are added up in
+// HBM with atomics -- the launcher then routes the output through a zeroed scratch vector).
 template <bool VALUED>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
-    const int *__restrict__ item_ptr, const unsigned *__restrict__ pk, const double *__restrict__ vals,
-    const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
+    const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
+    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
 {
   __shared__ double ytile[kLdsxRows];
   __shared__ double xsl[2][kLdsxCols];
   const int t = threadIdx.x;
-  const int p = blockIdx.x;
+  const int cp = chunk_panel[blockIdx.x];
+  const int p = cp & 0x7fffffff;
+  const bool shared = cp < 0;                  // other chunks add into the same rows
   const int row0 = panel_row[p];
   const int nr = panel_row[p + 1] - row0;
   for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
   const unsigned cmask = (1u << lcol_bits) - 1u;
-  const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
-  const int itl = it1 > it0 ? it1 - 1 : it0;   // descriptor reads outside the panel are clamped to its items ...
+  const int it0 = chunk_item[blockIdx.x], it1 = chunk_item[blockIdx.x + 1];
+  // descriptor reads outside the chunk are clamped to its items (an empty chunk reads the item in front of it; the
+  // array always holds at least one) ...
+  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
+  const int itf = it1 > it0 ? it0 : itl;
   auto item = [&](int i) {
-    int4 d = items[i < it0 ? it0 : (i < itl ? i : itl)];
+    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
     if (i < it0 || i >= it1) d.y = 0;           // ... and emptied: loads one entry and one slice, contributes nothing
     return d;
   };
@@ -493,7 +504,18 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
 #undef FS_PHASE
 #undef FS_PUBLISH
   __syncthreads();
-  for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+  if (shared) {
+    for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
+  } else {
+    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+  }
+}
+
+// y[r * ys] = v[r] (output of a product that went through a contiguous scratch vector)
+__global__ __launch_bounds__(kBlock) void strided_copy_kernel(int n, const double *__restrict__ v, double *__restrict__ y, int ys)
+{
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < n) y[r * ys] = v[r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -785,12 +807,27 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
   double *out = T.split ? T.yv : y;              // cut rows: virtual sums first, combined below
   const int os = T.split ? 1 : ys;
   if (T.ldsx) {
-    if (A.vals)
-      hipLaunchKernelGGL(spmv_ldsx_kernel<true>, dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, A.ncol,
-                         T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os);
-    else
-      hipLaunchKernelGGL(spmv_ldsx_kernel<false>, dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, A.ncol,
-                         T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os);
+    // chunks of one panel add into the same rows: the output then goes through the zeroed scratch vector
+    if (T.shared) {
+      FS_HIP(hipMemsetAsync(T.yv, 0, sizeof(double) * (size_t)A.nrow, s));
+      out = T.yv;
+    }
+    const int ost = T.shared ? 1 : ys;
+    if (T.nchunks > 0) {
+      if (A.vals)
+        hipLaunchKernelGGL(spmv_ldsx_kernel<true>, dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits,
+                           A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost);
+      else
+        hipLaunchKernelGGL(spmv_ldsx_kernel<false>, dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits,
+                           A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost);
+      FS_HIP(hipGetLastError());
+    }
+    if (T.shared) {
+      hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                         A.nrow, T.yv, y, ys);
+      FS_HIP(hipGetLastError());
+    }
+    return FS_OK;   // rows are never cut for this kernel: no combine pass
   } else {
 #define FS_TILED(V, N)                                                                                         \
   hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, \

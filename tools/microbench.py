@@ -185,7 +185,8 @@ def main():
         t0 = time.time()
         A.build_transpose(st)
         torch.cuda.synchronize()
-        print("c3 transpose build s", time.time() - t0, "kernel", A.kernel_name(True), flush=True)
+        print("c3 transpose build s", time.time() - t0, "kernel", A.kernel_name(True), "builder timed", A.candidate_ms(True),
+              "forward", A.candidate_ms(), flush=True)
         u = torch.randint(-1000, 1001, (nrow,), device="cuda").to(torch.float64)
         z = torch.empty(ncol, dtype=torch.float64, device="cuda")
         report(out, f"c3_bcsr_At_mul_B_auto:{A.kernel_name(True)}", A.algorithmic_bytes(), timeit(lambda: A.spmv(z, u, st, transposed=True)))
