@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -124,10 +126,26 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
   FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
   if (!allow_tiled) return FS_OK;
+  // FS_TRACE_BUILD=1 prints where the one-time format work goes
+  static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
+  auto now = [&] { (void)hipStreamSynchronize(s); return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t0 = trace ? now() : std::chrono::steady_clock::time_point();
   if (int rc = build_binned(A, s)) return rc;
+  const auto t1 = trace ? now() : t0;
   if (int rc = build_tiled(A, s)) return rc;
+  const auto t2 = trace ? now() : t0;
   if (int rc = build_tiledx(A, s)) return rc;
-  return choose_copy(A, s);
+  const auto t3 = trace ? now() : t0;
+  const int rc = choose_copy(A, s);
+  if (trace) {
+    const auto t4 = now();
+    fprintf(stderr, "[fastsparse] %d x %d, %lld nnz: two-pass copy %.1f ms, tiled copy %.1f ms, LDS-staged copy %.1f ms, "
+            "timed choice %.1f ms\n", A.nrow, A.ncol, (long long)A.nnz, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
+  }
+  return rc;
 }
 
 // ---- stable COO -> CSR -----------------------------------------------------------------------
