@@ -336,6 +336,16 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
     if (!rc && hipMalloc(&M->cell_sums, sizeof(double) * (ncell ? ncell : 1)) != hipSuccess) rc = FS_ERR_HIP;
     M->use_cells = !rc;
   }
+  // large enough for the copies of the general SpMV path to pay: a plain CSR of the same entries (an optimisation:
+  // if it cannot be built the cell path above stays)
+  if (!rc && M->nnz >= (4 << 20) && ncell < (size_t)0x7fffffff) {
+    if (fs::cbcsr_rows_device(M->rows, nrow, ncol, nblocks, M->nnz, M->row_ptr, M->cols, nullptr) == FS_OK) {
+      M->use_rows = true;
+    } else {
+      fs::free_csr(M->rows);
+      (void)hipGetLastError();
+    }
+  }
   if (rc) { fs_cbcsr_destroy(M); return nullptr; }
   return M;
 }
@@ -344,6 +354,7 @@ void fs_cbcsr_destroy(fs_cbcsr_t A)
 {
   if (!A) return;
   fs::free_csr(A->cells);        // borrowed arrays: frees the schedule only
+  fs::free_csr(A->rows);
   if (A->cell_sums) (void)hipFree(A->cell_sums);
   if (A->row_ptr) (void)hipFree(A->row_ptr);
   if (A->cols) (void)hipFree(A->cols);

@@ -143,6 +143,10 @@ struct fs_cbcsr_s {
   fs::DeviceCsr cells;
   double *cell_sums = nullptr;  // nblocks*nrow
   bool use_cells = false;
+  // larger still: the same entries as an ordinary pattern-only CSR (rows keep the block-by-block order), so that the
+  // product runs on whatever kernel the format builder measures fastest (the LDS-staged kernel for dense tiles)
+  fs::DeviceCsr rows;
+  bool use_rows = false;
 };
 
 namespace fs {
@@ -194,6 +198,8 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,
                       const int *cols_dev, const double *vals_dev, hipStream_t s);
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s);
+int cbcsr_rows_device(DeviceCsr &out, int nrow, int ncol, int nblocks, int64_t nnz, const int *cell_ptr_dev,
+                      const int *cols_dev, hipStream_t s);
 void free_csr(DeviceCsr &A);
 
 }  // namespace fs

@@ -230,6 +230,32 @@ __global__ void expand_rows_kernel(int nrow, int64_t nnz, const int *__restrict_
   rows[i] = lo;
 }
 
+// ---- column-blocked binary CSR -> plain pattern-only CSR --------------------------------------------------------
+// cell = block * nrow + row, cells stored block-major: a stable sort of the entries by row leaves every row's entries
+// block by block and, inside a cell, in storage order -- the order in which the reference's one-thread loop adds them
+// (cbcsr.h:88-97).  The plain CSR then goes through the ordinary format builder (copies, timed choice).
+__global__ void cell_rows_kernel(int ncell, int nrow, int64_t nnz, const int *__restrict__ cell_ptr, int *__restrict__ rows)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  int lo = 0, hi = ncell;  // last cell with cell_ptr[cell] <= i
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    if ((int64_t)cell_ptr[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  rows[i] = lo % nrow;
+}
+
+int cbcsr_rows_device(DeviceCsr &out, int nrow, int ncol, int nblocks, int64_t nnz, const int *cell_ptr_dev,
+                      const int *cols_dev, hipStream_t s)
+{
+  Scratch<int> rows;
+  FS_HIP(rows.alloc((size_t)nnz));
+  hipLaunchKernelGGL(cell_rows_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nblocks * nrow, nrow, nnz, cell_ptr_dev, rows.p);
+  FS_HIP(hipGetLastError());
+  return coo_to_csr_device(out, nrow, ncol, nnz, rows.p, cols_dev, nullptr, s);
+}
+
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
 {
   Scratch<int> rows;

@@ -993,6 +993,12 @@ __global__ __launch_bounds__(kBlock) void cbcsr_combine_kernel(int nrow, int nbl
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
+  // largest matrices: the plain CSR of the same entries on the general SpMV path (spmv_kernel 4 / 5 / 9 force the
+  // column-block kernels below)
+  // (not under strict_order: the reference adds cell sums, not one flat sum per row)
+  if (A.use_rows && !options().strict_order && options().spmv_kernel != 4 && options().spmv_kernel != 5 &&
+      options().spmv_kernel != 9)
+    return launch_spmv(A.rows, y, x, s);
   // large matrices: cell sums by the chunk-streaming kernel over the (block, row) cells, then one pass that
   // adds each row's cells block by block.  spmv_kernel 4 / 5 force the one-thread-per-row kernels below.
   if (A.use_cells && options().spmv_kernel != 4 && options().spmv_kernel != 5) {

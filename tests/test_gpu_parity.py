@@ -439,6 +439,41 @@ def test_cbcsr_large_uses_cell_streaming(hip):
     assert np.array_equal(y.cpu().numpy(), ref)
 
 
+def test_cbcsr_largest_runs_on_the_general_path(hip):
+    """>= 4 M entries: the column-blocked matrix is also kept as a plain pattern-only CSR (rows in block-by-block
+    order) and the product runs on the kernel the format builder chose; equals the cell-streaming path (mode 9) and the
+    one-thread-per-row kernel bit for bit with integer x, the oracle within the fp64 bar, and under strict_order the
+    oracle's one-thread order bit for bit (cell path)"""
+    import torch
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    nrow, ncol, per, cbs = 400_000, 250_000, 24, 65536
+    rp, cc, _ = pysynth.uniform(nrow, ncol, per, 78, valued=False)
+    rows = np.repeat(np.arange(nrow, dtype=np.int32), per)
+    nb, crp, ccc = O.coo_to_cbcsr(cbs, nrow, ncol, rows, cc)
+    m = capi.ColBlockMatrix(nrow, ncol, nb, cbs, torch.from_numpy(crp).cuda(), torch.from_numpy(ccc).cuda())
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    xi = S.x_int(3, ncol)
+    ref = O.cbcsr_mul(nrow, nb, crp, ccc, xi)
+    for mode in (0, 9, 5):
+        capi.set_option("spmv_kernel", mode)
+        try:
+            m.spmv(y, torch.from_numpy(xi).cuda(), capi.current_stream())
+        finally:
+            capi.set_option("spmv_kernel", 0)
+        assert np.array_equal(y.cpu().numpy(), ref), mode
+    xs = S.x_sin(ncol)
+    ref = O.cbcsr_mul(nrow, nb, crp, ccc, xs)
+    m.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+    assert np.max(np.abs(y.cpu().numpy() - ref)) <= TOL * per * 1.0
+    capi.set_option("strict_order", 1)
+    try:
+        m.spmv(y, torch.from_numpy(xs).cuda(), capi.current_stream())
+    finally:
+        capi.set_option("strict_order", 0)
+    assert np.array_equal(y.cpu().numpy(), ref)
+
+
 def test_every_copy_on_extreme_distributions(hip):
     """matrices the format builder has to cut up -- one row holding almost everything, a heavy-tailed matrix with many
     empty rows, and a matrix whose entries sit in one column band, most of them in one column -- with the builder's own

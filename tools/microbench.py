@@ -239,7 +239,7 @@ def main():
         x = torch.randint(-1000, 1001, (nc,), device="cuda").to(torch.float64)
         y = torch.empty(nr, dtype=torch.float64, device="cuda")
         B = 4 * len(cc) + 4 * (K.nblocks * nr + 1) + 8 * nr + 8 * nc
-        for mode, label in ((0, "cells_streamed"), (5, "thread_per_row"), (4, "thread_per_row_lds_x")):
+        for mode, label in ((0, "general_path"), (9, "cells_streamed"), (5, "thread_per_row"), (4, "thread_per_row_lds_x")):
             capi.set_option("spmv_kernel", mode)
             report(out, f"cbcsr_2Mx1M_64_{label}", B, timeit(lambda: m.spmv(y, x, st), iters=5, warm=1))
         capi.set_option("spmv_kernel", 0)
