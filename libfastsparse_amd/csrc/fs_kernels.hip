@@ -550,42 +550,53 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(int nrow, int lg, c
 // KP (col,val) pairs with one coalesced load and broadcasts them with shuffles; each term is a
 // contiguous 8k-byte read of X row cols[i] -- the whole group reads one X row per step.
 // ------------------------------------------------------------------------------------------
-template <bool VALUED>
-__global__ __launch_bounds__(kBlock) void spmm_kernel(int nrow, int k, int lg, const int *__restrict__ row_ptr,
+template <bool VALUED, int LG>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(int nrow, int k, const int *__restrict__ row_ptr,
                                                      const int *__restrict__ cols,
                                                      const double *__restrict__ vals,
                                                      const double *__restrict__ X, double *__restrict__ Y)
 {
-  const int KP = 1 << lg;
-  const int gpb = kBlock >> lg;
+  constexpr int KP = 1 << LG;                    // lanes per row = output columns handled together
+  constexpr int EPL = LG < 3 ? (8 >> LG) : 1;    // entries per lane and step: a step always covers >= 8 entries
+  constexpr int EB = KP * EPL;                   // entries per step
+  constexpr int gpb = kBlock >> LG;
   const int j = threadIdx.x & (KP - 1);
-  const int64_t row = (int64_t)blockIdx.x * gpb + (threadIdx.x >> lg);
+  const int64_t row = (int64_t)blockIdx.x * gpb + (threadIdx.x >> LG);
   if (row >= nrow) return;
   const int a = row_ptr[row], b = row_ptr[row + 1];
   for (int j0 = 0; j0 < k; j0 += KP) {
     const int col = j0 + j;
     const bool act = col < k;
+    const int colc = act ? col : k - 1;          // lanes past the last column read a valid address and store nothing
     double acc = 0.0;
-    for (int base = a; base < b; base += KP) {
-      int myc = 0;
-      double myv = 0.0;
-      if (base + j < b) {
-        myc = cols[base + j];
-        if (VALUED) myv = vals[base + j];
+    for (int base = a; base < b; base += EB) {
+      // the step's (column, value) pairs, spread over the row's lanes; positions past the row's end re-read its last
+      // entry so that every load below is unconditional (no load sits behind a branch: see spmv_tiled_kernel)
+      int myc[EPL];
+      double myv[EPL];
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) {
+        const int e = base + q * KP + j;
+        const int ec = e < b ? e : b - 1;
+        myc[q] = cols[ec];
+        if (VALUED) myv[q] = vals[ec];
       }
-      const int n = (b - base < KP) ? b - base : KP;
-      for (int i0 = 0; i0 < n; i0 += 8) {
-        double xv[8], wv[8];
+      const int n = (b - base < EB) ? b - base : EB;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u;
-          const int cc = __shfl(myc, i & (KP - 1), KP);
-          if (VALUED) wv[u] = __shfl(myv, i & (KP - 1), KP);
-          xv[u] = (act && i < n) ? X[(int64_t)cc * k + col] : 0.0;
+      for (int i0 = 0; i0 < EB; i0 += 8) {
+        if (i0 < n) {
+          double xv[8], wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u;                // entry i of the step lives in lane i % KP, register i / KP
+            const int cc = __shfl(myc[(i / KP) % EPL], i & (KP - 1), KP);
+            if (VALUED) wv[u] = __shfl(myv[(i / KP) % EPL], i & (KP - 1), KP);
+            xv[u] = X[(int64_t)cc * k + colc];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (i0 + u < n) acc += VALUED ? xv[u] * wv[u] : xv[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (i0 + u < n) acc += VALUED ? xv[u] * wv[u] : xv[u];
       }
     }
     if (act) Y[row * k + col] = acc;
@@ -948,7 +959,8 @@ int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream
   // two right-hand sides (the block-CG case, bsbm_A_mul_B2 / bcsr_A_mul_B2) on a matrix with an L2-tiled copy:
   // one tiled sweep per column of the
   // row-major X / Y (strided gathers and stores) beats the row kernel, whose every X-row gather misses L2
-  if (k <= 2 && A.binned && A.binned->built && !options().strict_order && !options().reproducible &&
+  // (three sweeps of the two-pass pair: 3.0 ms on config 2 against 3.8 ms for the row kernel; four: 4.0 against 3.5)
+  if (k <= 3 && A.binned && A.binned->built && !options().strict_order && !options().reproducible &&
       (options().spmv_kernel == 0 || options().spmv_kernel == 7)) {
     for (int j = 0; j < k; ++j)
       if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
@@ -966,15 +978,20 @@ int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream
       if (int rc = launch_spmv_tiled(A, *A.tiled, Y + j, X + j, s, k, k)) return rc;
     return FS_OK;
   }
-  int lg = ceil_log2(k > 64 ? 64 : k);
+  const int lg = ceil_log2(k > 64 ? 64 : k);
   const int gpb = kBlock >> lg;
   const unsigned grid = (unsigned)(((int64_t)A.nrow + gpb - 1) / gpb);
-  if (A.vals)
-    hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, k, lg, A.row_ptr, A.cols, A.vals, X,
-                       Y);
-  else
-    hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, k, lg, A.row_ptr, A.cols, A.vals, X,
-                       Y);
+#define FS_SPMM(V, L) \
+  hipLaunchKernelGGL((spmm_kernel<V, L>), dim3(grid), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y)
+#define FS_SPMM_LG(V)                                                                                   \
+  switch (lg) {                                                                                         \
+    case 0: FS_SPMM(V, 0); break; case 1: FS_SPMM(V, 1); break; case 2: FS_SPMM(V, 2); break;           \
+    case 3: FS_SPMM(V, 3); break; case 4: FS_SPMM(V, 4); break; case 5: FS_SPMM(V, 5); break;           \
+    default: FS_SPMM(V, 6); break;                                                                      \
+  }
+  if (A.vals) { FS_SPMM_LG(true) } else { FS_SPMM_LG(false) }
+#undef FS_SPMM_LG
+#undef FS_SPMM
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
