@@ -746,3 +746,73 @@ def test_lds_staged_kernel_dense_tiles(hip, valued):
                 assert np.all(np.abs(Y.cpu().numpy()[:, j] - Yref[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
         del A
     assert chosen[0] == "lds-staged", chosen
+
+
+def test_fuzz_every_forced_copy_small_shapes(hip):
+    """seeded fuzz over shapes (1 x 1 up to a few thousand x tens of thousands, empty rows, a long row, duplicates),
+    forced copies and geometry overrides: A x, A' u and a two-column product of every kernel against the oracle"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(20261004)
+    opts = ("binning", "ldsx", "tiling", None)
+    try:
+        for trial in range(48):
+            nrow = int(rng.choice([1, 2, 17, 300, 1500, 5000]))
+            ncol = int(rng.choice([1, 3, 64, 900, 20000, 40000]))
+            maxlen = int(rng.choice([1, 4, 30, 200]))
+            lens = rng.integers(0, maxlen + 1, nrow)
+            if rng.uniform() < 0.5:
+                lens[rng.uniform(size=nrow) < 0.3] = 0
+            if rng.uniform() < 0.3:
+                lens[int(rng.integers(0, nrow))] = int(rng.integers(1000, 6000))
+            rp = np.zeros(nrow + 1, np.int64)
+            np.cumsum(lens, out=rp[1:])
+            rp = rp.astype(np.int32)
+            nnz = int(rp[-1])
+            cc = rng.integers(0, ncol, nnz).astype(np.int32)
+            valued = bool(rng.uniform() < 0.5)
+            vv = rng.uniform(-1, 1, nnz) if valued else None
+            forced = opts[trial % 4]
+            geo = {"tile_rows": int(rng.choice([0, 7, 64, 300])), "tile_cols": int(rng.choice([0, 33, 128, 2048])),
+                   "bin_rows": int(rng.choice([0, 64, 1000])), "tile_split": int(rng.choice([0, 5, 37]))}
+            for k_, v_ in geo.items():
+                capi.set_option(k_, v_)
+            if forced:
+                capi.set_option(forced, 2)
+            try:
+                A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+                A.build_transpose(capi.current_stream())
+            finally:
+                if forced:
+                    capi.set_option(forced, 1)
+            what = (trial, nrow, ncol, nnz, valued, forced, geo, A.kernel_name(), A.kernel_name(True))
+            x = S.x_sin(ncol) if valued else S.x_int(trial, ncol)
+            y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+            A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
+            ref = O.csr_mul(nrow, rp, cc, vv, x)
+            if valued:
+                sc = O.csr_abs_scale(nrow, rp, cc, vv, x)
+                assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(sc, 1e-300)), what
+            else:
+                assert np.array_equal(y.cpu().numpy(), ref), what
+            u = S.x_sin(nrow, 11.0, -0.2) if valued else S.x_int(trial + 1, nrow)
+            z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+            A.spmv(z, torch.from_numpy(u).cuda(), capi.current_stream(), transposed=True)
+            rows = np.repeat(np.arange(nrow, dtype=np.int32), lens)
+            zref = O.coo_tmul(ncol, rows, cc, vv, u)
+            if valued:
+                zs = O.coo_tmul(ncol, rows, cc, np.abs(vv), np.abs(u))
+                assert np.all(np.abs(z.cpu().numpy() - zref) <= TOL * np.maximum(zs, 1e-300)), what
+            else:
+                assert np.array_equal(z.cpu().numpy(), zref), what
+            X = S.X_sin(ncol, 2)
+            Y = torch.full((nrow, 2), -1.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y, torch.from_numpy(X).cuda(), 2, capi.current_stream())
+            Yref = O.csr_mul_n(nrow, rp, cc, vv, X, 2)
+            for j in range(2):
+                sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X[:, j]))
+                assert np.all(np.abs(Y.cpu().numpy()[:, j] - Yref[:, j]) <= TOL * np.maximum(sc, 1e-300)), (what, j)
+            del A
+    finally:
+        for k_ in ("tile_rows", "tile_cols", "bin_rows", "tile_split"):
+            capi.set_option(k_, 0)
