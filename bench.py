@@ -263,12 +263,18 @@ def main():
         klabel = labels.get(kname, kname)
         if kname_t != kname:   # the format builder's timed choice may differ between A and A' (they are within a few %)
             klabel = "A: %s; A': %s" % (klabel, labels.get(kname_t, kname_t))
-        tfile = os.path.join(ROOT, "profiles", "traffic_spmv_%s.json" % kname.replace("-", "_")) if kname_t == kname else ""
-        if os.path.exists(tfile):
+        # PMC traffic per product (profiles/traffic_spmv_<kernel>.json, measured on this workload): the mean over
+        # the step's two products, which may run on different kernels
+        traffic = None
+        if world == 1:
             try:
-                tj = json.load(open(tfile))
-                if tj.get("rows") == n_local and tj.get("per_row") == per and world == 1:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                vals_ = []
+                for kn in (kname, kname_t):
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_spmv_%s.json" % kn.replace("-", "_"))))
+                    if tj.get("rows") != n_local or tj.get("per_row") != per:
+                        raise ValueError("traffic file is for another workload")
+                    vals_.append(float(tj["hbm_bytes_per_launch"]))
+                traffic = sum(vals_) / len(vals_)
             except Exception:
                 traffic = None
         rec = {
