@@ -238,6 +238,38 @@ def main():
     total_bytes = float(world) * (bytes_a + bytes_t) * args.steps
     value = total_bytes / elapsed / 1e9
 
+    # self-check outside the timed region (no oracle here: that is the tests' job): the products the timed loop left in
+    # y and z against the storage-order chunk-streaming kernel on the same operands, and, at N > 1, every rank holding
+    # the same gathered y / reduced z
+    self_check = {}
+    try:
+        y_ref = torch.empty(n_local, dtype=torch.float64, device=dev)
+        capi.set_option("strict_order", 1)
+        try:
+            A.spmv(y_ref, x, capi.current_stream())
+            z_ref = torch.empty(ncol, dtype=torch.float64, device=dev)
+            A.spmv(z_ref, u[lo:lo + n_local], capi.current_stream(), transposed=True)
+        finally:
+            capi.set_option("strict_order", 0)
+        self_check["A_mul_B_max_abs_diff_vs_storage_order_kernel"] = float((y[lo:lo + n_local] - y_ref).abs().max())
+        if world > 1:
+            zr = z_ref.clone()
+            fsd.all_reduce_sum(zr)                                    # sum of the ranks' partial products
+            sums = torch.tensor([float(y.sum()), float(z.sum())], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            lo_, hi_ = sums.clone(), sums.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            self_check["ranks_hold_identical_y_and_z"] = bool(torch.equal(lo_, hi_))
+        else:
+            zr = z_ref
+        self_check["At_mul_B_max_abs_diff_vs_storage_order_kernel"] = float((z - zr).abs().max())
+        self_check["ok"] = bool(self_check["A_mul_B_max_abs_diff_vs_storage_order_kernel"] <= 1e-11 and
+                                self_check["At_mul_B_max_abs_diff_vs_storage_order_kernel"] <= 1e-11 * world and
+                                self_check.get("ranks_hold_identical_y_and_z", True))
+        del y_ref, z_ref, zr
+    except Exception as ex:   # a failed check must show in the line, not kill it
+        self_check = {"ok": False, "error": repr(ex)}
+
     # on-box streaming ceiling (SURVEY 8d asks for % of the measured stream peak next to % of the 8 TB/s spec):
     # a read-only pass over 1.92 GB, the size of config 2's cols + vals
     stream_gbs = None
@@ -290,6 +322,7 @@ def main():
                        "stream_read_GBs_measured": stream_gbs,
                        "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
                        "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt),
+                       "self_check": self_check,
                        "kernel_A": A.kernel_name(), "kernel_At": A.kernel_name(True),
                        "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": A.candidate_ms(True)},
             "roofline": {"bound": "hbm", "kernel": klabel, "achieved": achieved,
