@@ -43,6 +43,13 @@ __device__ __forceinline__ T stream_load(const T *p)
   return *p;
 }
 
+template <bool NT, typename T>
+__device__ __forceinline__ void stream_store(T v, T *p)
+{
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // y = A x, chunk-streaming kernel.
 //   replaces csr_A_mul_B (csr.h:425-438), bcsr_A_mul_B (csr.h:149-161) and, through the
@@ -415,7 +422,7 @@ constexpr int kLdsxXPer = kLdsxCols / kTiledBlock;    // x values per thread and
 // Every load of a phase is unconditional and its result is not touched before the phase that needs it (addresses
 // are clamped here, lanes outside the slice are masked when the slice is published): a load under a branch, or a
 // select on its result, makes the compiler wait for it on the spot and the pipeline collapses.
-template <bool VALUED>
+template <bool VALUED, bool NT>
 __device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, const unsigned *__restrict__ pk,
                                           const double *__restrict__ vals, const double *__restrict__ x, int xs,
                                           unsigned (&w)[kLdsxPer], double (&v)[kLdsxPer], double (&xr)[kLdsxXPer])
@@ -433,15 +440,15 @@ __device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, 
   for (int q = 0; q < kLdsxPer; ++q) {
     const int pos = q * kTiledBlock + t;
     const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
-    w[q] = __builtin_nontemporal_load(pk + e);
-    if (VALUED) v[q] = __builtin_nontemporal_load(vals + e);
+    w[q] = stream_load<NT>(pk + e);
+    if (VALUED) v[q] = stream_load<NT>(vals + e);
   }
 }
 
 // A workgroup takes one CHUNK: a contiguous range of the work items of one panel (normally the whole panel; panels
 // that hold far more than their share of the entries are cut into several chunks, whose y slices are added up in
 // HBM with atomics -- the launcher then routes the output through a zeroed scratch vector).
-template <bool VALUED>
+template <bool VALUED, bool NT>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
 #define FS_PHASE(IT, D0, W0, V0, D1, X1, D3, W3, V3, X3)                                          \
   D3 = dN;                                                                                        \
   dN = item((IT) + 4);                                                                            \
-  ldsx_load<VALUED>(D3, t, W, ncol, pk, vals, x, xs, W3, V3, X3);                                 \
+  ldsx_load<VALUED, NT>(D3, t, W, ncol, pk, vals, x, xs, W3, V3, X3);                                 \
   _Pragma("unroll") for (int q = 0; q < kLdsxPer; ++q) {                                          \
     const int pos = q * kTiledBlock + t;                                                          \
     if (pos < D0.y) {                                                                             \
@@ -658,7 +665,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // pass 1: persistent workgroups, one per CU; workgroup w streams the w-th equal share of the (band, panel)-ordered
 // groups and reloads its x band when the share crosses into the next band (every band is loaded once, plus once
 // per share boundary: cutting bands into many small workgroups instead re-reads x several times over)
-template <bool VALUED, int U>
+template <bool VALUED, int U, bool NTLD, bool NTST>
 __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
     int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
     const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
@@ -715,9 +722,9 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         const int64_t e = o + (int64_t)k * 2 * kBinBlock;
-        a[k] = __builtin_nontemporal_load((const unsigned *)(lcol + e));
-        d[k] = __builtin_nontemporal_load(gdst + (e >> kBinGroupLog));
-        if (VALUED) v[k] = __builtin_nontemporal_load((const v2d *)(vals + e));
+        a[k] = stream_load<NTLD>((const unsigned *)(lcol + e));
+        d[k] = stream_load<NTLD>(gdst + (e >> kBinGroupLog));
+        if (VALUED) v[k] = stream_load<NTLD>((const v2d *)(vals + e));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -725,24 +732,25 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
         const int64_t e = o + (int64_t)k * 2 * kBinBlock;
         v2d p = {xband[a[k] & 0xffffu], xband[a[k] >> 16]};
         if (VALUED) { p.x *= v[k].x; p.y *= v[k].y; }
-        __builtin_nontemporal_store(p, (v2d *)(prod + (int64_t)d[k] * kBinGroup + (e & (kBinGroup - 1))));
+        stream_store<NTST>(p, (v2d *)(prod + (int64_t)d[k] * kBinGroup + (e & (kBinGroup - 1))));
       }
     }
     for (; o < e1; o += 2 * kBinBlock) {
-      const unsigned a = __builtin_nontemporal_load((const unsigned *)(lcol + o));
-      const unsigned d = __builtin_nontemporal_load(gdst + (o >> kBinGroupLog));
+      const unsigned a = stream_load<NTLD>((const unsigned *)(lcol + o));
+      const unsigned d = stream_load<NTLD>(gdst + (o >> kBinGroupLog));
       v2d p = {xband[a & 0xffffu], xband[a >> 16]};
       if (VALUED) {
-        const v2d v = __builtin_nontemporal_load((const v2d *)(vals + o));
+        const v2d v = stream_load<NTLD>((const v2d *)(vals + o));
         p.x *= v.x; p.y *= v.y;
       }
-      __builtin_nontemporal_store(p, (v2d *)(prod + (int64_t)d * kBinGroup + (o & (kBinGroup - 1))));
+      stream_store<NTST>(p, (v2d *)(prod + (int64_t)d * kBinGroup + (o & (kBinGroup - 1))));
     }
     g = gb;
   }
 }
 
 // pass 2: workgroup = one row panel; its products are contiguous
+template <bool NTLD>
 __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
     const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
     const double *__restrict__ prod, double *__restrict__ y, int ys)
@@ -769,19 +777,19 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int64_t ek = e + (int64_t)k * 8 * kBinBlock;
-      a[k] = __builtin_nontemporal_load((const v4u *)(lrow + ek));
+      a[k] = stream_load<NTLD>((const v4u *)(lrow + ek));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) p[k][j] = __builtin_nontemporal_load((const v2d *)(prod + ek + 2 * j));
+      for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ek + 2 * j));
     }
     __builtin_amdgcn_sched_barrier(0);
     FS_ADD8(a[0], p[0])
     FS_ADD8(a[1], p[1])
   }
   for (; e < e1; e += 8 * kBinBlock) {
-    const v4u a = __builtin_nontemporal_load((const v4u *)(lrow + e));
+    const v4u a = stream_load<NTLD>((const v4u *)(lrow + e));
     v2d p[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = __builtin_nontemporal_load((const v2d *)(prod + e + 2 * j));
+    for (int j = 0; j < 4; ++j) p[j] = stream_load<NTLD>((const v2d *)(prod + e + 2 * j));
     FS_ADD8(a, p)
   }
 #undef FS_ADD8
@@ -825,12 +833,12 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
     }
     const int ost = T.shared ? 1 : ys;
     if (T.nchunks > 0) {
-      if (A.vals)
-        hipLaunchKernelGGL(spmv_ldsx_kernel<true>, dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits,
-                           A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost);
-      else
-        hipLaunchKernelGGL(spmv_ldsx_kernel<false>, dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits,
-                           A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost);
+#define FS_LDSX(V, N)                                                                                              \
+  hipLaunchKernelGGL((spmv_ldsx_kernel<V, N>), dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, \
+                     A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
+      if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
+      else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
+#undef FS_LDSX
       FS_HIP(hipGetLastError());
     }
     if (T.shared) {
@@ -862,16 +870,29 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   double *out = N.split ? N.yv : y;              // cut rows: virtual sums first, combined below
   const int os = N.split ? 1 : ys;
   if (N.nwg1 > 0) {
-    const int flags = options().bin_flags;   // tuning switches: bits 0-1 select the pass-1 unroll (0: default)
-#define FS_EXPAND(V, U)                                                                                            \
-  hipLaunchKernelGGL((spmv_expand_kernel<V, U>), dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol, \
-                     N.vals, N.gdst, x, xs, N.prod)
-    if (A.vals) { if ((flags & 3) == 1) FS_EXPAND(true, 8); else if ((flags & 3) == 2) FS_EXPAND(true, 2); else FS_EXPAND(true, 4); }
-    else        { if ((flags & 3) == 1) FS_EXPAND(false, 8); else if ((flags & 3) == 2) FS_EXPAND(false, 2); else FS_EXPAND(false, 4); }
+    // tuning switches (A/B runs): bits 0-1 pass-1 unroll (1: 8, 2: 2 steps; default 4), bit 2 pass-2 loads
+    // non-temporal, bit 3 pass-1 stores plain, bit 4 pass-1 loads non-temporal.  Defaults, measured on config 2
+    // (valued / pattern-only, ms per product): plain loads in both passes and non-temporal stores 0.95 / 0.69;
+    // non-temporal loads in pass 1 0.98 / 0.73, in pass 2 as well 1.09 / 0.84; plain stores 1.01 / 0.75
+    const int flags = options().bin_flags;
+#define FS_EXPAND4(V, U)                                                                                          \
+  do {                                                                                                            \
+    if (flags & 16) { if (flags & 8) FS_EXPAND(V, U, true, false);  else FS_EXPAND(V, U, true, true); }           \
+    else            { if (flags & 8) FS_EXPAND(V, U, false, false); else FS_EXPAND(V, U, false, true); }          \
+  } while (0)
+#define FS_EXPAND(V, U, NL, NS)                                                                                    \
+  hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
+                     N.lcol, N.vals, N.gdst, x, xs, N.prod)
+    if (A.vals) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
+    else        { if ((flags & 3) == 1) FS_EXPAND4(false, 8); else if ((flags & 3) == 2) FS_EXPAND4(false, 2); else FS_EXPAND4(false, 4); }
+#undef FS_EXPAND4
 #undef FS_EXPAND
     FS_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(spmv_reduce_kernel, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+  if (options().bin_flags & 4)
+    hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+  else
+    hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
   FS_HIP(hipGetLastError());
   if (N.split) {
     hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,

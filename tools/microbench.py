@@ -112,7 +112,10 @@ def main():
             A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
             x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
             y = torch.empty(n, dtype=torch.float64, device="cuda")
-            report(out, f"c2_{'f64' if valued else 'pattern'}_{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            for fl in (0, 1, 0):
+                capi.set_option("tiled_flags", fl)
+                report(out, f"c2_{'f64' if valued else 'pattern'}_{A.kernel_name()}_flags{fl}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            capi.set_option("tiled_flags", 0)
             del A, rp, cc, vv
         capi.set_option("tiling", args.tiling)
     if "bin" in what:
@@ -130,7 +133,8 @@ def main():
             x = torch.sin(7.0 * torch.arange(ncol, device="cuda", dtype=torch.float64) + 0.3)
             y = torch.empty(n, dtype=torch.float64, device="cuda")
             tag = "f64" if valued else "pattern"
-            for kern, label, fl in ((7, "two_pass", 0), (6, "tiled", 0), (7, "two_pass_u8", 1), (7, "two_pass_u2", 2), (7, "two_pass", 0)):
+            for kern, label, fl in ((7, "two_pass", 0), (6, "tiled", 0), (7, "two_pass_p2_nt_loads", 4), (7, "two_pass_p1_plain_stores", 8),
+                                    (7, "two_pass_p1_nt_loads", 16), (7, "two_pass", 0)):
                 capi.set_option("spmv_kernel", kern)
                 capi.set_option("bin_flags", fl)
                 report(out, f"c2_{tag}_ncol{ncol}_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
@@ -196,6 +200,10 @@ def main():
             A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
             capi.set_option(opt, 1)
             report(out, f"c3_bcsr_forced_{label}:{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+            if opt in ("ldsx", "tiling"):
+                capi.set_option("tiled_flags", 1)
+                report(out, f"c3_bcsr_forced_{label}_cached_entry_loads", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+                capi.set_option("tiled_flags", 0)
             del A
         capi.set_option("spmv_kernel", 0)
     if "cols" in what:
