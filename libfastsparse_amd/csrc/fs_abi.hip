@@ -93,6 +93,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "tile_split")) { fs::options().tile_split = value; return FS_OK; }
   if (!strcmp(name, "tiled_flags")) { fs::options().tiled_flags = value; return FS_OK; }
   if (!strcmp(name, "reproducible")) { fs::options().reproducible = value; return FS_OK; }
+  if (!strcmp(name, "bin_wgs")) { fs::options().bin_wgs = value; return FS_OK; }
   if (!strcmp(name, "bin_flags")) { fs::options().bin_flags = value; return FS_OK; }
   if (!strcmp(name, "bin_rows")) { fs::options().bin_rows = value; return FS_OK; }
   if (!strcmp(name, "ldsx")) { fs::options().ldsx = value; return FS_OK; }

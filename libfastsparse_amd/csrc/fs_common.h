@@ -172,6 +172,7 @@ struct Options {
   int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
   int reproducible = 0;  // 1: only kernels whose sums are bit-identical run to run (the two-pass kernels add with LDS
                          // atomics in arrival order); read when a matrix is created and at every product
+  int bin_wgs = 0;       // override the number of persistent pass-1 workgroups (0 = one per CU)
   int bin_flags = 0;     // tuning switches of the two-pass kernels (see launch_spmv_binned)
   int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
   int ldsx = 1;          // the copy for the LDS-staged kernel: 1 when the estimates do not rule it out, 2 always, 0 never

@@ -869,7 +869,8 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   const BinnedCsr &N = *A.binned;
   double *out = N.split ? N.yv : y;              // cut rows: virtual sums first, combined below
   const int os = N.split ? 1 : ys;
-  if (N.nwg1 > 0) {
+  const int nwg1 = (options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1;
+  if (nwg1 > 0) {
     // tuning switches (A/B runs): bits 0-1 pass-1 unroll (1: 8, 2: 2 steps; default 4), bit 2 pass-2 loads
     // non-temporal, bit 3 pass-1 stores plain, bit 4 pass-1 loads non-temporal.  Defaults, measured on config 2
     // (valued / pattern-only, ms per product): plain loads in both passes and non-temporal stores 0.95 / 0.69;
@@ -881,7 +882,7 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
     else            { if (flags & 8) FS_EXPAND(V, U, false, false); else FS_EXPAND(V, U, false, true); }          \
   } while (0)
 #define FS_EXPAND(V, U, NL, NS)                                                                                    \
-  hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(N.nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
+  hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
                      N.lcol, N.vals, N.gdst, x, xs, N.prod)
     if (A.vals) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
     else        { if ((flags & 3) == 1) FS_EXPAND4(false, 8); else if ((flags & 3) == 2) FS_EXPAND4(false, 2); else FS_EXPAND4(false, 4); }

@@ -104,6 +104,40 @@ def main():
         report(out, f"c2_hybrid_tiled_part_alone", B, timeit(lambda: A1.spmv(y[:n1], x, st)))
         report(out, f"c2_hybrid_two_pass_part_alone", B, timeit(lambda: A2.spmv(y[n1:], x, st)))
         del A1, A2
+    if "wgs" in what:
+        # pass-1 time of the two-pass pair against the number of persistent workgroups (= the share size): HBM channel camping?
+        capi.set_option("binning", 2)
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+        for w in (256, 255, 254, 253, 252, 250, 248, 247, 240, 232, 224, 256):
+            capi.set_option("bin_wgs", w)
+            report(out, f"c2_two_pass_pass1_wgs{w}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        capi.set_option("bin_wgs", 0)
+        capi.set_option("binning", 1)
+        del A
+    if "sortcols" in what:
+        # does the order of a row's entries matter to the two-pass kernels?  config 2 with each row's columns sorted
+        capi.set_option("binning", 2)
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+        report(out, "c2_two_pass_random_order_in_rows", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        del A
+        cs, _ = torch.sort(cc.view(n, 16), dim=1)
+        cs = cs.contiguous().view(-1)
+        A = capi.Matrix.from_csr(n, n, rp, cs, vv, borrow=True)
+        report(out, "c2_two_pass_sorted_columns_in_rows", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        del A
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+        report(out, "c2_two_pass_random_order_in_rows_again", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        del A
+        A = capi.Matrix.from_csr(n, n, rp, cs, vv, borrow=True)
+        report(out, "c2_two_pass_sorted_columns_in_rows_again", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
+        del A
+        capi.set_option("binning", 1)
     if "tiledab" in what:
         # the tiled kernel alone on the config-2 shape, valued and pattern-only (A/B runs of kernel changes)
         capi.set_option("tiling", 2)
