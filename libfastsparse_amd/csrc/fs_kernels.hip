@@ -12,10 +12,13 @@
 //                        default for large matrices.  Pass 1 keeps a band of x in LDS and writes the products,
 //                        regrouped by row panel, to HBM; pass 2 keeps a panel of y in LDS and adds them up.
 //                        Neither pass gathers from L2 or HBM.
-//   spmv_tiled_kernel    y = A x on the L2-tiled copy (row panels x column bands): the default for matrices
-//                        whose x does not fit a CU's L1 many times over.  One 1024-thread workgroup per CU;
-//                        producer waves stream the entries and gather x inside the current band, consumer
-//                        waves reduce the staged products into the panel's y slice in LDS.
+//   spmv_ldsx_kernel     y = A x on a tiled copy with bands of <= 2048 columns: the band's slice of x is staged
+//                        in LDS, so gathers and adds are LDS operations.  For dense tiles (config 3, cbcsr).
+//   spmv_tiled_kernel    y = A x on the L2-tiled copy (row panels x column bands): x gathered from L2 inside
+//                        the current band.  One 1024-thread workgroup per CU; producer waves stream the
+//                        entries and gather, consumer waves reduce the staged products into the panel's y
+//                        slice in LDS.  The fixed-order (run-to-run reproducible) kernel for large matrices.
+//   (which of the three runs on a matrix is the format builder's measured choice: fs_format.hip, choose_copy)
 //   spmv_stream_kernel   y = A x, CSR or pattern-only CSR.  One 256-thread workgroup streams a
 //                        fixed 2048-non-zero chunk of cols/vals with 16-byte loads, gathers x,
 //                        parks the products in LDS and reduces them per row.  Work per
