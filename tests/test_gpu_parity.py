@@ -753,12 +753,13 @@ def test_fuzz_every_forced_copy_small_shapes(hip):
     forced copies and geometry overrides: A x, A' u and a two-column product of every kernel against the oracle"""
     import torch
     from libfastsparse_amd import capi
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(int(os.environ.get("FS_FUZZ_SEED", "20261004")))
     opts = ("binning", "ldsx", "tiling", None)
     try:
-        for trial in range(48):
-            nrow = int(rng.choice([1, 2, 17, 300, 1500, 5000]))
-            ncol = int(rng.choice([1, 3, 64, 900, 20000, 40000]))
+        for trial in range(int(os.environ.get("FS_FUZZ_TRIALS", "48"))):
+            scale = int(os.environ.get("FS_FUZZ_SCALE", "1"))        # one-off runs at larger sizes
+            nrow = int(rng.choice([1, 2, 17, 300, 1500, 5000])) * scale
+            ncol = int(rng.choice([1, 3, 64, 900, 20000, 40000])) * scale
             maxlen = int(rng.choice([1, 4, 30, 200]))
             lens = rng.integers(0, maxlen + 1, nrow)
             if rng.uniform() < 0.5:
