@@ -74,6 +74,9 @@ def all_cases():
     out.append(syn("syn_dup_1024", 0x5EED03, 1024, 1024, 12, dup_frac=0.2))
     out.append(syn("syn_long_800x5000", 0x5EED04, 800, 5000, 3, long_row=(411, 50000)))
     out.append(syn("syn_rowmajor_3000x200", 0x5EED05, 3000, 200, 64, shuffle=False))
+    # wide: 40 000 columns = 3 bands of the two-pass copy, 20 slices of the LDS-staged one; tall: 70 columns
+    out.append(syn("syn_wide_300x40000", 0x5EED06, 300, 40000, 40))
+    out.append(syn("syn_tall_4000x70", 0x5EED07, 4000, 70, 5))
     return out
 
 

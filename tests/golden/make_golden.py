@@ -23,10 +23,17 @@ import _cases  # noqa: E402
 
 
 def main():
+    """python tests/golden/make_golden.py [case name ...]  -- no names: every case; names: only those (spread.json is
+    updated, not rewritten)"""
     strict = _cases.RefBackend(fast=False)
     fast = _cases.RefBackend(fast=True)
+    only = set(sys.argv[1:])
     spread = {}
+    if only and os.path.exists(os.path.join(HERE, "spread.json")):
+        spread = json.load(open(os.path.join(HERE, "spread.json")))
     for case in _cases.all_cases():
+        if only and case.name not in only:
+            continue
         out = _cases.run_case(strict, case)
         np.savez_compressed(os.path.join(HERE, case.name + ".npz"), **{k.replace("/", "|"): v for k, v in out.items()})
         outf = _cases.run_case(fast, case)
