@@ -419,6 +419,8 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
 // the residue classes): ds_add_f64 on random rows runs at 2.97 lanes per clock, conflict-free at 6.9, and the adds
 // are the largest share of the LDS time (config 3: 1.07 -> 0.87 ms with perfectly conflict-free rows).
 // ------------------------------------------------------------------------------------------
+constexpr int kLdsxSets = 4;                          // register sets = items in flight (8 measured no faster: 0.92 vs
+                                                      // 0.89 ms on config 3, 1.87 vs 1.84 ms on its transpose)
 constexpr int kLdsxPer = kTiledItem / kTiledBlock;    // entries per thread and item (2)
 constexpr int kLdsxXPer = kLdsxCols / kTiledBlock;    // x values per thread and slice (2)
 
@@ -451,7 +453,7 @@ __device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, 
 // A workgroup takes one CHUNK: a contiguous range of the work items of one panel (normally the whole panel; panels
 // that hold far more than their share of the entries are cut into several chunks, whose y slices are added up in
 // HBM with atomics -- the launcher then routes the output through a zeroed scratch vector).
-template <bool VALUED, bool NT>
+template <bool VALUED, bool NT, int NSETS>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
@@ -477,42 +479,54 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     if (i < it0 || i >= it1) d.y = 0;           // ... and emptied: loads one entry and one slice, contributes nothing
     return d;
   };
-  // no separate prologue: the sweep starts three phases early on empty items (see spmv_tiled_kernel)
-  int4 dA = item(it0 - 3), dB = dA, dC = dA, dD = dA, dN = item(it0);
-  unsigned wA[kLdsxPer] = {}, wB[kLdsxPer] = {}, wC[kLdsxPer] = {}, wD[kLdsxPer] = {};
-  double vA[kLdsxPer] = {}, vB[kLdsxPer] = {}, vC[kLdsxPer] = {}, vD[kLdsxPer] = {};
-  double xA[kLdsxXPer] = {}, xB[kLdsxXPer] = {}, xC[kLdsxXPer] = {}, xD[kLdsxXPer] = {};
-#define FS_PUBLISH(BUF, D, X)                                                                      \
-  _Pragma("unroll") for (int q = 0; q < kLdsxXPer; ++q) {                                         \
-    const int lc = q * kTiledBlock + t;                                                           \
-    xsl[(BUF) & 1][lc] = (lc < W && D.z * W + lc < ncol) ? X[q] : 0.0;                            \
+  // NSETS register sets hold the items in flight (set k % NSETS belongs to item k; all indices below are constants
+  // after unrolling, so the sets are registers).  No separate prologue: the sweep starts NSETS-1 phases early on empty
+  // items (see spmv_tiled_kernel).
+  int4 dset[NSETS];
+  unsigned w[NSETS][kLdsxPer];
+  double v[NSETS][kLdsxPer];
+  double xr[NSETS][kLdsxXPer];
+#pragma unroll
+  for (int k = 0; k < NSETS; ++k) {
+    dset[k] = item(it0 - 1);                     // an empty descriptor with valid addresses
+#pragma unroll
+    for (int q = 0; q < kLdsxPer; ++q) { w[k][q] = 0; v[k][q] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < kLdsxXPer; ++q) xr[k][q] = 0.0;
   }
+  const int first = it0 - (NSETS - 1);
+  int4 dN = item(first + NSETS - 1);              // descriptor of the item the first phase requests
   __syncthreads();   // ytile zeroed
-  // phase IT: request item IT+3 (set 3; its descriptor was fetched a phase ago) and the descriptor of IT+4, consume
-  // item IT (set 0) from slice buffer IT&1, publish the slice of item IT+1 (set 1) in the other buffer
-#define FS_PHASE(IT, D0, W0, V0, D1, X1, D3, W3, V3, X3)                                          \
-  D3 = dN;                                                                                        \
-  dN = item((IT) + 4);                                                                            \
-  ldsx_load<VALUED, NT>(D3, t, W, ncol, pk, vals, x, xs, W3, V3, X3);                                 \
-  _Pragma("unroll") for (int q = 0; q < kLdsxPer; ++q) {                                          \
-    const int pos = q * kTiledBlock + t;                                                          \
-    if (pos < D0.y) {                                                                             \
-      double pr = xsl[(IT) & 1][W0[q] & cmask];                                                   \
-      if (VALUED) pr *= V0[q];                                                                    \
-      __hip_atomic_fetch_add(&ytile[W0[q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    }                                                                                             \
-  }                                                                                               \
-  FS_PUBLISH((IT) + 1, D1, X1)                                                                    \
-  __syncthreads();
-  // whole rounds of four phases, no early exit (phases past the last item add nothing: their items are empty)
-  for (int it = it0 - 3; it < it1; it += 4) {
-    FS_PHASE(it, dA, wA, vA, dB, xB, dD, wD, vD, xD)
-    FS_PHASE(it + 1, dB, wB, vB, dC, xC, dA, wA, vA, xA)
-    FS_PHASE(it + 2, dC, wC, vC, dD, xD, dB, wB, vB, xB)
-    FS_PHASE(it + 3, dD, wD, vD, dA, xA, dC, wC, vC, xC)
+  // phase IT (IT = it + ph, ph constant): request item IT+NSETS-1 into the set item IT-1 has just left (its
+  // descriptor was fetched a phase ago) and fetch the descriptor after it; consume item IT from slice buffer IT&1;
+  // publish the slice of item IT+1 in the other buffer.  Whole rounds of NSETS phases, no early exit (phases past the
+  // last item add nothing: their items are empty).  Buffer parity: `first` may be odd, so it is carried explicitly.
+  for (int it = first; it < it1; it += NSETS) {
+#pragma unroll
+    for (int ph = 0; ph < NSETS; ++ph) {
+      const int IT = it + ph;
+      const int s0 = ph, s1 = (ph + 1) % NSETS, sl = (ph + NSETS - 1) % NSETS;
+      dset[sl] = dN;
+      dN = item(IT + NSETS);
+      ldsx_load<VALUED, NT>(dset[sl], t, W, ncol, pk, vals, x, xs, w[sl], v[sl], xr[sl]);
+      const int buf = IT & 1;
+#pragma unroll
+      for (int q = 0; q < kLdsxPer; ++q) {
+        const int pos = q * kTiledBlock + t;
+        if (pos < dset[s0].y) {
+          double pr = xsl[buf][w[s0][q] & cmask];
+          if (VALUED) pr *= v[s0][q];
+          __hip_atomic_fetch_add(&ytile[w[s0][q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kLdsxXPer; ++q) {
+        const int lc = q * kTiledBlock + t;
+        xsl[buf ^ 1][lc] = (lc < W && dset[s1].z * W + lc < ncol) ? xr[s1][q] : 0.0;
+      }
+      __syncthreads();
+    }
   }
-#undef FS_PHASE
-#undef FS_PUBLISH
   __syncthreads();
   if (shared) {
     for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
@@ -837,8 +851,8 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
     const int ost = T.shared ? 1 : ys;
     if (T.nchunks > 0) {
 #define FS_LDSX(V, N)                                                                                              \
-  hipLaunchKernelGGL((spmv_ldsx_kernel<V, N>), dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, \
-                     A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
+  hipLaunchKernelGGL((spmv_ldsx_kernel<V, N, kLdsxSets>), dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
+                     T.lcol_bits, A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
       if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
       else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
 #undef FS_LDSX

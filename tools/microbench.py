@@ -234,10 +234,6 @@ def main():
             A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
             capi.set_option(opt, 1)
             report(out, f"c3_bcsr_forced_{label}:{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
-            if opt in ("ldsx", "tiling"):
-                capi.set_option("tiled_flags", 1)
-                report(out, f"c3_bcsr_forced_{label}_cached_entry_loads", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
-                capi.set_option("tiled_flags", 0)
             del A
         capi.set_option("spmv_kernel", 0)
     if "cols" in what:
