@@ -1,4 +1,5 @@
-"""Size-independent properties at BASELINE.json's full single-GPU sizes (configs 2, 3, 4), where the
+"""Size-independent properties at BASELINE.json's full single-GPU sizes (configs 2, 3, 4, and one row shard of
+config 5's shape), where the
 oracle cannot be run on everything in seconds: exact integer checksums, adjointness, column consistency
 of the multi-RHS product, and an oracle check of a row window."""
 import numpy as np
@@ -144,3 +145,43 @@ def hip_env():
     from oracle import pyoracle as O
     capi.lib()
     return torch, capi, O
+
+
+def test_config5_like_shard_powerlaw(hip_env):
+    """one row shard of BASELINE config 5's shape: 4 M rows x 100 M columns (x of 800 MB), power-law row lengths
+    clipped at 1e6 (the generator of the full config, `fs_synth_powerlaw_lengths`), ~100 M non-zeros: row windows
+    around the longest rows and at both ends against the oracle, the builder's choice against the storage-order
+    kernel on every row, and the integer checksum of checksums on the pattern"""
+    torch, capi, O = hip_env
+    nrow, ncol = 4_000_000, 100_000_000
+    rp, cc, vv = capi.synth_powerlaw(nrow, ncol, 2.3, 1_000_000, 0x5EED0005)
+    nnz = int(rp[-1].item())
+    assert 50_000_000 < nnz < 300_000_000
+    A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+    st = capi.current_stream()
+    x = torch.sin(7.0 * torch.arange(ncol, device="cuda", dtype=torch.float64) + 0.3)
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    A.spmv(y, x, st)
+    lens = (rp[1:] - rp[:-1])
+    longest = int(torch.argmax(lens).item())
+    for lo in (0, max(0, min(longest - 100, nrow - 400)), nrow - 400):
+        _window_check(capi, O, rp, cc, vv, x, y, lo, lo + 400, exact=False)
+    y2 = torch.empty_like(y)
+    capi.set_option("strict_order", 1)
+    try:
+        A.spmv(y2, x, st)
+    finally:
+        capi.set_option("strict_order", 0)
+    # row-scaled bound with the row length as the scale's proxy: |x| <= 1, |v| <= 1
+    bound = 1e-12 * torch.clamp(lens.to(torch.float64), min=1.0)
+    assert bool(((y - y2).abs() <= bound).all()), A.kernel_name()
+    del A
+    Ap = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+    xi = _int_x(ncol, "cuda", 9)
+    Ap.spmv(y, xi, st)
+    total = 0
+    step = 50_000_000
+    xl = xi.to(torch.int64)
+    for a in range(0, nnz, step):
+        total += int(xl[cc[a:a + step].long()].sum().item())
+    assert int(y.to(torch.int64).sum().item()) == total, Ap.kernel_name()
