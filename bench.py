@@ -1,29 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- fp64 CSR SpMV (A_mul_B + At_mul_B) on BASELINE.json config 2, one rank per GPU.
+"""bench.py -- the A_mul_B / At_mul_B path on MI355X, one rank per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload: per GPU a CSR shard of 10 000 000 rows x 16 non-zeros, columns uniform over
-10 000 000 columns, values uniform(-1,1), generated on the device by the counter-based generator (seed
-0x5EED0002, identical on CPU).  N = 1 is exactly config 2 (10M x 10M).  N > 1 is weak scaling by rows, the
-partition config 5 names: the global matrix is (N*10M) x 10M, rank r owns rows [r*10M, (r+1)*10M) -- a
-config-2 matrix of its own -- x (80 MB) is replicated, y = A x is a local SpMV followed by the RCCL
-all-gather of the y shards, and z = A' u is the local transposed product of the rank's rows with its slice
-of u followed by an RCCL all-reduce (sum) of the 80 MB partial results.  The two products of a step are
-independent, so each exchange is started asynchronously and overlaps the next local product.
+`python bench.py --gpus N` with N > 1 and no launcher starts the N ranks ITSELF (fresh child processes, before this
+process touches the GPU) and fails loudly if the world it finds is not N.
 
-One step = y = A x  then  z = A' u  (two products per rank -- each one launch of the expand kernel and one of
-the reduce kernel of the two-pass SpMV -- plus one all-gather and one all-reduce when N > 1).  value = algorithmic bytes of all ranks' products / max-over-ranks wall time.
-Algorithmic bytes per product: 12*nnz + 4*(nrow+1) + 8*nrow + 8*ncol.
+Workloads (all data synthetic, generated on the device by the counter-based generators whose CPU twins
+live in oracle/fs_synth.c):
 
-Prints ONE JSON line on rank 0 with `roofline` (one product = spmv_expand_kernel + spmv_reduce_kernel, HIP-event
-timed inside the timed region; "launch" below means one product, i.e. that pair) and, at N = 1, `cpu_baseline` (the oracle's OpenMP restatement of csr_A_mul_B,
-built with the reference's flags, timed on this box's host cores on the same matrix).
+  c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on)
+      fp64 CSR 10 M x 10 M, 16 nnz/row uniform.  Step = y = A x then z = A' u (two products).  N > 1: weak scaling by
+      rows, the global matrix is (N*10M) x 10M, every rank owns a config-2 shard, x replicated, y = local SpMV + RCCL
+      all-gather of the y shards, z = local A_r' u_r + RCCL all-reduce; exchanges overlap the next local product.
+  c3  SparseBinaryMatrix 10 M x 1 M, 64 nnz/row, supplied as COO to the A_mul_B / At_mul_B handles (fs_coo_create),
+      integer-valued x.  Step = A_mul_B + At_mul_B.  One GPU.
+  c4  CSR x dense SpMM: the config-2 matrix times X (10 M x 32, row-major).  Step = one csr_A_mul_Bn (k = 32);
+      k = 2, 4, 8 are timed beside it.  One GPU.
+  c5  CSR 100 M x 100 M, power-law row lengths (mean 32, clipped at 1e6), rows cut by non-zeros over the N ranks, x
+      (800 MB) replicated, y = local SpMV + RCCL all-gather of the (unequal) y shards; with --transpose also
+      z = A' u as "row shards of A' + all-gather".  The matrix does not fit one struct CSR (3.2 G non-zeros > 2^31-1),
+      so N = 1 runs ONE real shard: the rows rank 3 of 8 owns under the nnz-balanced cut.
+
+value = algorithmic bytes of all ranks' products / max-over-ranks wall time of the K timed steps (barrier +
+synchronize on both sides), operands resident in HBM.  Algorithmic bytes per product:
+(12 | 4)*nnz + 4*(nrow+1) + 8k*nrow + 8k*ncol.
+
+Prints ONE JSON line on rank 0 with `roofline` (HIP-event timed inside the timed region) and, at N = 1,
+`cpu_baseline` (the oracle's OpenMP restatement built with the reference's flags and, where oracle/_ref travelled,
+the real reference's serial loop, on a stated bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,8 +43,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-SEED = 0x5EED0002
+SEED_C2 = 0x5EED0002
+SEED_C3 = 0x5EED0003
+SEED_C5 = 0x5EED0005
+C5_SCALE, C5_MAXLEN = 2.3, 1_000_000     # P(len >= L) ~ 2.3 / L clipped at 1e6: mean 31.7 non-zeros per row
 METRIC = "fp64 CSR SpMV effective GB/s (% HBM3E peak)"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# launching
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not touched the
+    GPU and never will), wait for them, return the worst exit code.  Rank 0 prints the JSON line."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                c = p.poll()
+                if c is None:
+                    continue
+                alive.remove(p)
+                if c != 0:
+                    rc = rc or c
+                    for q in alive:          # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def host_cpus():
@@ -55,41 +112,167 @@ def host_cpus():
     return n
 
 
-def cpu_baseline(rows, ncol, per_row, reps=10):
-    """csr_A_mul_B restated (oracle/fs_oracle.c: fso_csr_mul, omp parallel for schedule(dynamic,256) as csr.h:429),
-    built here with the reference's flags (-O3 -march=native -fopenmp -ffast-math), on the same config-2 matrix."""
-    import numpy as np
-    from oracle import pyoracle, pysynth
+# ------------------------------------------------------------------------------------------------------------
+# the device side behind a small interface (tests/test_dist_gloo.py rehearses the multi-rank workloads on CPU with
+# the oracle behind the same interface; bench.py itself only ever uses HipProvider)
+# ------------------------------------------------------------------------------------------------------------
+class HipProvider:
+    name = "hip"
+
+    def __init__(self, dev):
+        import torch
+        from libfastsparse_amd import capi
+        self.torch, self.capi, self.dev = torch, capi, dev
+        capi.lib()
+
+    def stream(self):
+        return self.capi.current_stream()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def elapsed_ms(self, e0, e1):
+        return e0.elapsed_time(e1)
+
+    def empty(self, n, dtype=None):
+        return self.torch.empty(n, dtype=dtype or self.torch.float64, device=self.dev)
+
+    def sin_vector(self, n, a, b):
+        t = self.torch
+        return t.sin(a * t.arange(n, device=self.dev, dtype=t.float64) + b)
+
+    def int_vector(self, n, seed):
+        t = self.torch
+        g = t.Generator(device=self.dev)
+        g.manual_seed(seed)
+        return t.randint(-1000, 1001, (n,), device=self.dev, generator=g).to(t.float64)
+
+    def powerlaw_lengths(self, nrow, row_offset):
+        t = self.torch
+        lens = t.empty(nrow, dtype=t.int32, device=self.dev)
+        self.capi.check(self.capi.lib().fs_synth_powerlaw_lengths(nrow, C5_SCALE, C5_MAXLEN, SEED_C5, row_offset,
+                                                                    lens.data_ptr(), self.stream()))
+        return lens
+
+    def fill(self, row_ptr, ncol, row_offset, valued=True):
+        t = self.torch
+        nrow = row_ptr.numel() - 1
+        nnz = int(row_ptr[-1].item())
+        cols = t.empty(max(nnz, 1), dtype=t.int32, device=self.dev)[:nnz]
+        vals = t.empty(max(nnz, 1), dtype=t.float64, device=self.dev)[:nnz] if valued else None
+        self.capi.check(self.capi.lib().fs_synth_fill(nrow, ncol, SEED_C5, row_offset, row_ptr.data_ptr(), cols.data_ptr(),
+                                                      vals.data_ptr() if valued else None, self.stream()))
+        return cols, vals
+
+    def csr(self, nrow, ncol, rp, cc, vv):
+        return self.capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+
+    def coo(self, nrow, ncol, rows, cols, vals):
+        return self.capi.Matrix.from_coo(nrow, ncol, rows, cols, vals)
+
+    def spmv(self, A, y, x, transposed=False):
+        A.spmv(y, x, self.stream(), transposed=transposed)
+
+
+def timed_steps(prov, step, drain, steps, warmup, world, backend_is_nccl):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks (seconds)"""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step(None)
+    drain()
+    prov.synchronize()
+    if world > 1:
+        dist.barrier()
+    evs = [[prov.event() for _ in range(4)] for _ in range(steps)]
+    prov.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(evs[k])
+    drain()
+    prov.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=prov.dev if backend_is_nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, evs
+
+
+def stream_probe(prov):
+    """on-box streaming ceiling: a read-only pass over 1.92 GB, the size of config 2's cols + vals"""
+    t = prov.torch
+    probe = t.empty(240_000_000, dtype=t.float64, device=prov.dev).fill_(1.0)
+    for _ in range(2):
+        probe.sum()
+    e0, e1 = prov.event(), prov.event()
+    e0.record()
+    for _ in range(5):
+        probe.sum()
+    e1.record()
+    prov.synchronize()
+    gbs = 5 * probe.numel() * 8 / (prov.elapsed_ms(e0, e1) * 1e-3) / 1e9
+    del probe
+    return gbs
+
+
+def csr_bytes(nnz, nrow, ncol, valued=True, k=1):
+    return (12 if valued else 4) * nnz + 4 * (nrow + 1) + 8 * k * nrow + 8 * k * ncol
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baselines (the ONLY place bench.py touches oracle/: the checker timed as the reported baseline, never the product)
+# ------------------------------------------------------------------------------------------------------------
+def _fast_oracle():
+    from oracle import pyoracle
     import ctypes as C
     out = os.path.join("/tmp", "liboracle_fast_%d.so" % os.getpid())
     fast = pyoracle.load(pyoracle.build_fast(out))
+    os.remove(out)
+    ncpu = host_cpus()
     # one OpenMP thread per host CPU this process may run on (the box gives a GPU job a share of the host's cores;
     # libgomp's default would be every core of the machine)
-    ncpu = host_cpus()
     C.CDLL("libgomp.so.1").omp_set_num_threads(ncpu)
-    rp, cc, vv = pysynth.uniform(rows, ncol, per_row, SEED)
-    x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
-    y = np.empty(rows)
-    vp = vv.ctypes.data
-    fast.fso_csr_mul(y, rows, rp, cc, vp, x)          # warm-up (bench_a_mul_b.c does one untimed call)
+    return fast, ncpu
+
+
+def _time_calls(f, reps):
+    f()                                   # warm-up (bench_a_mul_b.c does one untimed call)
     t0 = time.time()
     for _ in range(reps):
-        fast.fso_csr_mul(y, rows, rp, cc, vp, x)
-    dt = (time.time() - t0) / reps
-    nbytes = 12 * rows * per_row + 4 * (rows + 1) + 8 * rows + 8 * ncol
-    strict = pyoracle.load()
-    os.remove(out)
-    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": int(strict.fso_threads()), "kind": "port",
-            "host_cpus_available": ncpu,
-            "ms_per_product": dt * 1e3,
-            "sample": "csr_A_mul_B on the full config-2 matrix (%d x %d, %d nnz/row), 1 warm-up + mean of %d "
-                      "repeats, OpenMP schedule(dynamic,256), gcc -O3 -march=native -ffast-math" % (rows, ncol, per_row, reps)}
+        f()
+    return (time.time() - t0) / reps
 
 
-def cpu_reference_serial(rows, ncol, per_row, reps=3):
-    """The REAL reference's csr_A_mul_B (oracle/_ref/libfsref.so, compiled from the reference's own headers in the
-    build container, without OpenMP -- see oracle/ref_shim.c) on the first `rows` rows of the config-2 matrix:
-    one host core.  Present only when the prebuilt library travelled with the repo."""
+def cpu_baseline_c2(rows, ncol, per_row, reps=10):
+    """csr_A_mul_B restated (oracle/fs_oracle.c: fso_csr_mul, omp parallel for schedule(dynamic,256) as csr.h:429),
+    built here with the reference's flags (-O3 -march=native -fopenmp -ffast-math), on the same config-2 matrix."""
+    import numpy as np
+    from oracle import pysynth
+    fast, ncpu = _fast_oracle()
+    rp, cc, vv = pysynth.uniform(rows, ncol, per_row, SEED_C2)
+    x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
+    y = np.empty(rows)
+    dt = _time_calls(lambda: fast.fso_csr_mul(y, rows, rp, cc, vv.ctypes.data, x), reps)
+    nbytes = csr_bytes(rows * per_row, rows, ncol)
+    rec = {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": ncpu, "kind": "port", "ms_per_product": dt * 1e3,
+           "sample": "csr_A_mul_B on the full config-2 matrix (%d x %d, %d nnz/row), 1 warm-up + mean of %d repeats, "
+                     "OpenMP schedule(dynamic,256), gcc -O3 -march=native -ffast-math" % (rows, ncol, per_row, reps)}
+    ref1 = cpu_reference_serial("csr_A_mul_B", min(rows, 2_000_000), ncol, per_row, SEED_C2, True)
+    if ref1:
+        rec["reference_serial"] = ref1
+    return rec
+
+
+def cpu_reference_serial(entry, rows, ncol, per_row, seed, valued, reps=3):
+    """The REAL reference (oracle/_ref/libfsref.so, compiled from the reference's own headers in the build container,
+    without OpenMP -- see oracle/ref_shim.c) on the first `rows` rows: one host core.  Present only when the prebuilt
+    library travelled with the repo.  entry: csr_A_mul_B (csr.h:425), bcsr_A_mul_B (csr.h:149), A_mul_B (sparse.h:58)."""
     import ctypes as C
     import numpy as np
     so = os.path.join(ROOT, "oracle", "_ref", "libfsref.so")
@@ -97,63 +280,120 @@ def cpu_reference_serial(rows, ncol, per_row, reps=3):
         return None
     from oracle import pysynth
     lib = C.CDLL(so)
-    rp, cc, vv = pysynth.uniform(rows, ncol, per_row, SEED)
-
-    class CSR(C.Structure):      # csr.h:358-366
-        _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_long), ("row_ptr", C.c_void_p),
-                    ("cols", C.c_void_p), ("vals", C.c_void_p)]
-    A = CSR(rows, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, vv.ctypes.data)
+    rp, cc, vv = pysynth.uniform(rows, ncol, per_row, seed, valued=valued)
     x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
     y = np.empty(rows)
-    f = lib.csr_A_mul_B
+    keep = [rp, cc, vv, x, y]
+    if entry == "A_mul_B":         # struct SparseBinaryMatrix, sparse.h:11-18
+        rows_arr = np.repeat(np.arange(rows, dtype=np.int32), per_row)
+        keep.append(rows_arr)
+
+        class SBM(C.Structure):
+            _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_long), ("rows", C.c_void_p), ("cols", C.c_void_p)]
+        A = SBM(rows, ncol, len(cc), rows_arr.ctypes.data, cc.ctypes.data)
+        nbytes = csr_bytes(len(cc), rows, ncol, valued=False)
+    elif entry == "bcsr_A_mul_B":  # struct BinaryCSR, csr.h:15-22
+        class BCSR(C.Structure):
+            _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_long), ("row_ptr", C.c_void_p), ("cols", C.c_void_p)]
+        A = BCSR(rows, ncol, len(cc), rp.ctypes.data, cc.ctypes.data)
+        nbytes = csr_bytes(len(cc), rows, ncol, valued=False)
+    else:                          # struct CSR, csr.h:358-366
+        class CSR(C.Structure):
+            _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_long), ("row_ptr", C.c_void_p),
+                        ("cols", C.c_void_p), ("vals", C.c_void_p)]
+        A = CSR(rows, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, vv.ctypes.data)
+        nbytes = csr_bytes(len(cc), rows, ncol)
+    f = getattr(lib, entry)
     f.restype = None
     args = (C.c_void_p(y.ctypes.data), C.byref(A), C.c_void_p(x.ctypes.data))
-    f(*args)
-    t0 = time.time()
-    for _ in range(reps):
-        f(*args)
-    dt = (time.time() - t0) / reps
-    nbytes = 12 * rows * per_row + 4 * (rows + 1) + 8 * rows + 8 * ncol
+    dt = _time_calls(lambda: f(*args), reps)
     return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference", "ms_per_product": dt * 1e3,
-            "sample": "reference csr_A_mul_B (csr.h:425, serial build) on the first %d rows of the config-2 matrix, "
-                      "x over all %d columns, 1 warm-up + mean of %d" % (rows, ncol, reps)}
+            "sample": "reference %s (serial build) on the first %d rows (%d x %d, %d nnz/row), 1 warm-up + mean of %d"
+                      % (entry, rows, rows, ncol, per_row, reps)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (config 2: 10M)")
-    ap.add_argument("--per-row", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_c3(nrow, ncol, per_row, sample_rows=2_500_000, reps=3):
+    """binary product: the oracle's bcsr_A_mul_B restatement (OpenMP as csr.h:152) on the first `sample_rows` rows, and
+    the real reference's SERIAL A_mul_B (sparse.h:58-65 has no OpenMP pragma) on a smaller sample"""
+    import numpy as np
+    from oracle import pysynth
+    fast, ncpu = _fast_oracle()
+    rows = min(nrow, sample_rows)
+    rp, cc, _ = pysynth.uniform(rows, ncol, per_row, SEED_C3, valued=False)
+    x = np.random.default_rng(3).integers(-1000, 1001, ncol).astype(np.float64)
+    y = np.empty(rows)
+    dt = _time_calls(lambda: fast.fso_csr_mul(y, rows, rp, cc, None, x), reps)
+    nbytes = csr_bytes(rows * per_row, rows, ncol, valued=False)
+    rec = {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": ncpu, "kind": "port", "ms_per_product": dt * 1e3,
+           "sample": "bcsr_A_mul_B restated (OpenMP schedule(dynamic,256)) on the first %d of %d rows (%d columns, %d "
+                     "nnz/row), 1 warm-up + mean of %d, gcc -O3 -march=native -ffast-math" % (rows, nrow, ncol, per_row, reps)}
+    ref1 = cpu_reference_serial("A_mul_B", min(nrow, 500_000), ncol, per_row, SEED_C3, False)
+    if ref1:
+        rec["reference_serial"] = ref1
+    return rec
 
+
+def cpu_baseline_c4(n, per_row, k, sample_rows=400_000, reps=2):
+    """csr_A_mul_Bn on the first `sample_rows` rows (X over all columns), both ways SURVEY note N4 asks for: with the
+    reference's own nested `omp parallel` + `omp parallel for` (csr.h:445-448: every thread walks all rows) and with
+    the corrected single `omp for`"""
+    import numpy as np
+    from oracle import pysynth
+    fast, ncpu = _fast_oracle()
+    rows = min(n, sample_rows)
+    rp, cc, vv = pysynth.uniform(rows, n, per_row, SEED_C2)
+    i = np.arange(n, dtype=np.float64)[:, None]
+    X = np.sin(7.0 * i + 17.0 * np.arange(k, dtype=np.float64)[None, :] + 0.3).reshape(-1)
+    Y = np.empty(rows * k)
+    nbytes = csr_bytes(rows * per_row, rows, n, k=k)
+    dt_fix = _time_calls(lambda: fast.fso_csr_mul_n(Y, rows, rp, cc, vv.ctypes.data, X, k), reps)
+    dt_ref = _time_calls(lambda: fast.fso_csr_mul_n_reference_schedule(Y, rows, rp, cc, vv.ctypes.data, X, k), reps)
+    what = "csr_A_mul_Bn k=%d on the first %d rows of the config-2 matrix (X %d x %d), 1 warm-up + mean of %d" % (k, rows, n, k, reps)
+    return {"value": nbytes / dt_fix / 1e9, "unit": "GB/s", "cores": ncpu, "kind": "port", "ms_per_product": dt_fix * 1e3,
+            "sample": what + "; corrected schedule: one `omp for` over rows",
+            "as_reference_runs_it": {"value": nbytes / dt_ref / 1e9, "unit": "GB/s", "cores": ncpu, "kind": "port",
+                                     "ms_per_product": dt_ref * 1e3,
+                                     "sample": what + "; the reference's nested parallel regions (csr.h:445-448): every one "
+                                               "of the %d threads computes every row" % ncpu}}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------
+KERNEL_LABELS = {"two-pass": "fs::spmv_expand_kernel + fs::spmv_reduce_kernel (one product)",
+                 "tiled": "fs::spmv_tiled_kernel", "lds-staged": "fs::spmv_ldsx_kernel", "stream": "fs::spmv_stream_kernel"}
+
+
+def _klabel(ka, kt=None):
+    lab = KERNEL_LABELS.get(ka, ka)
+    if kt is not None and kt != ka:   # the format builder's timed choice may differ between A and A'
+        lab = "A: %s; A': %s" % (lab, KERNEL_LABELS.get(kt, kt))
+    return lab
+
+
+def _traffic(kernels, workload, rows, per):
+    """PMC traffic per product (profiles/traffic_<workload>_<kernel>.json, measured on this workload): the mean over the
+    step's products"""
+    try:
+        vals_ = []
+        for kn in kernels:
+            name = "traffic_spmv_%s.json" % kn.replace("-", "_") if workload == "c2" else \
+                   "traffic_%s_%s.json" % (workload, kn.replace("-", "_"))
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if tj.get("rows") != rows or tj.get("per_row") != per:
+                raise ValueError("traffic file is for another workload")
+            vals_.append(float(tj["hbm_bytes_per_launch"]))
+        return sum(vals_) / len(vals_)
+    except Exception:
+        return None
+
+
+def run_c2(args, prov, world, rank, nccl):
     import torch
     import torch.distributed as dist
     from libfastsparse_amd import capi
     from libfastsparse_amd import dist as fsd
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # FS_BENCH_BACKEND=gloo rehearses the N > 1 code path with several ranks sharing one GPU (no RCCL there)
-    backend = os.environ.get("FS_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    capi.lib()
-
+    dev = prov.dev
     n_local, per = args.rows, args.per_row
     ncol = n_local                      # column space stays config 2's: every rank's shard is a config-2 matrix
     n_global = n_local * world          # global rows
@@ -161,7 +401,7 @@ def main():
     st = capi.current_stream()
 
     # ---- this rank's shard: rows lo .. lo+n_local of the (N*10M) x 10M matrix ------------------------
-    rp, cc, vv = capi.synth_uniform(n_local, ncol, per, SEED, row_offset=lo)
+    rp, cc, vv = capi.synth_uniform(n_local, ncol, per, SEED_C2, row_offset=lo)
     A = capi.Matrix.from_csr(n_local, ncol, rp, cc, vv, borrow=True)
     A.build_transpose(st)
     bounds = fsd.even_row_partition(n_global, world)
@@ -171,8 +411,8 @@ def main():
     op_t = fsd.TransposedShardedOperator(
         lambda z, u_local: A.spmv(z, u_local, capi.current_stream(), transposed=True), bounds)
 
-    x = torch.sin(7.0 * torch.arange(ncol, device=dev, dtype=torch.float64) + 0.3)        # bench_a_mul_b.c:142
-    u = torch.sin(11.0 * torch.arange(n_global, device=dev, dtype=torch.float64) - 0.2)   # 2nd column of X2col, :145
+    x = prov.sin_vector(ncol, 7.0, 0.3)             # bench_a_mul_b.c:142
+    u = prov.sin_vector(n_global, 11.0, -0.2)       # 2nd column of X2col, :145
     y = torch.empty(n_global, dtype=torch.float64, device=dev)
     z = torch.empty(ncol, dtype=torch.float64, device=dev)
 
@@ -218,26 +458,7 @@ def main():
             pending[0].wait()
             pending[0] = None
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k])
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, evs = timed_steps(prov, step, drain, args.steps, args.warmup, world, nccl)
 
     # per-product durations inside the timed region (HIP events on the launch stream); a product is the kernel
     # pair expand + reduce of the two-pass SpMV (or one launch of the tiled / streaming kernel if the format
@@ -248,7 +469,6 @@ def main():
     avg_ms = (sum(ka) + sum(kt)) / launches
     bytes_per_launch = (bytes_a + bytes_t) / 2.0
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-
     total_bytes = float(world) * (bytes_a + bytes_t) * args.steps
     value = total_bytes / elapsed / 1e9
 
@@ -270,7 +490,7 @@ def main():
         if world > 1:
             zr = z_ref.clone()
             fsd.all_reduce_sum(zr)                                    # sum of the ranks' partial products
-            sums = torch.tensor([float(y_last.sum()), float(z.sum())], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            sums = torch.tensor([float(y_last.sum()), float(z.sum())], dtype=torch.float64, device=dev if nccl else "cpu")
             lo_, hi_ = sums.clone(), sums.clone()
             dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
@@ -285,74 +505,460 @@ def main():
     except Exception as ex:   # a failed check must show in the line, not kill it
         self_check = {"ok": False, "error": repr(ex)}
 
-    # on-box streaming ceiling (SURVEY 8d asks for % of the measured stream peak next to % of the 8 TB/s spec):
-    # a read-only pass over 1.92 GB, the size of config 2's cols + vals
-    stream_gbs = None
-    if rank == 0:
-        probe = torch.empty(240_000_000, dtype=torch.float64, device=dev).fill_(1.0)
+    if rank != 0:
+        return None
+    stream_gbs = stream_probe(prov)
+    kname, kname_t = A.kernel_name(), A.kernel_name(True)
+    rec = {
+        "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B"
+                               % (n_global, ncol, per) if world == 1 else
+                               "config-2 shards, weak scaling by rows: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
+                               "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (n_global, ncol, n_local, per),
+                   "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
+                   "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
+                   "stream_read_GBs_measured": stream_gbs,
+                   "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
+                   "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt),
+                   "self_check": self_check,
+                   "kernel_A": kname, "kernel_At": kname_t,
+                   "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": A.candidate_ms(True)},
+        "roofline": {"bound": "hbm", "kernel": _klabel(kname, kname_t), "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _traffic((kname, kname_t), "c2", n_local, per) if world == 1 else None,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                     "launches_timed": launches},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_c2(n_local, ncol, per)
+        except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
+            rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+    return rec
+
+
+def run_c3(args, prov, world, rank, nccl):
+    """BASELINE config 3 through its own entry points: the COO arrays of a SparseBinaryMatrix go to the A_mul_B handle
+    (fs_coo_create: stable device sort by row = new_bcsr's order, csr.h:30-67) and, swapped, to the At_mul_B handle"""
+    import torch
+    from libfastsparse_amd import capi
+    if world != 1:
+        raise SystemExit("--workload c3 is a one-GPU workload (BASELINE configs[2])")
+    dev = prov.dev
+    nrow, ncol, per = args.rows, max(args.rows // 10, 1), 64
+    st = capi.current_stream()
+    _, cols, _ = capi.synth_uniform(nrow, ncol, per, SEED_C3, valued=False)
+    rows = torch.arange(nrow, device=dev, dtype=torch.int32).repeat_interleave(per)   # row-major COO, as SURVEY C3 says
+    nnz = nrow * per
+    prov.synchronize()
+    t0 = time.perf_counter()
+    A = capi.Matrix.from_coo(nrow, ncol, rows, cols, None)
+    prov.synchronize()
+    t_build_a = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    At = capi.Matrix.from_coo(ncol, nrow, cols, rows, None)        # each output keeps the COO entry order (sparse.h:72-74)
+    prov.synchronize()
+    t_build_t = time.perf_counter() - t0
+    del rows
+    x = prov.int_vector(ncol, 3)
+    u = prov.int_vector(nrow, 4)
+    y = torch.empty(nrow, dtype=torch.float64, device=dev)
+    z = torch.empty(ncol, dtype=torch.float64, device=dev)
+    bytes_a = csr_bytes(nnz, nrow, ncol, valued=False)
+    bytes_t = csr_bytes(nnz, ncol, nrow, valued=False)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        A.spmv(y, x, st)
+        if ev is not None:
+            ev[1].record()
+            ev[2].record()
+        At.spmv(z, u, st)
+        if ev is not None:
+            ev[3].record()
+
+    elapsed, evs = timed_steps(prov, step, lambda: None, args.steps, args.warmup, 1, nccl)
+    ka = [e[0].elapsed_time(e[1]) for e in evs]
+    kt = [e[2].elapsed_time(e[3]) for e in evs]
+    avg_ms = (sum(ka) + sum(kt)) / (2 * args.steps)
+    bpl = (bytes_a + bytes_t) / 2.0
+    achieved = bpl / (avg_ms * 1e-3) / 1e9
+    value = (bytes_a + bytes_t) * args.steps / elapsed / 1e9
+    # self-check: integer data, so the storage-order kernel must give the same bits
+    sc = {}
+    try:
+        y2, z2 = torch.empty_like(y), torch.empty_like(z)
+        capi.set_option("strict_order", 1)
+        try:
+            A.spmv(y2, x, st)
+            At.spmv(z2, u, st)
+        finally:
+            capi.set_option("strict_order", 0)
+        # integer checksum of checksums: sum_r y[r] == sum over the entries of x[col] (exact below 2^53)
+        xl, tot = x.to(torch.int64), 0
+        for a in range(0, nnz, 64_000_000):
+            tot += int(xl[cols[a:a + 64_000_000].long()].sum().item())
+        sc = {"A_mul_B_bit_identical_to_storage_order_kernel": bool(torch.equal(y, y2)),
+              "At_mul_B_bit_identical_to_storage_order_kernel": bool(torch.equal(z, z2)),
+              "integer_checksum_of_checksums": int(y.to(torch.int64).sum().item()) == tot}
+        sc["ok"] = all(sc.values())
+    except Exception as ex:
+        sc = {"ok": False, "error": repr(ex)}
+    ka_name, kt_name = A.kernel_name(), At.kernel_name()
+    rec = {
+        "metric": "binary SpMV (A_mul_B + At_mul_B) effective GB/s (% HBM3E peak)", "value": value, "unit": "GB/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: SparseBinaryMatrix %d x %d, %d nnz/row, COO -> A_mul_B + At_mul_B, "
+                               "integer-valued x" % (nrow, ncol, per),
+                   "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt),
+                   "A_mul_B_GBs": bytes_a / (sum(ka) / len(ka) * 1e-3) / 1e9,
+                   "At_mul_B_GBs": bytes_t / (sum(kt) / len(kt) * 1e-3) / 1e9,
+                   "device_coo_to_csr_and_format_s": {"A": t_build_a, "At": t_build_t},
+                   "kernel_A": ka_name, "kernel_At": kt_name,
+                   "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": At.candidate_ms(), "self_check": sc},
+        "roofline": {"bound": "hbm", "kernel": _klabel(ka_name, kt_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic((ka_name,), "c3", nrow, per),
+                     "algorithmic_bytes_per_launch": bpl, "avg_launch_ms": avg_ms, "launches_timed": 2 * args.steps},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_c3(nrow, ncol, per)
+        except Exception as ex:
+            rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+    return rec
+
+
+def run_c4(args, prov, world, rank, nccl):
+    """BASELINE config 4: csr_A_mul_Bn, A as config 2, X 10 M x 32 row-major (X[i,c] = sin(7i + 17c + 0.3),
+    bench_a_mul_b.c:149).  k = 2, 4, 8 beside it."""
+    import torch
+    from libfastsparse_amd import capi
+    if world != 1:
+        raise SystemExit("--workload c4 is a one-GPU workload (BASELINE configs[3])")
+    dev = prov.dev
+    n, per, k = args.rows, args.per_row, 32
+    st = capi.current_stream()
+    rp, cc, vv = capi.synth_uniform(n, n, per, SEED_C2)
+    A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+
+    def make_x(kk):
+        i = torch.arange(n, device=dev, dtype=torch.float64)[:, None]
+        c = torch.arange(kk, device=dev, dtype=torch.float64)[None, :]
+        return torch.sin(7.0 * i + 17.0 * c + 0.3).contiguous()
+
+    X = make_x(k)
+    Y = torch.empty(n, k, dtype=torch.float64, device=dev)
+    nbytes = A.algorithmic_bytes(k)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        A.spmm(Y, X, k, st)
+        if ev is not None:
+            ev[1].record()
+
+    elapsed, evs = timed_steps(prov, step, lambda: None, args.steps, args.warmup, 1, nccl)
+    kms = [e[0].elapsed_time(e[1]) for e in evs]
+    avg_ms = sum(kms) / len(kms)
+    achieved = nbytes / (avg_ms * 1e-3) / 1e9
+    value = nbytes * args.steps / elapsed / 1e9
+    sc = {}
+    try:     # column j of Y against the single-vector product of column j of X, both in storage order: identical bits
+        yj = torch.empty(n, dtype=torch.float64, device=dev)
+        capi.set_option("strict_order", 1)
+        try:
+            ok = True
+            for j in (0, 17, 31):
+                A.spmv(yj, X[:, j].contiguous(), st)
+                ok = ok and bool(torch.equal(Y[:, j], yj))
+        finally:
+            capi.set_option("strict_order", 0)
+        sc = {"columns_bit_identical_to_storage_order_spmv": ok, "ok": ok}
+    except Exception as ex:
+        sc = {"ok": False, "error": repr(ex)}
+    del X, Y
+    small = {}
+    for kk in (2, 4, 8):
+        Xk, Yk = make_x(kk), torch.empty(n, kk, dtype=torch.float64, device=dev)
         for _ in range(2):
-            probe.sum()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            A.spmm(Yk, Xk, kk, st)        # the first call builds the k-column copy
+        e0, e1 = prov.event(), prov.event()
         e0.record()
         for _ in range(5):
-            probe.sum()
+            A.spmm(Yk, Xk, kk, st)
         e1.record()
-        torch.cuda.synchronize()
-        stream_gbs = 5 * probe.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del probe
+        prov.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        small["k%d" % kk] = {"ms": ms, "GBs": A.algorithmic_bytes(kk) / (ms * 1e-3) / 1e9,
+                             "frac_of_peak": A.algorithmic_bytes(kk) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del Xk, Yk
+    rec = {
+        "metric": "fp64 CSR SpMM (k = 32) effective GB/s (% HBM3E peak)", "value": value, "unit": "GB/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: CSR %d x %d, %d nnz/row, times X %d x %d row-major (csr_A_mul_Bn)" % (n, n, per, n, k),
+                   "gather_traffic_model_bytes": n * per * 8 * k, "flops_per_product": 2 * k * n * per,
+                   "small_k": small, "mfma_instructions": 0, "self_check": sc},
+        "roofline": {"bound": "hbm", "kernel": "fs::spmm_kernel<valued, 5> (32 lanes per row)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _traffic(("spmm_k32",), "c4", n, per),
+                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_timed": args.steps},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_c4(n, per, k)
+        except Exception as ex:
+            rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+    return rec
 
-    if rank == 0:
-        traffic = None
-        kname, kname_t = A.kernel_name(), A.kernel_name(True)
-        labels = {"two-pass": "fs::spmv_expand_kernel<valued> + fs::spmv_reduce_kernel (one product)",
-                  "tiled": "fs::spmv_tiled_kernel<valued>", "lds-staged": "fs::spmv_ldsx_kernel<valued>",
-                  "stream": "fs::spmv_stream_kernel<valued>"}
-        klabel = labels.get(kname, kname)
-        if kname_t != kname:   # the format builder's timed choice may differ between A and A' (they are within a few %)
-            klabel = "A: %s; A': %s" % (klabel, labels.get(kname_t, kname_t))
-        # PMC traffic per product (profiles/traffic_spmv_<kernel>.json, measured on this workload): the mean over
-        # the step's two products, which may run on different kernels
-        traffic = None
+
+def c5_partition(prov, n_global, parts):
+    """row lengths of the whole power-law matrix (generated in slabs on this rank's device) -> cut points with equal
+    non-zero counts (libfastsparse_amd/dist.py nnz_balanced_partition on the 64-bit prefix sums), total non-zeros"""
+    import torch
+    slab = 25_000_000
+    sums = []
+    total = 0
+    for lo in range(0, n_global, slab):
+        lens = prov.powerlaw_lengths(min(slab, n_global - lo), lo)
+        c = torch.cumsum(lens.to(torch.int64), 0)
+        sums.append(c + total)
+        total += int(c[-1].item())
+        del lens
+    prefix = torch.cat(sums)                 # prefix[i] = non-zeros of rows 0 .. i
+    del sums
+    targets = torch.tensor([total * r // parts for r in range(1, parts)], dtype=torch.int64, device=prefix.device)
+    # first row index whose exclusive prefix >= target  (== searchsorted on row_ptr, row_ptr[i+1] = prefix[i])
+    cuts = torch.searchsorted(prefix, targets, right=False) + 1
+    cuts = torch.clamp(cuts, 0, n_global)
+    b = [0] + [int(v) for v in cuts.cpu()] + [n_global]
+    for i in range(1, len(b)):
+        b[i] = max(b[i], b[i - 1])
+    cum = [0] + [int(prefix[b[i] - 1].item()) if b[i] > 0 else 0 for i in range(1, len(b))]   # non-zeros in front of each cut
+    del prefix
+    return b, cum, total
+
+
+def c5_shard(prov, lo, hi, ncol):
+    """rows [lo, hi) of the power-law matrix as a local CSR (local row_ptr, GLOBAL column ids)"""
+    import torch
+    lens = prov.powerlaw_lengths(hi - lo, lo)
+    rp64 = torch.zeros(hi - lo + 1, dtype=torch.int64, device=lens.device)
+    torch.cumsum(lens, 0, out=rp64[1:])
+    nnz = int(rp64[-1].item())
+    if nnz > 2**31 - 1:
+        raise SystemExit("shard holds %d non-zeros: more than an int row_ptr (csr.h:363) can index; use more ranks" % nnz)
+    rp = rp64.to(torch.int32)
+    del rp64, lens
+    cc, vv = prov.fill(rp, ncol, lo)
+    return rp, cc, vv, nnz
+
+
+def run_c5(args, prov, world, rank, nccl, out=None):
+    """BASELINE config 5 (`out`, a dict, receives the final vectors: the gloo rehearsal in tests/ checks them against
+    the oracle's product with the whole matrix)"""
+    import torch
+    import torch.distributed as dist
+    from libfastsparse_amd import dist as fsd
+    n_global = args.c5_rows
+    ncol = n_global
+    parts = world if world > 1 else 8
+    mine = rank if world > 1 else min(3, parts - 1)     # N = 1: the shard rank 3 of 8 owns
+    bounds, cum_nnz, total_nnz = c5_partition(prov, n_global, parts)
+    lo, hi = bounds[mine], bounds[mine + 1]
+    rp, cc, vv, nnz = c5_shard(prov, lo, hi, ncol)
+    n_local = hi - lo
+    A = prov.csr(n_local, ncol, rp, cc, vv)
+    bytes_local = csr_bytes(nnz, n_local, ncol)
+
+    x = prov.sin_vector(ncol, 7.0, 0.3)
+    if world > 1:
+        op = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds)
+        ops = [op, fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds)]
+        ybufs = [prov.empty(n_global), prov.empty(n_global)]
+    else:
+        ops, ybufs = None, [prov.empty(n_local)] * 2
+
+    # A' u as "row shards of A' + all-gather" (N > 1 with --transpose): columns are uniform, so an even cut of the
+    # rows of A' is balanced; the shard is built once by an all-to-all of the entries
+    opt = At = None
+    t_err = None
+    if world > 1 and args.transpose:
+        try:
+            cb = fsd.even_row_partition(ncol, world)
+            tr, tc, tv = fsd.build_transposed_shard(rp, cc, vv, lo, cb)
+            At = prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), tv)
+            del tr, tc, tv
+            opt = fsd.TransposedGatherOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb)
+            u = prov.sin_vector(n_global, 11.0, -0.2)
+            z = prov.empty(ncol)
+            bytes_t = csr_bytes(int(At.nnz), cb[rank + 1] - cb[rank], n_global)
+        except Exception as ex:      # the transposed direction is an extra: report, keep the config-5 number
+            opt, t_err = None, repr(ex)
+    gather = [None]
+    zg = [None]
+    count = [0]
+
+    def step(ev=None):
+        b = count[0] & 1
+        count[0] += 1
+        if ev is not None:
+            ev[0].record()
         if world == 1:
+            prov.spmv(A, ybufs[0], x)
+            yl = None
+        else:
+            yl = ops[b].local(ybufs[b], x)
+        if ev is not None:
+            ev[1].record()
+        g = ops[b].gather_async(ybufs[b], yl) if world > 1 else None
+        if opt is not None:
+            if zg[0] is not None:
+                zg[0].wait()
+            if ev is not None:
+                ev[2].record()
+            zl = opt.local(z, u)
+            if ev is not None:
+                ev[3].record()
+            zg[0] = opt.gather_async(z, zl)
+        if gather[0] is not None:
+            gather[0].wait()          # the other y buffer is complete before the next step reuses its shard buffer
+        gather[0] = g
+
+    def drain():
+        for h in (gather, zg):
+            if h[0] is not None:
+                h[0].wait()
+                h[0] = None
+
+    elapsed, evs = timed_steps(prov, step, drain, args.steps, args.warmup, world, nccl)
+    ka = [prov.elapsed_ms(e[0], e[1]) for e in evs]
+    local_ms = sum(ka) / len(ka)
+    kt_ms = sum(prov.elapsed_ms(e[2], e[3]) for e in evs) / len(evs) if opt is not None else None
+
+    # the same loop without any exchange: what the all-gather costs on top of the local products
+    noex = None
+    if world > 1:
+        def step_local(ev=None):
+            ops[0].local(ybufs[0], x)
+            if opt is not None:
+                opt.local(z, u)
+        noex, _ = timed_steps(prov, step_local, lambda: None, args.steps, 1, world, nccl)
+
+    tot = torch.tensor([float(bytes_local), float(bytes_t) if opt is not None else 0.0], dtype=torch.float64,
+                       device=prov.dev if (nccl and world > 1) else "cpu")
+    if world > 1:
+        dist.all_reduce(tot)
+    bytes_all = float(tot[0].item()) + float(tot[1].item())
+    value = bytes_all * args.steps / elapsed / 1e9
+
+    sc = {}
+    try:
+        y_last = ybufs[(count[0] - 1) & 1]
+        if out is not None:
+            out["y"], out["z"], out["bounds"] = y_last, (z if opt is not None else None), bounds
+        if world > 1:
+            sums = torch.tensor([float(y_last.sum())], dtype=torch.float64, device=prov.dev if nccl else "cpu")
+            lo_, hi_ = sums.clone(), sums.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            sc["ranks_hold_identical_y"] = bool(torch.equal(lo_, hi_))
+        if hasattr(prov, "capi"):
+            y_ref = prov.empty(n_local)
+            prov.capi.set_option("strict_order", 1)
             try:
-                vals_ = []
-                for kn in (kname, kname_t):
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_spmv_%s.json" % kn.replace("-", "_"))))
-                    if tj.get("rows") != n_local or tj.get("per_row") != per:
-                        raise ValueError("traffic file is for another workload")
-                    vals_.append(float(tj["hbm_bytes_per_launch"]))
-                traffic = sum(vals_) / len(vals_)
-            except Exception:
-                traffic = None
-        rec = {
-            "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B"
-                                   % (n_global, ncol, per) if world == 1 else
-                                   "config-2 shards, weak scaling by rows: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
-                                   "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (n_global, ncol, n_local, per),
-                       "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
-                       "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
-                       "stream_read_GBs_measured": stream_gbs,
-                       "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
-                       "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt),
-                       "self_check": self_check,
-                       "kernel_A": A.kernel_name(), "kernel_At": A.kernel_name(True),
-                       "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": A.candidate_ms(True)},
-            "roofline": {"bound": "hbm", "kernel": klabel, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                         "launches_timed": launches},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                rec["cpu_baseline"] = cpu_baseline(n_local, ncol, per)
-                ref1 = cpu_reference_serial(min(n_local, 2_000_000), ncol, per)
-                if ref1:
-                    rec["cpu_baseline"]["reference_serial"] = ref1
-            except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
-                rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+                prov.spmv(A, y_ref, x)
+            finally:
+                prov.capi.set_option("strict_order", 0)
+            mine_y = y_last[lo:hi] if world > 1 else y_last
+            lens = (rp[1:] - rp[:-1]).to(torch.float64).clamp(min=1.0)
+            sc["rows_within_1e-12_x_row_length_of_storage_order_kernel"] = bool(((mine_y - y_ref).abs() <= 1e-12 * lens).all())
+        sc["ok"] = all(v for v in sc.values())
+    except Exception as ex:
+        sc = {"ok": False, "error": repr(ex)}
+    if rank != 0:
+        return None
+    kname = A.kernel_name() if hasattr(A, "kernel_name") else "injected"
+    achieved = bytes_local / (local_ms * 1e-3) / 1e9
+    rec = {
+        "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": ("BASELINE config 5: CSR %d x %d power-law (mean %.1f nnz/row, clipped at %d), rows cut by "
+                                "non-zeros over %d GPUs, x replicated, step = local SpMV + all-gather of y%s"
+                                % (n_global, ncol, total_nnz / n_global, C5_MAXLEN, world,
+                                   " + A'u (row shards of A' + all-gather of z)" if opt is not None else "")) if world > 1 else
+                               ("ONE shard of BASELINE config 5 (CSR %d x %d power-law, %d non-zeros in all): the rows rank %d of "
+                                "%d owns under the nnz-balanced cut; one GPU cannot hold the matrix in a struct CSR "
+                                "(2^31-1 non-zeros)" % (n_global, ncol, total_nnz, mine, parts)),
+                   "total_nnz": total_nnz, "rows_this_rank": n_local, "nnz_this_rank": nnz,
+                   "row_bounds": bounds if len(bounds) <= 17 else None,
+                   "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
+                   "local_A_mul_B_ms_rank0": local_ms, "local_At_mul_B_ms_rank0": kt_ms,
+                   "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
+                   "transpose_error": t_err, "kernel": kname,
+                   "builder_timed_ms": A.candidate_ms() if hasattr(A, "candidate_ms") else None, "self_check": sc},
+        "roofline": {"bound": "hbm", "kernel": _klabel(kname), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic((kname,), "c5", n_local, 0) if world == 1 else None,
+                     "algorithmic_bytes_per_launch": bytes_local, "avg_launch_ms": local_ms, "launches_timed": args.steps},
+    }
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (config 2 / 3 / 4: 10M)")
+    ap.add_argument("--per-row", type=int, default=16)
+    ap.add_argument("--c5-rows", type=int, default=100_000_000, help="rows = columns of the config-5 matrix")
+    ap.add_argument("--transpose", action="store_true", help="c5, N > 1: also time z = A' u")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    # ---- ranks: a launcher's world must be the one asked for; without a launcher, start the ranks here, before this
+    # process does anything with the GPU (a process that has initialised HIP must not be replaced or forked) -------
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run "
+                             "--nproc-per-node %d) or drop the launcher and let bench.py start them" % (args.gpus, world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # FS_BENCH_BACKEND=gloo rehearses the N > 1 code path with several ranks sharing one GPU (no RCCL there)
+    backend = os.environ.get("FS_BENCH_BACKEND", "nccl")
+    nccl = backend == "nccl"
+    ndev = max(torch.cuda.device_count(), 1)
+    if nccl and world > ndev:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, ndev))
+    dev_index = local_rank if nccl else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if nccl:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    prov = HipProvider(dev)
+    run = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload]
+    rec = run(args, prov, world, rank, nccl)
+    if rank == 0 and rec is not None:
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

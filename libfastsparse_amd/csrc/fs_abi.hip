@@ -98,6 +98,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "bin_rows")) { fs::options().bin_rows = value; return FS_OK; }
   if (!strcmp(name, "ldsx")) { fs::options().ldsx = value; return FS_OK; }
   if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
+  if (!strcmp(name, "spmm_kernel")) { fs::options().spmm_kernel = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
 }
@@ -113,6 +114,7 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "binning")) return fs::options().binning;
   if (name && !strcmp(name, "ldsx")) return fs::options().ldsx;
   if (name && !strcmp(name, "reproducible")) return fs::options().reproducible;
+  if (name && !strcmp(name, "spmm_kernel")) return fs::options().spmm_kernel;
   return FS_ERR_ARG;
 }
 
@@ -292,6 +294,7 @@ int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream
   if (int rc = check_mul(A, Y, X, "fs_spmm")) return rc;
   if (k < 1) { set_error("fs_spmm: k < 1"); return FS_ERR_ARG; }
   if (k == 1) return fs_spmv(A, Y, X, stream);
+  std::lock_guard<std::mutex> g(A->lock);   // k <= 4 may build a copy and uses the handle's product scratch
   return fs::launch_spmm(A->a, Y, X, k, (hipStream_t)stream);
 }
 
@@ -301,6 +304,7 @@ int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stre
   if (k < 1) { set_error("fs_spmm_t: k < 1"); return FS_ERR_ARG; }
   if (!A->has_t) { set_error("fs_spmm_t: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   if (k == 1) return fs_spmv_t(A, Y, X, stream);
+  std::lock_guard<std::mutex> g(A->lock);
   return fs::launch_spmm(A->at, Y, X, k, (hipStream_t)stream);
 }
 

@@ -38,6 +38,10 @@ struct DeviceCsr {
   TiledCsr *tiled = nullptr;  // optional L2-tiled copy (owned)
   TiledCsr *tiledx = nullptr; // optional copy in the same layout with the LDS-staged kernel's geometry (owned)
   BinnedCsr *binned = nullptr;  // optional two-pass copy (owned)
+  // two-pass copies for k = 2 / k = 4 right-hand sides in ONE sweep (a k-column band of X in LDS, k products per entry):
+  // built on the first multi-column product that can use them (launch_spmm); `tried` = the builder declined once
+  BinnedCsr *binned2 = nullptr, *binned4 = nullptr;
+  bool tried2 = false, tried4 = false;
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
@@ -105,13 +109,16 @@ constexpr int kBinShareMin = 8192;     // a pass-1 workgroup streams at least th
 
 struct BinnedCsr {
   bool built = false;
+  int kw = 1;                  // right-hand sides one sweep serves: bands of kBinCols / kw columns (kw * 8 bytes of X per
+                               // column in LDS), panels of at most kBinRowsMax / kw rows, groups of kBinGroup / kw entries
+                               // (a group is always kBinGroup products = one 128-byte line)
   int B = 0, P = 0;            // bands, panels
   int64_t n = 0;               // padded entry count (multiple of kBinGroup)
   uint16_t *lcol = nullptr;    // n, pass-1 order: column - band*kBinCols; padding = kBinCols (a zero slot)
   double *vals = nullptr;      // n, pass-1 order (nullptr: pattern-only); padding = 0
   unsigned *gdst = nullptr;    // n / kBinGroup: pass-2 group index of every pass-1 group
   uint16_t *lrow = nullptr;    // n, pass-2 order: (virtual) row - first row of the panel; padding = 0
-  double *prod = nullptr;      // n, pass-2 order: written by pass 1, read by pass 2
+  double *prod = nullptr;      // n * kw, pass-2 order: written by pass 1, read by pass 2
   unsigned *band_ptr = nullptr;  // B + 1: first pass-1 group of every band
   int nwg1 = 0;                // pass-1 workgroups (persistent, one per CU)
   unsigned *bin_ptr = nullptr; // P + 1: first pass-2 group of every panel
@@ -177,12 +184,14 @@ struct Options {
   int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
   int ldsx = 1;          // the copy for the LDS-staged kernel: 1 when the estimates do not rule it out, 2 always, 0 never
   int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
+  int spmm_kernel = 0;   // multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep (k = 2..4), 3 one
+                         // single-vector sweep per column, 4 the MFMA row kernel (experiment, see spmm_mfma_kernel)
 };
 Options &options();
 
 // ---- launchers implemented in fs_kernels.hip --------------------------------------------
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
-int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);
+int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // may build a k-column copy
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
@@ -192,6 +201,8 @@ int build_tiledx(DeviceCsr &A, hipStream_t s);      // the same for the LDS-stag
 int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs = 1,
                       int ys = 1);                  // T.ldsx selects the LDS-staged kernel
 int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heuristic ask for it
+int build_binned_k(DeviceCsr &A, int kw, hipStream_t s);   // the k-column copy (kw = 2 or 4) into A.binned2 / A.binned4
+int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys);
 int choose_copy(DeviceCsr &A, hipStream_t s);       // times the candidates and keeps the fastest copy
 int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,

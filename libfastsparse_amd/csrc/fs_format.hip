@@ -46,16 +46,17 @@ static void free_tiled_slot(TiledCsr *&T)
 static void free_tiled(DeviceCsr &A) { free_tiled_slot(A.tiled); }
 static void free_tiledx(DeviceCsr &A) { free_tiled_slot(A.tiledx); }
 
-static void free_binned(DeviceCsr &A)
+static void free_binned_slot(BinnedCsr *&N)
 {
-  BinnedCsr *N = A.binned;
   if (!N) return;
   void *owned[] = {N->lcol, N->vals, N->gdst, N->lrow, N->prod, N->band_ptr, N->bin_ptr, N->panel_row, N->vfirst, N->yv};
   for (void *q : owned)
     if (q) (void)hipFree(q);
   delete N;
-  A.binned = nullptr;
+  N = nullptr;
 }
+
+static void free_binned(DeviceCsr &A) { free_binned_slot(A.binned); }
 
 void free_csr(DeviceCsr &A)
 {
@@ -70,6 +71,8 @@ void free_csr(DeviceCsr &A)
   free_tiled(A);
   free_tiledx(A);
   free_binned(A);
+  free_binned_slot(A.binned2);
+  free_binned_slot(A.binned4);
   A = DeviceCsr();
 }
 
@@ -359,7 +362,7 @@ __global__ void max_row_len_kernel(int nrow, const int *__restrict__ row_ptr, in
 // every row) and the vector of virtual sums; the two device arrays are handed to the caller's structure at once so
 // that its destructor releases them on every path
 static int make_virtual_rows(const DeviceCsr &A, int split, hipStream_t s, Scratch<int> &vrow_ptr, int *nvrow_out,
-                             int **vfirst_out, double **yv_out)
+                             int **vfirst_out, double **yv_out, int kw = 1)
 {
   Scratch<int> cnt;
   Scratch<char> tmp;
@@ -380,7 +383,7 @@ static int make_virtual_rows(const DeviceCsr &A, int split, hipStream_t s, Scrat
   hipLaunchKernelGGL(vrow_fill_kernel, dim3(grid_for((int64_t)A.nrow + 1)), dim3(256), 0, s, A.nrow, split, A.row_ptr,
                      vfirst, vrow_ptr.p);
   FS_HIP(hipGetLastError());
-  FS_HIP(hipMalloc(yv_out, sizeof(double) * (size_t)nvrow));
+  FS_HIP(hipMalloc(yv_out, sizeof(double) * (size_t)nvrow * (size_t)kw));
   *nvrow_out = nvrow;
   return FS_OK;
 }
@@ -679,7 +682,7 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
 // ---- two-pass copy ------------------------------------------------------------------------------------
 // key of entry e = band(col) * P + panel(virtual row): a stable sort by key starting from CSR order leaves every
 // (band, panel) run in CSR storage order
-__global__ void bin_key_kernel(int nvrow, int64_t nnz, int P, const int *__restrict__ vrow_ptr,
+__global__ void bin_key_kernel(int nvrow, int64_t nnz, int P, int bcols, const int *__restrict__ vrow_ptr,
                                const int *__restrict__ panel_row, const int *__restrict__ cols,
                                int *__restrict__ vrows, unsigned *__restrict__ keys)
 {
@@ -687,12 +690,12 @@ __global__ void bin_key_kernel(int nvrow, int64_t nnz, int P, const int *__restr
   if (i >= nnz) return;
   const int v = last_le(vrow_ptr, nvrow, i);
   vrows[i] = v;
-  keys[i] = (unsigned)(cols[i] / kBinCols) * (unsigned)P + (unsigned)last_le(panel_row, P, v);
+  keys[i] = (unsigned)(cols[i] / bcols) * (unsigned)P + (unsigned)last_le(panel_row, P, v);
 }
 
 // group counts of the padded runs in pass-1 order (g1[band*P + panel]) and pass-2 order (g2[panel*B + band]);
 // slot nruns of both is the zero that turns the exclusive scans into B*P + 1 offsets
-__global__ void bin_groups_kernel(int B, int P, const int *__restrict__ run_ptr, unsigned *__restrict__ g1,
+__global__ void bin_groups_kernel(int B, int P, int ge, const int *__restrict__ run_ptr, unsigned *__restrict__ g1,
                                   unsigned *__restrict__ g2)
 {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -700,12 +703,12 @@ __global__ void bin_groups_kernel(int B, int P, const int *__restrict__ run_ptr,
   if (k > nruns) return;
   if (k == nruns) { g1[k] = 0; g2[k] = 0; return; }
   const int b = (int)(k / P), p = (int)(k % P);
-  const unsigned g = (unsigned)(run_ptr[k + 1] - run_ptr[k] + kBinGroup - 1) / kBinGroup;
+  const unsigned g = (unsigned)(run_ptr[k + 1] - run_ptr[k] + ge - 1) / (unsigned)ge;   // ge entries per group
   g1[k] = g;
   g2[(int64_t)p * B + b] = g;
 }
 
-__global__ void bin_scatter_kernel(int64_t nnz, int B, int P, const unsigned *__restrict__ skeys,
+__global__ void bin_scatter_kernel(int64_t nnz, int B, int P, int bcols, int ge, const unsigned *__restrict__ skeys,
                                    const unsigned *__restrict__ perm, const int *__restrict__ vrows,
                                    const int *__restrict__ panel_row, const int *__restrict__ cols,
                                    const double *__restrict__ vals, const int *__restrict__ run_ptr,
@@ -717,9 +720,9 @@ __global__ void bin_scatter_kernel(int64_t nnz, int B, int P, const unsigned *__
   const unsigned key = skeys[i], src = perm[i];
   const int b = (int)(key / (unsigned)P), p = (int)(key % (unsigned)P);
   const int64_t rank = i - run_ptr[key];
-  const int64_t pos1 = (int64_t)start1[key] * kBinGroup + rank;
-  const int64_t pos2 = (int64_t)start2[(int64_t)p * B + b] * kBinGroup + rank;
-  lcol[pos1] = (uint16_t)(cols[src] - b * kBinCols);
+  const int64_t pos1 = (int64_t)start1[key] * ge + rank;
+  const int64_t pos2 = (int64_t)start2[(int64_t)p * B + b] * ge + rank;
+  lcol[pos1] = (uint16_t)(cols[src] - b * bcols);
   if (vals) vals1[pos1] = vals[src];
   lrow[pos2] = (uint16_t)(vrows[src] - panel_row[p]);
 }
@@ -744,12 +747,12 @@ __global__ void bin_ptr_kernel(int B, int P, const unsigned *__restrict__ start1
   if (k <= P) bin_ptr[k] = start2[k * B];
 }
 
-static int build_binned_impl(DeviceCsr &A, hipStream_t s);
+static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int kw);
 
 // Like the tiled copy, an optimisation: a failed build leaves the matrix on the other kernels.
 int build_binned(DeviceCsr &A, hipStream_t s)
 {
-  const int rc = build_binned_impl(A, s);
+  const int rc = build_binned_impl(A, s, A.binned, 1);
   if (rc != FS_OK || (A.binned && !A.binned->built)) {
     free_binned(A);
     (void)hipGetLastError();
@@ -757,9 +760,26 @@ int build_binned(DeviceCsr &A, hipStream_t s)
   return FS_OK;
 }
 
-static int build_binned_impl(DeviceCsr &A, hipStream_t s)
+// the copy that serves kw = 2 or 4 right-hand sides in one sweep (bsbm_A_mul_B2 / _B4, bcsr_A_mul_B2 / _B4, block CG):
+// the north_star's "LDS-tiled dense B panel" -- a band of kBinCols / kw rows of the row-major X lives in LDS
+int build_binned_k(DeviceCsr &A, int kw, hipStream_t s)
+{
+  if (kw != 2 && kw != 4) return FS_ERR_ARG;
+  BinnedCsr *&slot = kw == 2 ? A.binned2 : A.binned4;
+  (kw == 2 ? A.tried2 : A.tried4) = true;
+  const int rc = build_binned_impl(A, s, slot, kw);
+  if (rc != FS_OK || (slot && !slot->built)) {
+    free_binned_slot(slot);
+    (void)hipGetLastError();
+  }
+  return FS_OK;
+}
+
+static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int kw)
 {
   const Options &o = options();
+  const int bcols = kBinCols / kw;     // columns per band: kw * 8 bytes of X per column, 128 KiB in LDS
+  const int ge = kBinGroup / kw;       // entries per group: a group of products is one 128-byte line
   if (o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz == 0) return FS_OK;
   // (measured on 10 M x 10 M x 16: 0.75 ms against 1.06 ms tiled and 2.99 ms streaming; the two passes move
   // 20.5 bytes per entry at stream speed whatever the size of x, so the copy pays once the matrix is large
@@ -776,21 +796,22 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   const int split = o.tile_split > 0 ? o.tile_split : 256;
   const bool virt = max_len > split;
   BinnedCsr *N = new BinnedCsr();
-  A.binned = N;
+  slot = N;
+  N->kw = kw;
   N->split = virt ? split : 0;
   Scratch<int> vrow_ptr_own;
   const int *vrow_ptr = A.row_ptr;
   int nvrow = A.nrow;
   if (virt) {
-    if (int rc = make_virtual_rows(A, split, s, vrow_ptr_own, &nvrow, &N->vfirst, &N->yv)) return rc;
+    if (int rc = make_virtual_rows(A, split, s, vrow_ptr_own, &nvrow, &N->vfirst, &N->yv, kw)) return rc;
     vrow_ptr = vrow_ptr_own.p;
   }
   N->nvrow = nvrow;
 
   // ---- panels of equal non-zero count, at most R rows: pass 2 runs one workgroup per panel and they all
   // have to finish together; the count is a whole number of generations of resident workgroups -----------
-  int R = o.bin_rows > 0 ? o.bin_rows : kBinRowsMax;
-  if (R > kBinRowsMax) R = kBinRowsMax;
+  int R = o.bin_rows > 0 ? o.bin_rows : kBinRowsMax / kw;
+  if (R > kBinRowsMax / kw) R = kBinRowsMax / kw;   // kw * 8 bytes of Y per row in LDS
   std::vector<int> vp((size_t)nvrow + 1);
   FS_HIP(hipMemcpyAsync(vp.data(), vrow_ptr, sizeof(int) * vp.size(), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
@@ -815,10 +836,11 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   }
   const int P = (int)panel_row.size();
   panel_row.push_back(nvrow);
-  const int B = (A.ncol + kBinCols - 1) / kBinCols;
+  const int B = (A.ncol + bcols - 1) / bcols;
   const int64_t nruns = (int64_t)P * B;
   if (nruns >= (1ll << 28)) return FS_OK;
-  if (o.binning == 1 && (double)A.nnz / (double)nruns < 24.0) return FS_OK;   // padding would dominate
+  // padding would dominate (a run is padded to whole groups: (ge - 1) / 2 entries on average)
+  if (o.binning == 1 && (double)A.nnz / (double)nruns < 1.5 * ge) return FS_OK;
   N->P = P; N->B = B;
   FS_HIP(hipMalloc(&N->panel_row, sizeof(int) * panel_row.size()));
   FS_HIP(hipMemcpyAsync(N->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
@@ -841,8 +863,8 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(start2.alloc((size_t)nruns + 1));
   FS_HIP(hipMalloc(&N->band_ptr, sizeof(unsigned) * ((size_t)B + 1)));
   FS_HIP(hipMalloc(&N->bin_ptr, sizeof(unsigned) * ((size_t)P + 1)));
-  hipLaunchKernelGGL(bin_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, nvrow, A.nnz, P, vrow_ptr, N->panel_row, A.cols,
-                     vrows.p, keys.p);
+  hipLaunchKernelGGL(bin_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, nvrow, A.nnz, P, bcols, vrow_ptr, N->panel_row,
+                     A.cols, vrows.p, keys.p);
   hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
   FS_HIP(hipGetLastError());
   int bits = 1;
@@ -851,7 +873,7 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(tmp.alloc(tmp_bytes));
   FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
   hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, nruns, A.nnz, skeys.p, run_ptr.p);
-  hipLaunchKernelGGL(bin_groups_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, B, P, run_ptr.p, g1.p, g2.p);
+  hipLaunchKernelGGL(bin_groups_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, B, P, ge, run_ptr.p, g1.p, g2.p);
   FS_HIP(hipGetLastError());
   tmp_bytes = 0;
   FS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, g1.p, start1.p, 0u, (size_t)nruns + 1, rocprim::plus<unsigned>(), s));
@@ -865,10 +887,11 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMemcpyAsync(&total_groups, N->band_ptr + B, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
   const int64_t groups = total_groups;
-  // every padded run adds at most kBinGroup - 1 entries: n <= nnz + 15 * nruns < 2^31 + 2^32
-  if (groups >= (1ll << 28)) return FS_OK;
-  N->n = groups * kBinGroup;
-  if (o.binning == 1) {
+  // every padded run adds at most ge - 1 entries: n <= nnz + 15 * nruns < 2^31 + 2^32
+  if (groups >= (1ll << 28) * (int64_t)kw) return FS_OK;   // group indices are 32-bit, entry offsets 64-bit
+  if (groups >= (1ll << 32) - 1) return FS_OK;
+  N->n = groups * ge;
+  if (o.binning == 1 && kw == 1) {
     // two streaming passes (measured 4.6-5.0 TB/s) against what the other kernels reach on this shape
     const double x_bytes = (double)A.ncol * 8;
     const double t_bin = ((double)N->n * (A.vals ? 28.5 : 20.5) + (double)(B + ncu) * kBinCols * 8 + (double)nvrow * 8) / 4.6e12;
@@ -881,21 +904,21 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipMalloc(&N->lcol, sizeof(uint16_t) * np));
   FS_HIP(hipMalloc(&N->lrow, sizeof(uint16_t) * np));
   FS_HIP(hipMalloc(&N->gdst, sizeof(unsigned) * (size_t)groups));
-  FS_HIP(hipMalloc(&N->prod, sizeof(double) * np));
+  FS_HIP(hipMalloc(&N->prod, sizeof(double) * np * (size_t)kw));
   if (A.vals) {
     FS_HIP(hipMalloc(&N->vals, sizeof(double) * np));
     FS_HIP(hipMemsetAsync(N->vals, 0, sizeof(double) * np, s));
   }
-  FS_HIP(hipMemsetD16Async((hipDeviceptr_t)N->lcol, (unsigned short)kBinCols, np, s));
+  FS_HIP(hipMemsetD16Async((hipDeviceptr_t)N->lcol, (unsigned short)bcols, np, s));   // padding: the zero row behind the band
   FS_HIP(hipMemsetAsync(N->lrow, 0, sizeof(uint16_t) * np, s));
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, skeys.p, idx_out.p, vrows.p,
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, bcols, ge, skeys.p, idx_out.p, vrows.p,
                      N->panel_row, A.cols, A.vals, run_ptr.p, start1.p, start2.p, N->lcol, N->vals, N->lrow);
   hipLaunchKernelGGL(bin_gdst_kernel, dim3(grid_for(nruns)), dim3(256), 0, s, B, P, start1.p, start2.p, N->gdst);
   FS_HIP(hipGetLastError());
 
   // ---- pass-1 work: one persistent workgroup per CU, fewer when the shares would be tiny --------------------
   {
-    const int64_t by_size = (N->n + kBinShareMin - 1) / kBinShareMin;
+    const int64_t by_size = (N->n * kw + kBinShareMin - 1) / kBinShareMin;
     N->nwg1 = (int)(by_size < ncu ? by_size : ncu);
   }
   FS_HIP(hipStreamSynchronize(s));

@@ -628,6 +628,61 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(int nrow, int k, const int
 }
 
 // ------------------------------------------------------------------------------------------
+// Y = A X on the matrix cores: the experiment BASELINE.json's north_star asks for ("MFMA only to the dense panel
+// accumulate"), kept as an opt-in kernel (option spmm_kernel = 4) so that its counters can be put next to the row
+// kernel's.  One wave per CSR row.  v_mfma_f64_16x16x4_f64 computes D(16x16) += A(16x4) B(4x16) with ONE f64 of A and
+// of B per lane (lane l: A[l & 15][l >> 4], B[l >> 4][l & 15]; D[(l >> 4) + 4 reg][l & 15]).  A row of Y is a sum of
+// scaled rows of X, so B = four gathered rows of X (16 columns of them) and A carries the row's four values in
+// its row 0 only: the columns of different CSR rows are unrelated, nothing else can share B -- 1/16 of the
+// multiply-adds of an instruction are useful, which is the structural answer to "how much of this SpMM is a GEMM".
+// The multiply-adds inside the instruction are fused (one rounding), so results agree with the strict CPU order
+// to rounding (1e-12 bar), bit for bit only for pattern matrices with integer-valued X.
+// ------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <bool VALUED>
+__global__ __launch_bounds__(kBlock) void spmm_mfma_kernel(int nrow, int k, const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ cols, const double *__restrict__ vals,
+                                                          const double *__restrict__ X, double *__restrict__ Y)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= nrow) return;                       // whole waves leave together
+  const int a = row_ptr[row], b = row_ptr[row + 1];
+  const int kk = lane >> 4, jj = lane & 15;
+  for (int j0 = 0; j0 < k; j0 += 32) {
+    const int c0 = j0 + jj, c1 = j0 + 16 + jj;
+    const int c0c = c0 < k ? c0 : k - 1, c1c = c1 < k ? c1 : k - 1;   // clamped: loads stay unconditional
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int base = a; base < b; base += 16) {
+      // 16 entries per round: four MFMA steps, eight X loads per lane in flight
+      double av[4], b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = base + 4 * u + kk;
+        const int ec = e < b ? e : b - 1;
+        const int c = cols[ec];
+        const double v = VALUED ? vals[ec] : 1.0;
+        av[u] = (jj == 0 && e < b) ? v : 0.0;     // row 0 of A; entries past the row's end contribute 0
+        b0[u] = X[(int64_t)c * k + c0c];
+        b1[u] = X[(int64_t)c * k + c1c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (base + 4 * u < b) {                   // wave-uniform
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], b0[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], b1[u], acc1, 0, 0, 0);
+        }
+      }
+    }
+    if (kk == 0) {                                // D row 0 lives in register 0 of lanes 0-15
+      if (c0 < k) Y[row * k + c0] = acc0.x;
+      if (c1 < k) Y[row * k + c1] = acc1.x;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Column-blocked binary CSR (cbcsr_A_mul_B, cbcsr.h:76-106): cell = block*nrow + row.
 // One thread per row; the workgroup walks the column blocks in order, so every row adds its
 // cell sums block by block (the order one CPU thread produces).  With STAGE the x tile of the
@@ -815,6 +870,169 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
   for (int i = t; i < nr; i += kBinBlock) y[(int64_t)(r0 + i) * ys] = ytile[i];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Y = A X for K = 2 or 4 row-major right-hand sides in ONE sweep of a two-pass copy built with bands of
+// kBinCols / K columns (BinnedCsr::kw == K): the north_star's "LDS-tiled dense B panel".
+//   replaces bcsr_A_mul_B2 / _B4 (csr.h:164-202), bsbm_A_mul_B2 / _B4 (sparse.h:276-315), csr_A_mul_Bn /
+//   bcsr_A_mul_Bn / bsbm_A_mul_Bn with ncol = 2, 4 (csr.h:441-465, 257-280, sparse.h:318-336) and the two
+//   products of every bsbm_cg2 iteration (cg.h:134-135).
+// Pass 1 keeps a band of X -- kBinCols / K rows of K doubles, 128 KiB -- in LDS; an entry is read once (2-byte
+// local column, value) and gives K products, written as one 128-byte line per group of kBinGroup / K entries to
+// the place of its run in (panel, band) order.  Pass 2 keeps the K-column Y slice of a panel (<= kBinRowsMax / K
+// rows) in LDS and adds the products up.  Per entry: 2 + 8 + 8K written + 8K read + 2 bytes, against K times
+// 28.25 for K sweeps of the single-vector pair.  Sum order as the single-vector pair (band-major, LDS atomics).
+// ------------------------------------------------------------------------------------------
+template <bool VALUED, int K, int U>
+__global__ __launch_bounds__(kBinBlock) void spmm_expand_kernel(
+    int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
+    const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ X, int xs,
+    double *__restrict__ prod)
+{
+  constexpr int BC = kBinCols / K;       // columns per band
+  constexpr int GE = kBinGroup / K;      // entries per group
+  constexpr int LP = K / 2;              // lanes per entry: every lane owns two neighbouring products (one 16-byte store)
+  constexpr int EPS = kBinBlock / LP;    // entries per step of the workgroup
+  __shared__ double xband[kBinCols + 8];  // [BC][K]; row BC is the zero row the padding entries point at
+  const int t = threadIdx.x;
+  const int le = t / LP, h = t % LP;
+  const uint64_t groups = band_ptr[B];
+  const unsigned g0 = (unsigned)(groups * blockIdx.x / gridDim.x), g1 = (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
+  if (g0 >= g1) return;
+  int b;
+  {
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo + 1) >> 1);
+      if (band_ptr[mid] <= g0) lo = mid; else hi = mid - 1;
+    }
+    b = lo;
+  }
+  for (unsigned g = g0; g < g1; ++b) {
+    const unsigned gb = band_ptr[b + 1] < g1 ? band_ptr[b + 1] : g1;
+    if (gb <= g) continue;
+    const int c0 = b * BC;
+    const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
+    __syncthreads();
+    {
+      // the band: rows c0 .. c0+w of X, K doubles each (contiguous when xs == K); 16 loads per thread in flight
+      double r[kBinCols / kBinBlock];
+#pragma unroll
+      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+        const int f = j * kBinBlock + t, i = f / K, q = f % K;
+        r[j] = __builtin_nontemporal_load(X + (int64_t)(c0 + (i < w ? i : w - 1)) * xs + q);
+      }
+#pragma unroll
+      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+        const int f = j * kBinBlock + t;
+        xband[f] = (f / K < w) ? r[j] : 0.0;
+      }
+      if (t < 8) xband[kBinCols + t] = 0.0;
+    }
+    __syncthreads();
+    const int64_t e0 = (int64_t)g * GE, e1 = (int64_t)gb * GE;
+    constexpr int64_t kRound = (int64_t)U * EPS;
+    int64_t o = e0 + le;
+    for (; o - le + kRound <= e1; o += kRound) {
+      unsigned a[U], d[U];
+      double v[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t e = o + (int64_t)k * EPS;
+        a[k] = lcol[e];
+        d[k] = gdst[e / GE];
+        if (VALUED) v[k] = vals[e];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t e = o + (int64_t)k * EPS;
+        v2d p = *reinterpret_cast<const v2d *>(&xband[a[k] * K + 2 * h]);
+        if (VALUED) { p.x *= v[k]; p.y *= v[k]; }
+        __builtin_nontemporal_store(p, (v2d *)(prod + ((int64_t)d[k] * GE + (e % GE)) * K + 2 * h));
+      }
+    }
+    for (; o < e1; o += EPS) {
+      const unsigned a = lcol[o];
+      const unsigned d = gdst[o / GE];
+      v2d p = *reinterpret_cast<const v2d *>(&xband[a * K + 2 * h]);
+      if (VALUED) { const double v = vals[o]; p.x *= v; p.y *= v; }
+      __builtin_nontemporal_store(p, (v2d *)(prod + ((int64_t)d * GE + (o % GE)) * K + 2 * h));
+    }
+    g = gb;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(kBinBlock) void spmm_reduce_kernel(
+    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
+    const double *__restrict__ prod, double *__restrict__ Y, int ys)
+{
+  constexpr int GE = kBinGroup / K;
+  constexpr int EPL = 8 / K;             // entries per lane and step: 64 bytes of products
+  __shared__ double ytile[kBinRowsMax];  // [rows of the panel][K]
+  const int t = threadIdx.x;
+  const int r0 = panel_row[blockIdx.x], nr = panel_row[blockIdx.x + 1] - r0;
+  for (int i = t; i < nr * K; i += kBinBlock) ytile[i] = 0.0;
+  __syncthreads();
+  const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * GE, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * GE;
+  typedef uint16_t rows_t __attribute__((ext_vector_type(EPL)));
+#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+  auto add8 = [&](const rows_t a, const v2d (&p)[4]) {
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+      const int base = (int)a[q] * K;
+#pragma unroll
+      for (int j = 0; j < K; j += 2) {
+        FS_ADD(base + j, p[(q * K + j) / 2].x);
+        FS_ADD(base + j + 1, p[(q * K + j) / 2].y);
+      }
+    }
+  };
+  constexpr int64_t kStep = (int64_t)EPL * kBinBlock;
+  constexpr int64_t kRound = 2 * kStep;
+  int64_t e = e0 + (int64_t)EPL * t;
+  for (; e - EPL * t + kRound <= e1; e += kRound) {
+    rows_t a[2];
+    v2d p[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t ek = e + k * kStep;
+      a[k] = *reinterpret_cast<const rows_t *>(lrow + ek);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[k][j] = *reinterpret_cast<const v2d *>(prod + ek * K + 2 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    add8(a[0], p[0]);
+    add8(a[1], p[1]);
+  }
+  for (; e < e1; e += kStep) {
+    const rows_t a = *reinterpret_cast<const rows_t *>(lrow + e);
+    v2d p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const v2d *>(prod + e * K + 2 * j);
+    add8(a, p);
+  }
+#undef FS_ADD
+  __syncthreads();
+  for (int i = t; i < nr * K; i += kBinBlock) Y[(int64_t)(r0 + i / K) * ys + (i % K)] = ytile[i];
+}
+
+// Y[r, 0:K] = sum of the virtual rows of row r, in storage order (yv holds K doubles per virtual row)
+template <int K>
+__global__ __launch_bounds__(kBlock) void tiled_combine_k_kernel(int nrow, const int *__restrict__ vfirst,
+                                                                const double *__restrict__ yv, double *__restrict__ Y, int ys)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t r = i / K;
+  const int j = (int)(i % K);
+  if (r >= nrow) return;
+  const int a = vfirst[r], b = vfirst[r + 1];
+  double acc = yv[(int64_t)a * K + j];
+  for (int v = a + 1; v < b; ++v) acc += yv[(int64_t)v * K + j];
+  Y[r * ys + j] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -920,6 +1138,38 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   return FS_OK;
 }
 
+// one sweep of a k-column two-pass copy: Y[:, 0:kw] = A X[:, 0:kw]; X / Y rows are xs / ys doubles apart
+int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys)
+{
+  const int K = N.kw;
+  double *out = N.split ? N.yv : Y;
+  const int os = N.split ? K : ys;
+  const int nwg1 = (options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1;
+#define FS_XP(V, KK)                                                                                                  \
+  hipLaunchKernelGGL((spmm_expand_kernel<V, KK, 4>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol, \
+                     N.vals, N.gdst, X, xs, N.prod)
+  if (nwg1 > 0) {
+    if (K == 2) { if (A.vals) FS_XP(true, 2); else FS_XP(false, 2); }
+    else        { if (A.vals) FS_XP(true, 4); else FS_XP(false, 4); }
+    FS_HIP(hipGetLastError());
+  }
+#undef FS_XP
+  if (K == 2)
+    hipLaunchKernelGGL(spmm_reduce_kernel<2>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+  else
+    hipLaunchKernelGGL(spmm_reduce_kernel<4>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+  FS_HIP(hipGetLastError());
+  if (N.split) {
+    const unsigned grid = (unsigned)(((int64_t)A.nrow * K + kBlock - 1) / kBlock);
+    if (K == 2)
+      hipLaunchKernelGGL(tiled_combine_k_kernel<2>, dim3(grid), dim3(kBlock), 0, s, A.nrow, N.vfirst, N.yv, Y, ys);
+    else
+      hipLaunchKernelGGL(tiled_combine_k_kernel<4>, dim3(grid), dim3(kBlock), 0, s, A.nrow, N.vfirst, N.yv, Y, ys);
+    FS_HIP(hipGetLastError());
+  }
+  return FS_OK;
+}
+
 // diagnostic: one launch of the tiled kernel that also records, per work item, the start time
 // (100 MHz wall clock) and, per panel, the XCD that ran it
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
@@ -992,29 +1242,56 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
   return FS_OK;
 }
 
-int launch_spmm(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
+int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
-  // two right-hand sides (the block-CG case, bsbm_A_mul_B2 / bcsr_A_mul_B2) on a matrix with an L2-tiled copy:
-  // one tiled sweep per column of the
-  // row-major X / Y (strided gathers and stores) beats the row kernel, whose every X-row gather misses L2
-  // (three sweeps of the two-pass pair: 3.0 ms on config 2 against 3.8 ms for the row kernel; four: 4.0 against 3.5)
-  if (k <= 3 && A.binned && A.binned->built && !options().strict_order && !options().reproducible &&
-      (options().spmv_kernel == 0 || options().spmv_kernel == 7)) {
+  const Options &o = options();
+  const bool free_order = !o.strict_order && !o.reproducible;   // the two-pass kernels add in arrival order
+  // k = 2, 3, 4 on a matrix large enough for the two-pass kernels: ONE sweep with a k-column band of X in LDS
+  // (k = 3: a 2-column sweep and a single-vector sweep).  The copy is built on the first such product.
+  // spmm_kernel: 0 auto, 1 row kernel, 2 k-column two-pass sweep (fails over to the row kernel when the builder
+  // declines), 3 one single-vector sweep per column
+  const int want = o.spmm_kernel;
+  // (only where the format builder kept the two-pass copy for the single-vector product: that is the class of
+  // matrices -- large x, thin tiles -- on which streaming products beats gathering; config 3's dense tiles stay on
+  // the LDS-staged kernel, two sweeps of 0.9 ms against 36 bytes per entry here)
+  if (free_order && k >= 2 && k <= 4 && (want == 0 || want == 2) && o.binning != 0 && (o.spmv_kernel == 0 || o.spmv_kernel == 7) &&
+      ((A.binned && A.binned->built) || o.binning == 2 || want == 2)) {
+    const int kw = k == 4 ? 4 : 2;
+    BinnedCsr *&slot = kw == 2 ? A.binned2 : A.binned4;
+    if (!slot && !(kw == 2 ? A.tried2 : A.tried4)) {
+      if (int rc = build_binned_k(A, kw, s)) return rc;
+    }
+    const bool tail_ok = k != 3 || (A.binned && A.binned->built);
+    if (slot && slot->built && tail_ok) {
+      if (int rc = launch_spmm_binned(A, *slot, Y, X, s, k, k)) return rc;
+      if (k == 3) return launch_spmv_binned(A, Y + 2, X + 2, s, k, k);
+      return FS_OK;
+    }
+  }
+  // column by column on the single-vector kernels (strided gathers and stores) where that beats the row kernel, whose
+  // every X-row gather misses L2 (three sweeps of the two-pass pair: 3.0 ms on config 2 against 3.8 ms for the row
+  // kernel; four: 4.0 against 3.5)
+  if (want != 1 && (k <= 3 || want == 3) && A.binned && A.binned->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) {
     for (int j = 0; j < k; ++j)
       if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
     return FS_OK;
   }
-  if (k <= 2 && A.tiledx && A.tiledx->built && !options().strict_order && !options().reproducible &&
-      (options().spmv_kernel == 0 || options().spmv_kernel == 8)) {
+  if (want != 1 && k <= 2 && A.tiledx && A.tiledx->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) {
     for (int j = 0; j < k; ++j)
       if (int rc = launch_spmv_tiled(A, *A.tiledx, Y + j, X + j, s, k, k)) return rc;
     return FS_OK;
   }
-  if (k <= 2 && A.tiled && A.tiled->built && !options().strict_order &&
-      (options().spmv_kernel == 0 || options().spmv_kernel == 6)) {
+  if (want != 1 && k <= 2 && A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) {
     for (int j = 0; j < k; ++j)
       if (int rc = launch_spmv_tiled(A, *A.tiled, Y + j, X + j, s, k, k)) return rc;
+    return FS_OK;
+  }
+  if (want == 4) {   // the matrix-core experiment (see spmm_mfma_kernel)
+    const unsigned g4 = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
+    if (A.vals) hipLaunchKernelGGL(spmm_mfma_kernel<true>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
+    else        hipLaunchKernelGGL(spmm_mfma_kernel<false>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
+    FS_HIP(hipGetLastError());
     return FS_OK;
   }
   const int lg = ceil_log2(k > 64 ? 64 : k);

@@ -166,6 +166,39 @@ FSO_API void fso_csr_mul_n(double *Y, int nrow, const int *row_ptr, const int *c
   }
 }
 
+/* The same product with the reference's own OpenMP structure (csr.h:445-448 /
+ * 260-263): an `omp parallel for` nested inside an `omp parallel` region.  With
+ * nested parallelism off (libgomp's default) the inner region gets a team of
+ * one, so EVERY thread of the outer team walks all rows and writes the same
+ * values (SURVEY note N4): the results equal fso_csr_mul_n's, the time is what
+ * the reference costs as shipped.  Used only by bench.py's cpu_baseline leg,
+ * which reports both schedules, labelled. */
+FSO_API void fso_csr_mul_n_reference_schedule(double *Y, int nrow, const int *row_ptr, const int *cols,
+                                              const double *vals, const double *X, int k)
+{
+#pragma omp parallel
+  {
+    double *acc = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int r = 0; r < nrow; r++) {
+      for (int j = 0; j < k; j++) acc[j] = 0;
+      int64_t e = row_ptr[r + 1];
+      for (int64_t i = row_ptr[r]; i < e; i++) {
+        const double *xr = X + (int64_t)cols[i] * k;
+        if (vals) {
+          double v = vals[i];
+          for (int j = 0; j < k; j++) acc[j] += xr[j] * v;
+        } else {
+          for (int j = 0; j < k; j++) acc[j] += xr[j];
+        }
+      }
+      double *yr = Y + (int64_t)r * k;
+      for (int j = 0; j < k; j++) yr[j] = acc[j];
+    }
+    free(acc);
+  }
+}
+
 /* y = A'A x on a binary CSR, serial (bcsr_AA_mul_B, csr.h:305-319).  With one
  * thread parallel_bcsr_AA_mul_B (csr.h:323-355) performs the same additions in
  * the same order (its single ytmp replica is summed onto 0.0). */

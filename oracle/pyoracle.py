@@ -55,6 +55,8 @@ def load(path=None):
     lib.fso_coo_to_cbcsr.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p]
     lib.fso_csr_mul.argtypes = [_f64p, C.c_int, _i32p, _i32p, C.c_void_p, _f64p]
     lib.fso_csr_mul_n.argtypes = [_f64p, C.c_int, _i32p, _i32p, C.c_void_p, _f64p, C.c_int]
+    lib.fso_csr_mul_n_reference_schedule.argtypes = lib.fso_csr_mul_n.argtypes
+    lib.fso_csr_mul_n_reference_schedule.restype = None
     lib.fso_bcsr_aa_mul.argtypes = [_f64p, C.c_int, C.c_int, _i32p, _i32p, _f64p]
     lib.fso_coo_mul.argtypes = [_f64p, C.c_int, C.c_int64, _i32p, _i32p, C.c_void_p, _f64p]
     lib.fso_coo_tmul.argtypes = [_f64p, C.c_int, C.c_int64, _i32p, _i32p, C.c_void_p, _f64p]

@@ -92,6 +92,15 @@ def _worker(rank, world, port, mode, ret):
         h2 = opr.reduce_async(z3)
         h2.wait()
         ok = ok and np.array_equal(y3.numpy(), ref) and np.array_equal(z3.numpy(), z2.numpy())
+        # the config-5 scheme for A'u (bench.py --workload c5): shard of A' straight from the local CSR, product with
+        # the replicated u, all-gather of the z slices -- bit-identical to the column sums in ascending-row order
+        br, bc, bv = fsd.build_transposed_shard(torch.from_numpy(lrp), torch.from_numpy(lcc), torch.from_numpy(lvv), lo, cb)
+        ok = ok and torch.equal(br, tr) and torch.equal(bc, tc) and torch.equal(bv, tv)
+        opg = fsd.TransposedGatherOperator(local_tspmv, cb)
+        z4 = torch.full((n,), -1.0, dtype=torch.float64)
+        hz = opg.gather_async(z4, opg.local(z4, torch.from_numpy(x)))
+        hz.wait()
+        ok = ok and np.array_equal(z4.numpy(), zref)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -113,3 +122,118 @@ def test_partitions():
     rp = np.array([0, 100, 101, 102, 103, 200], np.int64)
     b = fsd.nnz_balanced_partition(rp, 2)
     assert b[0] == 0 and b[-1] == 5 and 1 <= b[1] <= 4
+
+
+# ---- bench.py --workload c5 rehearsed on CPU: 8 gloo ranks, the oracle behind bench.py's provider interface -----------
+class _Ev:
+    def record(self):
+        import time
+        self.t = time.perf_counter()
+
+
+class OracleProvider:
+    """bench.HipProvider's interface on CPU tensors with the oracle as the local product (test infrastructure)"""
+    name, dev = "oracle", "cpu"
+
+    def __init__(self):
+        import bench
+        from oracle import pyoracle, pysynth
+        self.B, self.O, self.L = bench, pyoracle, pysynth._lib()
+
+    def stream(self):
+        return None
+
+    def synchronize(self):
+        pass
+
+    def event(self):
+        return _Ev()
+
+    def elapsed_ms(self, e0, e1):
+        return max((e1.t - e0.t) * 1e3, 1e-6)
+
+    def empty(self, n, dtype=None):
+        return torch.full((n,), -1.0, dtype=dtype or torch.float64)
+
+    def sin_vector(self, n, a, b):
+        return torch.sin(a * torch.arange(n, dtype=torch.float64) + b)
+
+    def powerlaw_lengths(self, nrow, row_offset):
+        lens = np.empty(nrow, np.int32)
+        self.L.fso_synth_powerlaw_lengths(nrow, self.B.C5_SCALE, self.B.C5_MAXLEN, self.B.SEED_C5, row_offset, lens)
+        return torch.from_numpy(lens)
+
+    def fill(self, row_ptr, ncol, row_offset, valued=True):
+        rp = row_ptr.numpy()
+        cc = np.empty(int(rp[-1]), np.int32)
+        vv = np.empty(int(rp[-1]), np.float64)
+        self.L.fso_synth_fill(len(rp) - 1, ncol, self.B.SEED_C5, row_offset, rp, cc, vv.ctypes.data)
+        return torch.from_numpy(cc), torch.from_numpy(vv)
+
+    class _M:
+        def __init__(self, nrow, rp, cc, vv):
+            self.nrow, self.rp, self.cc, self.vv, self.nnz = nrow, rp, cc, vv, len(cc)
+
+    def csr(self, nrow, ncol, rp, cc, vv):
+        return self._M(nrow, rp.numpy(), cc.numpy(), vv.numpy())
+
+    def coo(self, nrow, ncol, rows, cols, vals):
+        rp, cc, vv = self.O.coo_to_csr(nrow, rows.numpy(), cols.numpy(), vals.numpy())
+        return self._M(nrow, rp, cc, vv)
+
+    def spmv(self, A, y, x, transposed=False):
+        y.copy_(torch.from_numpy(self.O.csr_mul(A.nrow, A.rp, A.cc, A.vv, x.numpy())))
+
+
+def _c5_worker(rank, world, port, n, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import argparse
+        import bench
+        from oracle import pyoracle as O
+        from oracle import pysynth
+        prov = OracleProvider()
+        args = argparse.Namespace(c5_rows=n, steps=2, warmup=1, transpose=True)
+        out = {}
+        rec = bench.run_c5(args, prov, world, rank, False, out=out)
+        # the whole matrix on every rank (it is small here) with the same generator: the gathered y must be the
+        # oracle's product bit for bit (rows are independent), z the column sums in ascending-row order
+        rp, cc, vv = pysynth.powerlaw(n, n, bench.C5_SCALE, bench.C5_MAXLEN, bench.SEED_C5)
+        x = prov.sin_vector(n, 7.0, 0.3).numpy()
+        u = prov.sin_vector(n, 11.0, -0.2).numpy()
+        ok = np.array_equal(out["y"].numpy(), O.csr_mul(n, rp, cc, vv, x))
+        rows_all = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+        ok = ok and out["z"] is not None and np.array_equal(out["z"].numpy(), O.coo_tmul(n, rows_all, cc, vv, u))
+        b = out["bounds"]
+        per = [int(rp[b[i + 1]] - rp[b[i]]) for i in range(world)]
+        ok = ok and b[0] == 0 and b[-1] == n and max(per) - min(per) <= 2 * int(np.diff(rp).max())
+        ok = ok and len(set(np.diff(b))) > 1            # the shards really are unequal: the padded async gather ran
+        if rank == 0:
+            ok = ok and rec is not None and rec["n_gpus"] == world and rec["value"] > 0 and rec["config"]["self_check"]["ok"] \
+                and rec["config"]["transpose_error"] is None and rec["config"]["total_nnz"] == int(rp[-1])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_c5_workload_rehearsed_on_eight_gloo_ranks():
+    """`bench.py --workload c5 --gpus 8 --transpose` with small rows per rank: nnz-balanced cut of a power-law matrix,
+    local products, asynchronous all-gather of UNEQUAL y shards, A'u by exchanged row shards of A' + all-gather"""
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_c5_worker, args=(world, _free_port(), 60_000, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
+    """--gpus 8 under a launcher that started one rank must fail loudly (it used to run one rank and print n_gpus 1);
+    without a launcher bench.py starts the ranks itself (exercised on the GPU box)"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)

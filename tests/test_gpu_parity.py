@@ -817,3 +817,92 @@ def test_fuzz_every_forced_copy_small_shapes(hip):
     finally:
         for k_ in ("tile_rows", "tile_cols", "bin_rows", "tile_split"):
             capi.set_option(k_, 0)
+
+
+@pytest.mark.parametrize("valued", [False, True])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_spmm_k_columns_in_one_two_pass_sweep(hip, k, valued):
+    """k = 2, 3, 4 right-hand sides on the k-column two-pass copy (a k-column band of the row-major X in LDS, k products
+    per entry: bcsr_A_mul_B2/_B4 csr.h:164-202, bsbm_A_mul_B2/_B4/_Bn sparse.h:276-336, csr_A_mul_Bn csr.h:441-465):
+    4.8 M non-zeros, ragged rows (some cut into virtual rows), 3 M columns = hundreds of bands with a partial last one;
+    every element against the oracle within the row-scaled bar, pattern-only + integer X bit for bit, and the copy
+    really was the one that ran (the forced row kernel gives storage-order sums = the oracle's bits)"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(100 + k)
+    nrow, ncol = 400_000, 3_000_001
+    lens = rng.integers(0, 25, nrow)
+    lens[777] = 3000
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    cc[:40] = ncol - 1
+    vv = rng.uniform(-1, 1, nnz) if valued else None
+    st = capi.current_stream()
+    capi.set_option("binning", 2)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+        assert A.kernel_name() == "two-pass"
+        Xs = [S.X_sin(ncol, k)]
+        if not valued:
+            Xs.append(np.ascontiguousarray(np.stack([S.x_int(31 + j, ncol) for j in range(k)], 1)))
+        for X in Xs:
+            Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
+            got = Y.cpu().numpy()
+            ref = O.csr_mul_n(nrow, rp, cc, vv, X, k)
+            if not valued and np.all(X == np.round(X)):
+                assert np.array_equal(got, ref)
+            else:
+                for j in range(k):
+                    sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X[:, j]))
+                    assert np.all(np.abs(got[:, j] - ref[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
+            capi.set_option("spmm_kernel", 1)        # row kernel: storage order, the oracle's bits
+            try:
+                A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
+            finally:
+                capi.set_option("spmm_kernel", 0)
+            assert np.array_equal(Y.cpu().numpy(), ref)
+            if valued:
+                assert not np.array_equal(got, ref), "the k-column sweep adds band-major: identical bits mean it did not run"
+    finally:
+        capi.set_option("binning", 1)
+
+
+@pytest.mark.parametrize("k", [2, 4, 7, 16, 32, 40])
+def test_spmm_matrix_core_experiment(hip, k):
+    """spmm_kernel = 4: the v_mfma_f64_16x16x4_f64 row kernel (one wave per row, the row's values in row 0 of A, four
+    gathered X rows as B).  Same results as the row kernel to rounding (the instruction fuses multiply and add), bit
+    for bit for pattern-only matrices with integer X; empty rows, one long row, k not a multiple of 16"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(7 * k)
+    nrow, ncol = 30_000, 20_000
+    lens = rng.integers(0, 40, nrow)
+    lens[5] = 1234
+    lens[rng.uniform(size=nrow) < 0.05] = 0
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    st = capi.current_stream()
+    capi.set_option("spmm_kernel", 4)
+    try:
+        for vv, X in ((rng.uniform(-1, 1, nnz), S.X_sin(ncol, k)),
+                      (None, np.ascontiguousarray(np.stack([S.x_int(3 + j, ncol) for j in range(k)], 1)))):
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+            Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
+            got = Y.cpu().numpy()
+            ref = O.csr_mul_n(nrow, rp, cc, vv, X, k)
+            if vv is None:
+                assert np.array_equal(got, ref)
+            else:
+                for j in range(k):
+                    sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X[:, j]))
+                    assert np.all(np.abs(got[:, j] - ref[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
+    finally:
+        capi.set_option("spmm_kernel", 0)
