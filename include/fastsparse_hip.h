@@ -146,6 +146,11 @@ int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream);
 void fs_invalidate(const void *host_struct);
 /* drop every cached device copy */
 void fs_release_all(void);
+/* number of device copies currently in the side table.  The table is bounded (FS_DROPIN_MAX_ENTRIES, default 64:
+ * the least recently used idle copy goes first) and a copy whose build runs out of HBM is retried after every idle
+ * copy has been dropped.  Environment, read once: FS_STRICT_CACHE=1 hashes every host array in full on every call
+ * (default: in full up to 8 MB per matrix, 2048 samples per array beyond), FS_DROPIN_CACHE=0 reuses nothing. */
+int fs_cache_entries(void);
 
 /* ---- synthetic inputs for bench/tests (counter-based, identical to oracle/fs_synth.c) -- */
 /* exactly per_row entries per row, columns uniform on [0,ncol), vals uniform(-1,1) (vals may be NULL) */

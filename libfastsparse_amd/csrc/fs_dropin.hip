@@ -4,8 +4,11 @@
 // Contract of every product below:
 //   * the matrix argument is the reference's host struct; its device copy is made on first
 //     use and kept in a side table keyed by (struct address, variant).  An entry is reused
-//     only while the struct's dimensions, array pointers and a sampled fingerprint of the
-//     index arrays are unchanged; otherwise it is rebuilt.  fs_invalidate()/free_*() drop it.
+//     only while the struct's dimensions, array pointers and a fingerprint of the arrays (full
+//     for small matrices, sampled for large ones: see "fingerprints" below; FS_STRICT_CACHE=1 /
+//     FS_DROPIN_CACHE=0 change that) are unchanged; otherwise it is rebuilt.  fs_invalidate(),
+//     free_sbm/free_bcsr/free_csr, transpose and the sort_* functions drop it.  Entries are
+//     ref-counted: a copy in use by another host thread outlives its removal from the table.
 //   * x / y may be host or device pointers (hipPointerGetAttributes decides); host vectors are
 //     staged through per-thread device buffers.  The call returns after y is complete.
 //   * y is overwritten, never accumulated into (SURVEY.md note N5).
@@ -13,6 +16,9 @@
 //     exits -- there is no CPU fallback.
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
@@ -34,28 +40,71 @@ namespace {
 #define FS_MUST(expr, who) do { if ((expr) != FS_OK) die(who); } while (0)
 
 // ---- fingerprints ------------------------------------------------------------------------------
+// An entry of the side table is reused only while the host struct still describes the same matrix.  Dimensions and
+// array pointers are always compared.  The CONTENTS of the arrays are hashed IN FULL while that is cheap (at most
+// kFullHashBytes in all: re-reading 8 MB of host memory costs less than the PCIe copy of the vectors it rides with),
+// otherwise at 2048 strided samples per array plus both ends -- enough to notice a re-sort, a transpose or a reload,
+// not a handful of entries edited in place at the same addresses.  Callers who edit large matrices in place either
+// call fs_invalidate(A) (what this library's own sort_* / transpose / free_* do) or set FS_STRICT_CACHE=1 (every
+// array hashed in full on every call: a call then costs a pass over the host arrays) or FS_DROPIN_CACHE=0 (nothing
+// is reused: every call uploads).  Both switches are read once.
+constexpr int64_t kFullHashBytes = 8 << 20;
+
+int env_int(const char *name, int dflt)
+{
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+bool strict_cache() { static const bool v = env_int("FS_STRICT_CACHE", 0) != 0; return v; }
+bool cache_enabled() { static const bool v = env_int("FS_DROPIN_CACHE", 1) != 0; return v; }
+size_t max_entries() { static const int v = env_int("FS_DROPIN_MAX_ENTRIES", 64); return (size_t)(v > 0 ? v : 1); }
+
 uint64_t mix(uint64_t h, uint64_t v)
 {
   h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
   return h;
 }
 
-// up to 2048 strided samples plus both ends
-uint64_t sample_ints(uint64_t h, const int *a, int64_t n)
+// every byte: four independent multiply-rotate lanes over 8-byte words (about 10 GB/s on one core)
+uint64_t hash_bytes(uint64_t h, const void *p, size_t n)
+{
+  const unsigned char *b = (const unsigned char *)p;
+  uint64_t l[4] = {h ^ 0x243F6A8885A308D3ull, h ^ 0x13198A2E03707344ull, h ^ 0xA4093822299F31D0ull, h ^ 0x082EFA98EC4E6C89ull};
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    memcpy(w, b + i, 32);
+    for (int k = 0; k < 4; k++) {
+      l[k] = (l[k] ^ w[k]) * 0x9E3779B97F4A7C15ull;
+      l[k] = (l[k] << 29) | (l[k] >> 35);
+    }
+  }
+  uint64_t tail = 0;
+  for (int k = 0; i < n; ++i, ++k) tail = (tail << 8) | b[i];   // n - i < 32: at most 4 words' worth, folded into one
+  return mix(mix(mix(mix(mix(h, l[0]), l[1]), l[2]), l[3]), tail ^ (uint64_t)n);
+}
+
+// `full`: hash everything; otherwise up to 2048 strided samples plus both ends
+uint64_t print_ints(uint64_t h, const int *a, int64_t n, bool full)
 {
   if (!a || n <= 0) return mix(h, 0);
+  if (full) return hash_bytes(h, a, sizeof(int) * (size_t)n);
   const int64_t step = n > 2048 ? n / 2048 : 1;
   for (int64_t i = 0; i < n; i += step) h = mix(h, (uint64_t)(unsigned)a[i]);
   return mix(h, (uint64_t)(unsigned)a[n - 1]);
 }
 
-uint64_t sample_doubles(uint64_t h, const double *a, int64_t n)
+uint64_t print_doubles(uint64_t h, const double *a, int64_t n, bool full)
 {
   if (!a || n <= 0) return mix(h, 0);
+  if (full) return hash_bytes(h, a, sizeof(double) * (size_t)n);
   const int64_t step = n > 2048 ? n / 2048 : 1;
   for (int64_t i = 0; i < n; i += step) { uint64_t b; memcpy(&b, a + i, 8); h = mix(h, b); }
-  return h;
+  uint64_t e; memcpy(&e, a + n - 1, 8);
+  return mix(h, e);
 }
+
+bool hash_in_full(int64_t bytes) { return strict_cache() || bytes <= kFullHashBytes; }
 
 // ---- side table ------------------------------------------------------------------------------------
 enum Variant { kDirect = 0, kTransposed = 1 };
@@ -68,33 +117,69 @@ struct Key {
 struct KeyHash {
   size_t operator()(const Key &k) const { return std::hash<const void *>()(k.host) * 31u + (size_t)k.variant; }
 };
+// An entry is handed out as a shared_ptr and held by the caller across its launch: free_*() / fs_invalidate() /
+// a rebuild from another host thread only take it out of the table, the device copy itself lives until the last
+// product using it has returned (bench_a_mul_b.c:401-421 runs two host threads over shared matrices).
 struct Entry {
   fs_matrix_t m = nullptr;
   fs_cbcsr_t cb = nullptr;
   uint64_t print = 0;
+  uint64_t tick = 0;          // last use, for eviction
+  Entry() = default;
+  Entry(const Entry &) = delete;
+  Entry &operator=(const Entry &) = delete;
+  ~Entry()
+  {
+    if (m) fs_matrix_destroy(m);
+    if (cb) fs_cbcsr_destroy(cb);
+  }
 };
+typedef std::shared_ptr<Entry> EntryP;
 
 std::mutex g_table_lock;
-std::unordered_map<Key, Entry, KeyHash> g_table;
+std::unordered_map<Key, EntryP, KeyHash> g_table;
+uint64_t g_tick = 0;
 
-void drop(Entry &e)
+// drops the least recently used entries nobody is using right now until at most `keep` are left (table lock held)
+void evict_lru(size_t keep)
 {
-  if (e.m) fs_matrix_destroy(e.m);
-  if (e.cb) fs_cbcsr_destroy(e.cb);
-  e = Entry();
+  while (g_table.size() > keep) {
+    auto victim = g_table.end();
+    for (auto it = g_table.begin(); it != g_table.end(); ++it)
+      if (it->second.use_count() == 1 && (victim == g_table.end() || it->second->tick < victim->second->tick)) victim = it;
+    if (victim == g_table.end()) return;   // everything left is in use
+    g_table.erase(victim);
+  }
 }
 
-// returns the cached entry for (host, variant) when its fingerprint matches, else builds it
+// returns the cached entry for (host, variant) when its fingerprint matches, else builds it.  A build that fails
+// (typically: HBM full of other matrices' copies -- callers that construct matrices in a loop and never free them)
+// is retried once after every idle entry has been dropped.
 template <typename Build>
-Entry lookup(const void *host, int variant, uint64_t print, Build build, const char *who)
+EntryP lookup(const void *host, int variant, uint64_t print, Build build, const char *who)
 {
   std::lock_guard<std::mutex> g(g_table_lock);
-  Entry &e = g_table[Key{host, variant}];
-  if ((e.m || e.cb) && e.print == print) return e;
-  drop(e);
-  build(e);
-  if (!e.m && !e.cb) die(who);
-  e.print = print;
+  const Key key{host, variant};
+  auto it = g_table.find(key);
+  if (it != g_table.end()) {
+    if (cache_enabled() && it->second->print == print) {
+      it->second->tick = ++g_tick;
+      return it->second;
+    }
+    g_table.erase(it);        // a stale copy: gone from the table now, destroyed when its last user returns
+  }
+  EntryP e = std::make_shared<Entry>();
+  build(*e);
+  if (!e->m && !e->cb) {
+    evict_lru(0);
+    (void)hipGetLastError();
+    build(*e);
+  }
+  if (!e->m && !e->cb) die(who);
+  e->print = print;
+  e->tick = ++g_tick;
+  g_table[key] = e;
+  evict_lru(max_entries());
   return e;
 }
 
@@ -155,51 +240,52 @@ void with_vectors(double *y, size_t ny, const double *x, size_t nx, Mul mul, con
 }
 
 // ---- per-format uploads -----------------------------------------------------------------------------
-uint64_t print_csr(int nrow, int ncol, long nnz, const int *row_ptr, const int *cols, const double *vals)
+EntryP csr_entry(const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols,
+                 const double *vals, bool need_t, const char *who)
 {
+  const bool full = hash_in_full((int64_t)nnz * (vals ? 12 : 4) + 4 * ((int64_t)nrow + 1));
   uint64_t h = mix(mix(mix(1, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
   h = mix(mix(mix(h, (uint64_t)(uintptr_t)row_ptr), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
-  h = sample_ints(h, row_ptr, (int64_t)nrow + 1);
-  h = sample_ints(h, cols, nnz);
-  return sample_doubles(h, vals, nnz);
-}
-
-fs_matrix_t csr_handle(const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols,
-                       const double *vals, bool need_t, const char *who)
-{
-  const uint64_t p = print_csr(nrow, ncol, nnz, row_ptr, cols, vals);
-  Entry e = lookup(host, kDirect, p, [&](Entry &n) { n.m = fs_csr_create(nrow, ncol, nnz, row_ptr, cols, vals, FS_HOST, 0); },
-                   who);
-  if (need_t) FS_MUST(fs_matrix_build_transpose(e.m, nullptr), who);
-  return e.m;
+  h = print_ints(h, row_ptr, (int64_t)nrow + 1, full);
+  h = print_ints(h, cols, nnz, full);
+  h = print_doubles(h, vals, nnz, full);
+  EntryP e = lookup(host, kDirect, h, [&](Entry &n) { n.m = fs_csr_create(nrow, ncol, nnz, row_ptr, cols, vals, FS_HOST, 0); },
+                    who);
+  if (need_t) FS_MUST(fs_matrix_build_transpose(e->m, nullptr), who);
+  return e;
 }
 
 // COO (optionally valued); variant kTransposed uploads (cols, rows) so that each output element
 // keeps the entry order of the serial loop it replaces (sparse.h:72-74, dsparse.h:58-60)
-fs_matrix_t coo_handle(const void *host, int variant, int nrow, int ncol, long nnz, const int *rows, const int *cols,
-                       const double *vals, const char *who)
+EntryP coo_entry(const void *host, int variant, int nrow, int ncol, long nnz, const int *rows, const int *cols,
+                 const double *vals, const char *who)
 {
+  const bool full = hash_in_full((int64_t)nnz * (vals ? 16 : 8));
   uint64_t h = mix(mix(mix(2, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
   h = mix(mix(mix(h, (uint64_t)(uintptr_t)rows), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
-  h = sample_doubles(sample_ints(sample_ints(h, rows, nnz), cols, nnz), vals, nnz);
+  h = print_doubles(print_ints(print_ints(h, rows, nnz, full), cols, nnz, full), vals, nnz, full);
   return lookup(host, variant, h, [&](Entry &n) {
     n.m = variant == kDirect ? fs_coo_create(nrow, ncol, nnz, rows, cols, vals, FS_HOST)
                              : fs_coo_create(ncol, nrow, nnz, cols, rows, vals, FS_HOST);
-  }, who).m;
+  }, who);
 }
 
 // row-blocked COO: the per-block arrays are laid end to end and uploaded as one COO; a row lives in
 // exactly one block, so its entries keep the order bsbm_A_mul_B (sparse.h:269-271) adds them in
-fs_matrix_t blocked_handle(const void *host, int nrow, int ncol, int nblocks, const int *blk_nnz, int **brows,
-                           int **bcols, double **bvals, const char *who)
+EntryP blocked_entry(const void *host, int nrow, int ncol, int nblocks, const int *blk_nnz, int **brows,
+                     int **bcols, double **bvals, const char *who)
 {
-  uint64_t h = mix(mix(mix(3, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nblocks);
-  h = sample_ints(h, blk_nnz, nblocks);
   int64_t nnz = 0;
+  for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
+  const bool full = hash_in_full(nnz * (bvals ? 16 : 8));
+  uint64_t h = mix(mix(mix(3, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nblocks);
+  h = print_ints(h, blk_nnz, nblocks, true);
   for (int b = 0; b < nblocks; b++) {
-    nnz += blk_nnz[b];
     h = mix(mix(h, (uint64_t)(uintptr_t)brows[b]), (uint64_t)(uintptr_t)bcols[b]);
-    if (b % (nblocks / 64 + 1) == 0) h = sample_ints(sample_ints(h, brows[b], blk_nnz[b]), bcols[b], blk_nnz[b]);
+    if (full || b % (nblocks / 64 + 1) == 0) {
+      h = print_ints(print_ints(h, brows[b], blk_nnz[b], full), bcols[b], blk_nnz[b], full);
+      if (bvals) h = print_doubles(h, bvals[b], blk_nnz[b], full);
+    }
   }
   return lookup(host, kDirect, h, [&](Entry &n) {
     std::vector<int> r((size_t)nnz), c((size_t)nnz);
@@ -215,21 +301,21 @@ fs_matrix_t blocked_handle(const void *host, int nrow, int ncol, int nblocks, co
       o += m;
     }
     n.m = fs_coo_create(nrow, ncol, nnz, r.data(), c.data(), bvals ? v.data() : nullptr, FS_HOST);
-  }, who).m;
+  }, who);
 }
 
 void bcsr_mul_k(double *Y, struct BinaryCSR *A, double *X, int k, const char *who)
 {
-  fs_matrix_t m = csr_handle(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, false, who);
+  EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, false, who);
   with_vectors(Y, (size_t)A->nrow * k, X, (size_t)A->ncol * k,
-               [&](double *yd, const double *xd) { return fs_spmm(m, yd, xd, k, nullptr); }, who);
+               [&](double *yd, const double *xd) { return fs_spmm(e->m, yd, xd, k, nullptr); }, who);
 }
 
 void bsbm_mul_k(double *Y, struct BlockedSBM *B, double *X, int k, const char *who)
 {
-  fs_matrix_t m = blocked_handle(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, nullptr, who);
+  EntryP e = blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, nullptr, who);
   with_vectors(Y, (size_t)B->nrow * k, X, (size_t)B->ncol * k,
-               [&](double *yd, const double *xd) { return fs_spmm(m, yd, xd, k, nullptr); }, who);
+               [&](double *yd, const double *xd) { return fs_spmm(e->m, yd, xd, k, nullptr); }, who);
 }
 
 }  // namespace
@@ -239,30 +325,33 @@ extern "C" {
 void fs_invalidate(const void *host_struct)
 {
   std::lock_guard<std::mutex> g(g_table_lock);
-  for (int v = 0; v < 2; v++) {
-    auto it = g_table.find(Key{host_struct, v});
-    if (it != g_table.end()) { drop(it->second); g_table.erase(it); }
-  }
+  for (int v = 0; v < 2; v++) g_table.erase(Key{host_struct, v});   // a product still running on the copy keeps it alive
 }
 
 void fs_release_all(void)
 {
   std::lock_guard<std::mutex> g(g_table_lock);
-  for (auto &kv : g_table) drop(kv.second);
   g_table.clear();
+}
+
+// number of device copies in the side table (tests, diagnostics)
+int fs_cache_entries(void)
+{
+  std::lock_guard<std::mutex> g(g_table_lock);
+  return (int)g_table.size();
 }
 
 // ---- sparse.h ----------------------------------------------------------------------------------------
 void A_mul_B(double *y, struct SparseBinaryMatrix *A, double *x)
 {
-  fs_matrix_t m = coo_handle(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "A_mul_B");
-  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "A_mul_B");
+  EntryP e = coo_entry(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "A_mul_B");
+  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "A_mul_B");
 }
 
 void At_mul_B(double *y, struct SparseBinaryMatrix *A, double *x)
 {
-  fs_matrix_t m = coo_handle(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "At_mul_B");
-  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "At_mul_B");
+  EntryP e = coo_entry(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "At_mul_B");
+  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "At_mul_B");
 }
 
 void bsbm_A_mul_B(double *y, struct BlockedSBM *B, double *x) { bsbm_mul_k(y, B, x, 1, "bsbm_A_mul_B"); }
@@ -274,8 +363,9 @@ void bsbm_A_mul_Bn(double *y, struct BlockedSBM *B, double *x, int ncol) { bsbm_
 void bsbm_AtA(double *y, struct BlockedSBM *A, struct BlockedSBM *At, double *x, double *tmp, double lambda)
 {
   (void)tmp;  // host scratch of the CPU version; the intermediate A x stays in HBM here
-  fs_matrix_t a = blocked_handle(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, "bsbm_AtA");
-  fs_matrix_t at = blocked_handle(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, "bsbm_AtA");
+  EntryP ea = blocked_entry(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, "bsbm_AtA");
+  EntryP eat = blocked_entry(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, "bsbm_AtA");
+  fs_matrix_t a = ea->m, at = eat->m;
   double *t = nullptr;
   if (hipMalloc(&t, sizeof(double) * (size_t)(A->nrow ? A->nrow : 1)) != hipSuccess) {
     fs::set_error("hipMalloc of the A x scratch failed"); die("bsbm_AtA");
@@ -296,8 +386,9 @@ static void cg_common(double *x, struct BlockedSBM *A, struct BlockedSBM *At, do
     printf("A (%d x %d) and At (%d x %d) must be transposes of each other.\n", A->nrow, A->ncol, At->nrow, At->ncol);
     exit(1);
   }
-  fs_matrix_t a = blocked_handle(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, who);
-  fs_matrix_t at = blocked_handle(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, who);
+  EntryP ea = blocked_entry(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, who);
+  EntryP eat = blocked_entry(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, who);
+  fs_matrix_t a = ea->m, at = eat->m;
   const size_t n = (size_t)A->ncol * k;
   int iters = 0;
   with_vectors(x, n, b, n, [&](double *xd, const double *bd) {
@@ -319,20 +410,20 @@ void bsbm_cg2(double *X, struct BlockedSBM *A, struct BlockedSBM *At, double *B,
 // ---- dsparse.h ---------------------------------------------------------------------------------------
 void sdm_A_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)
 {
-  fs_matrix_t m = coo_handle(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_A_mul_B");
-  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "sdm_A_mul_B");
+  EntryP e = coo_entry(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_A_mul_B");
+  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "sdm_A_mul_B");
 }
 
 void sdm_At_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)
 {
-  fs_matrix_t m = coo_handle(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_At_mul_B");
-  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "sdm_At_mul_B");
+  EntryP e = coo_entry(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_At_mul_B");
+  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "sdm_At_mul_B");
 }
 
 void bsdm_A_mul_B(double *y, struct BlockedSDM *B, double *x)
 {
-  fs_matrix_t m = blocked_handle(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, B->vals, "bsdm_A_mul_B");
-  with_vectors(y, B->nrow, x, B->ncol, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "bsdm_A_mul_B");
+  EntryP e = blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, B->vals, "bsdm_A_mul_B");
+  with_vectors(y, B->nrow, x, B->ncol, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "bsdm_A_mul_B");
 }
 
 // ---- csr.h ---------------------------------------------------------------------------------------------
@@ -369,7 +460,8 @@ void bcsr_A_mul_B32n(double *Y, struct BinaryCSR *A, double *X, const int ncol)
 
 void bcsr_AA_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
-  fs_matrix_t m = csr_handle(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_AA_mul_B");
+  EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_AA_mul_B");
+  fs_matrix_t m = e->m;
   double *tmp = nullptr;
   if (hipMalloc(&tmp, sizeof(double) * (size_t)(A->nrow ? A->nrow : 1)) != hipSuccess) {
     fs::set_error("hipMalloc of the A x scratch failed"); die("bcsr_AA_mul_B");
@@ -387,25 +479,29 @@ void parallel_bcsr_AA_mul_B(double *y, struct BinaryCSR *A, double *x, double *y
 
 void bcsr_At_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
-  fs_matrix_t m = csr_handle(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_At_mul_B");
+  EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_At_mul_B");
+  fs_matrix_t m = e->m;
   with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv_t(m, yd, xd, nullptr); }, "bcsr_At_mul_B");
 }
 
 void csr_A_mul_B(double *y, struct CSR *A, double *x)
 {
-  fs_matrix_t m = csr_handle(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_B");
+  EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_B");
+  fs_matrix_t m = e->m;
   with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "csr_A_mul_B");
 }
 
 void csr_At_mul_B(double *y, struct CSR *A, double *x)
 {
-  fs_matrix_t m = csr_handle(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, true, "csr_At_mul_B");
+  EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, true, "csr_At_mul_B");
+  fs_matrix_t m = e->m;
   with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv_t(m, yd, xd, nullptr); }, "csr_At_mul_B");
 }
 
 void csr_A_mul_Bn(double *Y, struct CSR *A, double *X, const int ncol)
 {
-  fs_matrix_t m = csr_handle(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_Bn");
+  EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_Bn");
+  fs_matrix_t m = e->m;
   with_vectors(Y, (size_t)A->nrow * ncol, X, (size_t)A->ncol * ncol,
                [&](double *yd, const double *xd) { return fs_spmm(m, yd, xd, ncol, nullptr); }, "csr_A_mul_Bn");
 }
@@ -414,13 +510,14 @@ void csr_A_mul_Bn(double *Y, struct CSR *A, double *X, const int ncol)
 void cbcsr_A_mul_B(double *y, struct ColBinaryCSR *A, double *x)
 {
   const int64_t ncell = (int64_t)A->nblocks * A->nrow;
+  const bool full = hash_in_full(4 * ((int64_t)A->nnz + ncell + 1));
   uint64_t h = mix(mix(mix(4, (uint64_t)A->nrow), (uint64_t)A->ncol), (uint64_t)A->nnz);
   h = mix(mix(mix(h, (uint64_t)A->colblocksize), (uint64_t)(uintptr_t)A->row_ptr), (uint64_t)(uintptr_t)A->cols);
-  h = sample_ints(sample_ints(h, A->row_ptr, ncell + 1), A->cols, A->nnz);
-  Entry e = lookup(A, kDirect, h, [&](Entry &n) {
+  h = print_ints(print_ints(h, A->row_ptr, ncell + 1, full), A->cols, A->nnz, full);
+  EntryP e = lookup(A, kDirect, h, [&](Entry &n) {
     n.cb = fs_cbcsr_create(A->nrow, A->ncol, A->nblocks, A->colblocksize, A->row_ptr, A->cols, FS_HOST);
   }, "cbcsr_A_mul_B");
-  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_cbcsr_spmv(e.cb, yd, xd, nullptr); },
+  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_cbcsr_spmv(e->cb, yd, xd, nullptr); },
                "cbcsr_A_mul_B");
 }
 

@@ -22,6 +22,9 @@
 
 #define FS_EXPORT __attribute__((visibility("default")))
 
+/* side table of device copies (fs_dropin.hip): a struct whose arrays go away or change roles drops its copy */
+void fs_invalidate(const void *host_struct);
+
 static void *xmalloc(size_t bytes)
 {
   void *p = malloc(bytes ? bytes : 1);
@@ -60,6 +63,7 @@ FS_EXPORT struct SparseBinaryMatrix *new_sbm(long nrow, long ncol, long nnz, int
 
 FS_EXPORT void free_sbm(struct SparseBinaryMatrix *sbm)
 {
+  fs_invalidate(sbm);   /* both device copies: the A_mul_B handle and the At_mul_B handle */
   free(sbm->rows);
   free(sbm->cols);
 }
@@ -71,6 +75,7 @@ FS_EXPORT struct SparseBinaryMatrix *new_transpose(struct SparseBinaryMatrix *A)
 
 FS_EXPORT void transpose(struct SparseBinaryMatrix *A)
 {
+  fs_invalidate(A);
   int *r = A->rows; A->rows = A->cols; A->cols = r;
   int n = A->nrow; A->nrow = A->ncol; A->ncol = n;
 }
@@ -84,6 +89,7 @@ FS_EXPORT struct SparseDoubleMatrix *new_sdm(long nrow, long ncol, long nnz, int
 
 FS_EXPORT void sdm_transpose(struct SparseDoubleMatrix *A)
 {
+  fs_invalidate(A);
   int *r = A->rows; A->rows = A->cols; A->cols = r;
   int n = A->nrow; A->nrow = A->ncol; A->ncol = n;
 }

@@ -147,41 +147,128 @@ def hip_env():
     return torch, capi, O
 
 
-def test_config5_like_shard_powerlaw(hip_env):
-    """one row shard of BASELINE config 5's shape: 4 M rows x 100 M columns (x of 800 MB), power-law row lengths
-    clipped at 1e6 (the generator of the full config, `fs_synth_powerlaw_lengths`), ~100 M non-zeros: row windows
-    around the longest rows and at both ends against the oracle, the builder's choice against the storage-order
-    kernel on every row, and the integer checksum of checksums on the pattern"""
+def test_config5_one_real_shard_rank3_of_8(hip_env):
+    """BASELINE config 5, ONE real shard: CSR 100 M x 100 M, power-law row lengths (mean ~32, clipped at 1e6), the rows
+    rank 3 of 8 owns under the nnz-balanced cut (bench.py's own partition and generator: ~12.5 M rows, ~400 M
+    non-zeros, x of 800 MB).  Row windows around the longest rows and at both ends against the oracle, the builder's
+    choice against the storage-order kernel on EVERY row, and the integer checksum of checksums on the pattern."""
     torch, capi, O = hip_env
-    nrow, ncol = 4_000_000, 100_000_000
-    rp, cc, vv = capi.synth_powerlaw(nrow, ncol, 2.3, 1_000_000, 0x5EED0005)
-    nnz = int(rp[-1].item())
-    assert 50_000_000 < nnz < 300_000_000
+    import bench
+    prov = bench.HipProvider(torch.device("cuda", torch.cuda.current_device()))
+    n_global = 100_000_000
+    bounds, cum, total = bench.c5_partition(prov, n_global, 8)
+    assert bounds[0] == 0 and bounds[-1] == n_global and 3.0e9 < total < 3.4e9
+    per = [cum[i + 1] - cum[i] for i in range(8)]
+    assert max(per) - min(per) <= 2 * bench.C5_MAXLEN and max(per) <= 2**31 - 1     # equal shares, each fits an int row_ptr
+    lo, hi = bounds[3], bounds[4]
+    rp, cc, vv, nnz = bench.c5_shard(prov, lo, hi, n_global)
+    nrow, ncol = hi - lo, n_global
+    assert nnz == per[3] and 3.7e8 < nnz < 4.3e8 and 1.1e7 < nrow < 1.4e7
     A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
     st = capi.current_stream()
     x = torch.sin(7.0 * torch.arange(ncol, device="cuda", dtype=torch.float64) + 0.3)
     y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
     A.spmv(y, x, st)
     lens = (rp[1:] - rp[:-1])
-    longest = int(torch.argmax(lens).item())
-    for lo in (0, max(0, min(longest - 100, nrow - 400)), nrow - 400):
-        _window_check(capi, O, rp, cc, vv, x, y, lo, lo + 400, exact=False)
+    top = torch.topk(lens, 3).indices.tolist()
+    for lo_w in [0, nrow - 400] + [max(0, min(t - 100, nrow - 400)) for t in top]:
+        _window_check(capi, O, rp, cc, vv, x, y, lo_w, lo_w + 400, exact=False)
     y2 = torch.empty_like(y)
     capi.set_option("strict_order", 1)
     try:
         A.spmv(y2, x, st)
     finally:
         capi.set_option("strict_order", 0)
+    _window_check(capi, O, rp, cc, vv, x, y2, max(0, min(top[0] - 100, nrow - 400)), max(0, min(top[0] - 100, nrow - 400)) + 400,
+                  exact=True)                     # storage order = the oracle's bits, also on the longest row
     # row-scaled bound with the row length as the scale's proxy: |x| <= 1, |v| <= 1
     bound = 1e-12 * torch.clamp(lens.to(torch.float64), min=1.0)
     assert bool(((y - y2).abs() <= bound).all()), A.kernel_name()
-    del A
+    kernel = A.kernel_name()
+    del A, y2
     Ap = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
     xi = _int_x(ncol, "cuda", 9)
     Ap.spmv(y, xi, st)
-    total = 0
+    total_i = 0
     step = 50_000_000
     xl = xi.to(torch.int64)
     for a in range(0, nnz, step):
-        total += int(xl[cc[a:a + step].long()].sum().item())
-    assert int(y.to(torch.int64).sum().item()) == total, Ap.kernel_name()
+        total_i += int(xl[cc[a:a + step].long()].sum().item())
+    assert int(y.to(torch.int64).sum().item()) == total_i, (kernel, Ap.kernel_name())
+
+
+def test_config3_through_its_own_entry_points_coo(hip_env):
+    """BASELINE config 3 as the reference would run it: a SparseBinaryMatrix 10 M x 1 M with 64 entries per row given
+    as COO (row-major) to A_mul_B and At_mul_B (sparse.h:58-75) -- the device COO -> CSR sort at 640 M entries and the
+    transposed handle -- through (1) the device layer (fs_coo_create) and (2) the drop-in symbols with the host struct
+    and host vectors.  Integer-valued x: bit-exact windows against the oracle, exact checksums, both directions."""
+    import ctypes as C
+    import time
+    torch, capi, O = hip_env
+    import _hipbackend as H
+    nrow, ncol, per = 10_000_000, 1_000_000, 64
+    nnz = nrow * per
+    _, cols, _ = capi.synth_uniform(nrow, ncol, per, 0x5EED0003, valued=False)
+    rows = torch.arange(nrow, device="cuda", dtype=torch.int32).repeat_interleave(per)
+    st = capi.current_stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    A = capi.Matrix.from_coo(nrow, ncol, rows, cols, None)
+    torch.cuda.synchronize()
+    t_a = time.time() - t0
+    t0 = time.time()
+    At = capi.Matrix.from_coo(ncol, nrow, cols, rows, None)
+    torch.cuda.synchronize()
+    t_t = time.time() - t0
+    print("config 3: device COO -> CSR + format, 640 M entries: A %.2f s (%s), A' %.2f s (%s)"
+          % (t_a, A.kernel_name(), t_t, At.kernel_name()))
+    # the device CSR is what new_bcsr would build: row-major COO => cols unchanged, row_ptr = 64 r
+    rp = (torch.arange(nrow + 1, device="cuda", dtype=torch.int64) * per).to(torch.int32)
+    x = _int_x(ncol, "cuda", 3)
+    u = _int_x(nrow, "cuda", 4)
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+    A.spmv(y, x, st)
+    At.spmv(z, u, st)
+    for lo in (0, 6_543_210, nrow - 2000):
+        _window_check(capi, O, rp, cols, None, x, y, lo, lo + 2000, exact=True)
+    xl = x.to(torch.int64)
+    tot = 0
+    for a in range(0, nnz, 64_000_000):
+        tot += int(xl[cols[a:a + 64_000_000].long()].sum().item())
+    assert int(y.to(torch.int64).sum().item()) == tot
+    # transposed: z[c] = sum over the entries of column c of u[row]; checksum = 64 * sum(u); column windows vs the oracle
+    assert int(z.to(torch.int64).sum().item()) == per * int(u.to(torch.int64).sum().item())
+    for c0 in (0, 500_000, ncol - 300):
+        c1 = c0 + 300
+        hit = torch.zeros(nrow * per, dtype=torch.bool, device="cuda")
+        for a in range(0, nnz, 128_000_000):
+            blk = cols[a:a + 128_000_000]
+            hit[a:a + 128_000_000] = (blk >= c0) & (blk < c1)
+        idx = hit.nonzero().squeeze(1)
+        wr, wc = rows[idx].cpu().numpy(), (cols[idx] - c0).cpu().numpy().astype(np.int32)
+        ref = O.coo_tmul(c1 - c0, wr, wc, None, u.cpu().numpy())
+        assert np.array_equal(z[c0:c1].cpu().numpy(), ref), c0
+        del hit, idx
+    del A, At
+    y_dev, z_dev = y.cpu().numpy(), z.cpu().numpy()
+    # (2) the drop-in: host struct SparseBinaryMatrix (sparse.h:11-18), host vectors
+    hr, hc = rows.cpu().numpy(), cols.cpu().numpy()
+    del rows, cols, rp
+    S = H.SBM(nrow, ncol, nnz, H._ip(hr), H._ip(hc))
+    L = capi.lib()
+    xh, uh = x.cpu().numpy(), u.cpu().numpy()
+    yh, zh = np.full(nrow, -1.0), np.full(ncol, -1.0)
+    for f in (L.A_mul_B, L.At_mul_B):
+        f.restype = None
+    t0 = time.time()
+    L.A_mul_B(H._dp(yh), C.byref(S), H._dp(xh))
+    t_first = time.time() - t0
+    t0 = time.time()
+    L.A_mul_B(H._dp(yh), C.byref(S), H._dp(xh))
+    t_again = time.time() - t0
+    L.At_mul_B(H._dp(zh), C.byref(S), H._dp(uh))
+    print("config 3 drop-in A_mul_B with host struct + host vectors: first call %.2f s (upload + sort + format), next %.4f s"
+          % (t_first, t_again))
+    L.fs_invalidate(C.byref(S))
+    assert np.array_equal(yh, y_dev) and np.array_equal(zh, z_dev)

@@ -906,3 +906,161 @@ def test_spmm_matrix_core_experiment(hip, k):
                     assert np.all(np.abs(got[:, j] - ref[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
     finally:
         capi.set_option("spmm_kernel", 0)
+
+
+def _csr_struct(hip, nrow, ncol, rp, cc, vv):
+    return hip.CSR(nrow, ncol, len(cc), hip._ip(rp), hip._ip(cc), hip._dp(vv))
+
+
+def test_dropin_cache_sees_one_edited_entry(hip):
+    """an entry edited in place at the same pointers.  Matrices up to 8 MB are hashed in full on every call,
+    so ONE changed value or column is seen without fs_invalidate; beyond that the fingerprint is sampled and such an edit
+    needs fs_invalidate (asserted here, so the documented behaviour is pinned) or FS_STRICT_CACHE=1 (next test)"""
+    import ctypes as C
+    L = hip.HipDropinBackend().L
+    L.csr_A_mul_B.restype = None
+    rng = np.random.default_rng(5)
+    for nrow, per, expect_fresh in ((20_000, 10, True), (150_000, 10, False)):       # 2.4 MB / 18 MB of arrays
+        ncol = nrow
+        rp = (np.arange(nrow + 1, dtype=np.int64) * per).astype(np.int32)
+        cc = rng.integers(0, ncol, nrow * per).astype(np.int32)
+        vv = rng.uniform(-1, 1, nrow * per)
+        A = _csr_struct(hip, nrow, ncol, rp, cc, vv)
+        x = S.x_int(4, ncol)
+        y = np.full(nrow, -1.0)
+        L.csr_A_mul_B(hip._dp(y), C.byref(A), hip._dp(x))
+        ref0 = O.csr_mul(nrow, rp, cc, vv, x)
+        assert np.all(np.abs(y - ref0) <= TOL * O.csr_abs_scale(nrow, rp, cc, vv, x))
+        k = 777 * per + 3                                   # not one of the 2048 strided samples, not an end
+        assert k % max(1, (nrow * per) // 2048) != 0
+        vv[k] += 1000.0
+        cc[k] = (cc[k] + 1) % ncol
+        ref1 = O.csr_mul(nrow, rp, cc, vv, x)
+        assert ref1[777] != ref0[777]
+        L.csr_A_mul_B(hip._dp(y), C.byref(A), hip._dp(x))
+        if expect_fresh:
+            assert abs(y[777] - ref1[777]) <= 1e-9, "a small matrix is hashed in full: the edit must be seen"
+        else:
+            assert abs(y[777] - ref0[777]) <= 1e-9, "sampled fingerprint: the stale copy is what runs (documented)"
+            L.fs_invalidate(C.byref(A))
+            L.csr_A_mul_B(hip._dp(y), C.byref(A), hip._dp(x))
+            assert abs(y[777] - ref1[777]) <= 1e-9
+        L.fs_invalidate(C.byref(A))
+
+
+def test_dropin_strict_cache_and_bounded_table_in_a_fresh_process(hip):
+    """FS_STRICT_CACHE=1 (every array hashed in full on every call): the large-matrix edit of the previous test is
+    seen without fs_invalidate.  FS_DROPIN_MAX_ENTRIES=3: the side table never holds more than 3 idle copies.
+    free_sbm drops both copies (A_mul_B and At_mul_B handles) of a SparseBinaryMatrix."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import _hipbackend as H
+from oracle import pyoracle as O
+L = H.HipDropinBackend().L
+L.csr_A_mul_B.restype = None
+rng = np.random.default_rng(5)
+nrow = ncol = 150_000; per = 10
+rp = (np.arange(nrow + 1, dtype=np.int64) * per).astype(np.int32)
+cc = rng.integers(0, ncol, nrow * per).astype(np.int32)
+vv = rng.uniform(-1, 1, nrow * per)
+A = H.CSR(nrow, ncol, len(cc), H._ip(rp), H._ip(cc), H._dp(vv))
+x = np.arange(ncol, dtype=np.float64) %% 7 - 3
+y = np.full(nrow, -1.0)
+L.csr_A_mul_B(H._dp(y), C.byref(A), H._dp(x))
+k = 777 * per + 3
+vv[k] += 1000.0
+L.csr_A_mul_B(H._dp(y), C.byref(A), H._dp(x))
+ref = O.csr_mul(nrow, rp, cc, vv, x)
+assert abs(y[777] - ref[777]) <= 1e-9, (y[777], ref[777])
+keep = []
+for i in range(6):
+    r2 = rp[: 1001].copy(); c2 = cc[: r2[-1]].copy(); v2 = vv[: r2[-1]].copy()
+    B = H.CSR(1000, ncol, len(c2), H._ip(r2), H._ip(c2), H._dp(v2)); keep.append((B, r2, c2, v2))
+    yy = np.empty(1000)
+    L.csr_A_mul_B(H._dp(yy), C.byref(B), H._dp(x))
+    assert np.allclose(yy, ref[:1000] if i < 0 else O.csr_mul(1000, r2, c2, v2, x))
+assert L.fs_cache_entries() == 3, L.fs_cache_entries()
+L.fs_release_all()
+# free_sbm: both handles of a SparseBinaryMatrix go (arrays must be malloc'ed: free_sbm frees them)
+libc = C.CDLL(None); libc.malloc.restype = C.c_void_p
+n = 5000
+pr = libc.malloc(4 * n); pc = libc.malloc(4 * n)
+C.memmove(pr, (np.arange(n) %% 100).astype(np.int32).ctypes.data, 4 * n)
+C.memmove(pc, (np.arange(n) * 7 %% 50).astype(np.int32).ctypes.data, 4 * n)
+L.new_sbm.restype = C.POINTER(H.SBM)
+L.new_sbm.argtypes = [C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+S_ = L.new_sbm(100, 50, n, pr, pc)
+y1 = np.empty(100); y2 = np.empty(50)
+L.A_mul_B.restype = None; L.At_mul_B.restype = None
+L.A_mul_B(H._dp(y1), S_, H._dp(np.ones(50))); L.At_mul_B(H._dp(y2), S_, H._dp(np.ones(100)))
+assert y1.sum() == n and y2.sum() == n and L.fs_cache_entries() == 2
+L.free_sbm.restype = None
+L.free_sbm(S_)
+assert L.fs_cache_entries() == 0
+print("OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FS_STRICT_CACHE="1", FS_DROPIN_MAX_ENTRIES="3")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_two_host_threads_share_matrices(hip):
+    """bench_a_mul_b.c:401-421 ("[2x cg2]"): two host threads run bsbm_A_mul_B2 on shared B and Bt with their own X / Y,
+    while a third keeps invalidating and re-uploading another view of the same matrix: entries are ref-counted, products
+    of one handle are serialised by its lock, and every result equals the single-threaded one bit for bit (integer X)"""
+    import ctypes as C
+    import threading
+    be = hip.HipDropinBackend()
+    L = be.L
+    c = BY_NAME["syn_u16_2048"]
+    s = be.sbm(c.nrow, c.ncol, c.rows, c.cols)
+    st = be.sbm(c.ncol, c.nrow, c.cols, c.rows)
+    B, Bt = L.new_bsbm(C.byref(s), 64), L.new_bsbm(C.byref(st), 64)
+    for f in (L.bsbm_A_mul_B2, L.A_mul_B):
+        f.restype = None
+    blk = O.coo_to_blocked(c.nrow, 64, c.rows, c.cols)
+    blkt = O.coo_to_blocked(c.ncol, 64, c.cols, c.rows)
+    errors = []
+
+    def worker(seed):
+        try:
+            X = np.ascontiguousarray(np.stack([S.x_int(seed, c.ncol), S.x_int(seed + 1, c.ncol)], 1))
+            Y = np.full((c.nrow, 2), -1.0)
+            X2 = np.full((c.ncol, 2), -1.0)
+            Yref = O.blocked_mul_n(c.nrow, blk, X, 2)
+            X2ref = O.blocked_mul_n(c.ncol, blkt, Yref, 2)
+            for _ in range(25):
+                L.bsbm_A_mul_B2(hip._dp(Y.reshape(-1)), B, hip._dp(X.reshape(-1)))
+                L.bsbm_A_mul_B2(hip._dp(X2.reshape(-1)), Bt, hip._dp(Y.reshape(-1)))
+                if not (np.array_equal(Y, Yref) and np.array_equal(X2, X2ref)):
+                    errors.append("thread %d: wrong result" % seed)
+                    return
+        except Exception as ex:       # pragma: no cover
+            errors.append(repr(ex))
+
+    stop = threading.Event()
+
+    def churn():
+        x = S.x_int(3, c.ncol)
+        y = np.full(c.nrow, -1.0)
+        ref = O.coo_mul(c.nrow, c.rows, c.cols, None, x)
+        while not stop.is_set():
+            L.A_mul_B(hip._dp(y), C.byref(s), hip._dp(x))
+            if not np.array_equal(y, ref):
+                errors.append("churn: wrong result")
+                return
+            L.fs_invalidate(C.byref(s))
+
+    ts = [threading.Thread(target=worker, args=(10,)), threading.Thread(target=worker, args=(20,)), threading.Thread(target=churn)]
+    for t in ts:
+        t.start()
+    for t in ts[:2]:
+        t.join()
+    stop.set()
+    ts[2].join()
+    L.fs_release_all()
+    assert not errors, errors
