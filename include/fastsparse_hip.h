@@ -141,6 +141,16 @@ void fs_cbcsr_destroy(fs_cbcsr_t A);
 /* y[nrow] = A x: per column block the x tile is staged in LDS, cell sums are added block by block */
 int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream);
 
+/* ---- format construction on the device ------------------------------------------------ */
+/* Stable bucketing of host COO entries, the operation behind new_csr / new_bcsr (csr.h:375-422, 30-67: kind 0, key =
+ * row), new_cbcsr (cbcsr.h:16-65: kind 1, key = (col / param) * nrow + row) and new_bsbm / new_bsdm (sparse.h:175-213,
+ * dsparse.h:132-173: kind 2, key = row / param).  Host arrays in, host arrays out: offsets[nbuckets + 1], and the
+ * payload arrays in bucket order with every bucket keeping the input order (rows_out / vals_out may be NULL).  The
+ * constructors of include/csr.h, cbcsr.h, sparse.h, dsparse.h call it when fs_device_build_wanted(nnz) says so. */
+int fs_bucket_coo(int kind, int param, int nrow, int ncol, int64_t nbuckets, int64_t nnz, const int *rows, const int *cols,
+                  const double *vals, int *offsets, int *rows_out, int *cols_out, double *vals_out);
+int fs_device_build_wanted(int64_t nnz);
+
 /* ---- side table of layer (1) ---------------------------------------------------------- */
 /* forget the device copy made for a host struct (call after mutating its arrays in place) */
 void fs_invalidate(const void *host_struct);

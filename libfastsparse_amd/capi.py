@@ -22,7 +22,7 @@ DEVICE_API = [
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
     "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all", "fs_cache_entries",
-    "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill",
+    "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill", "fs_bucket_coo", "fs_device_build_wanted",
 ]
 REFERENCE_API = [
     # sparse.h

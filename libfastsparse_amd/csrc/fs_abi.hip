@@ -99,6 +99,8 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "ldsx")) { fs::options().ldsx = value; return FS_OK; }
   if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
   if (!strcmp(name, "spmm_kernel")) { fs::options().spmm_kernel = value; return FS_OK; }
+  if (!strcmp(name, "ata_kernel")) { fs::options().ata_kernel = value; return FS_OK; }
+  if (!strcmp(name, "device_build")) { fs::options().device_build = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
 }
@@ -115,6 +117,8 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "ldsx")) return fs::options().ldsx;
   if (name && !strcmp(name, "reproducible")) return fs::options().reproducible;
   if (name && !strcmp(name, "spmm_kernel")) return fs::options().spmm_kernel;
+  if (name && !strcmp(name, "ata_kernel")) return fs::options().ata_kernel;
+  if (name && !strcmp(name, "device_build")) return fs::options().device_build;
   return FS_ERR_ARG;
 }
 
@@ -141,6 +145,7 @@ fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, c
     if (!rc) rc = fs::to_device(&A.cols, cols, (size_t)nnz, space);
     if (!rc && vals) rc = fs::to_device(&A.vals, vals, (size_t)nnz, space);
   }
+  if (!rc) rc = fs::validate_indices(nrow, ncol, nnz, A.row_ptr, nullptr, A.cols, nullptr);
   if (!rc) rc = fs::build_schedule(A, nullptr);
   if (rc) { fs::free_csr(A); delete M; return nullptr; }
   return M;
@@ -165,6 +170,7 @@ fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, cons
     if (!rc) rc = fs::to_device(&c, cols, (size_t)nnz, FS_HOST);
     if (!rc && vals) rc = fs::to_device(&v, vals, (size_t)nnz, FS_HOST);
   }
+  if (!rc) rc = fs::validate_indices(nrow, ncol, nnz, nullptr, r, c, nullptr);
   if (!rc) rc = fs::coo_to_csr_device(M->a, nrow, ncol, nnz, r, c, v, nullptr);
   if (space != FS_DEVICE) {
     if (r) (void)hipFree(r);
@@ -311,6 +317,13 @@ int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stre
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream)
 {
   if (int rc = check_mul(A, y, x, "fs_ata_mul")) return rc;
+  if (fs::options().ata_kernel == 2 && !fs::options().strict_order && !fs::options().reproducible) {
+    // the fused form (bcsr_AA_mul_B's own loop nest): one pass over A per phase, no copy of A'.  Measured slower than
+    // the two products wherever A' fits: kept for callers short of HBM and as the measured answer to
+    // SURVEY 8f-4.
+    std::lock_guard<std::mutex> g(A->lock);
+    return fs::launch_ata_fused(A->a, y, x, (hipStream_t)stream);
+  }
   if (!tmp) { set_error("fs_ata_mul: NULL scratch"); return FS_ERR_ARG; }
   if (int rc = fs_matrix_build_transpose(A, stream)) return rc;
   if (int rc = fs_spmv(A, tmp, x, stream)) return rc;
@@ -332,6 +345,7 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
   if (!rc && hipMemcpy(&last, M->row_ptr + ncell, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = FS_ERR_HIP;
   M->nnz = last;
   if (!rc) rc = fs::to_device(&M->cols, cols, (size_t)M->nnz, space);
+  if (!rc && ncell < (size_t)0x7fffffff) rc = fs::validate_indices((int)ncell, ncol, M->nnz, M->row_ptr, nullptr, M->cols, nullptr);
   // big enough to pay for a temporary of cell sums: run the cells through the chunk-streaming kernel
   if (!rc && M->nnz >= (1 << 20) && ncell < (size_t)0x7fffffff) {
     fs::DeviceCsr &c = M->cells;

@@ -184,6 +184,9 @@ struct Options {
   int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
   int ldsx = 1;          // the copy for the LDS-staged kernel: 1 when the estimates do not rule it out, 2 always, 0 never
   int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
+  int device_build = -1; // format constructors (new_csr, new_bcsr, new_cbcsr, new_bsbm, new_bsdm): -1 = FS_DEVICE_BUILD or 1;
+                         // 0 host loops, 1 on the device from 4 M entries, 2 on the device whenever one is visible
+  int ata_kernel = 0;    // fs_ata_mul: 0 / 1 two products (A, then the cached A'), 2 the fused single kernel (no copy of A')
   int spmm_kernel = 0;   // multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep (k = 2..4), 3 one
                          // single-vector sweep per column, 4 the MFMA row kernel (experiment, see spmm_mfma_kernel)
 };
@@ -193,6 +196,7 @@ Options &options();
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // may build a k-column copy
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
+int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
@@ -212,6 +216,8 @@ int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s);
 int cbcsr_rows_device(DeviceCsr &out, int nrow, int ncol, int nblocks, int64_t nnz, const int *cell_ptr_dev,
                       const int *cols_dev, hipStream_t s);
+int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, const int *rows_dev, const int *cols_dev,
+                     hipStream_t s);   // FS_ERR_ARG (with a message) when an index is out of range
 void free_csr(DeviceCsr &A);
 
 }  // namespace fs

@@ -184,6 +184,48 @@ __global__ void row_ptr_kernel(int nrow, int64_t nnz, const int *__restrict__ so
 
 static unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
+// ---- index validation at upload -------------------------------------------------------------------------
+// The reference validates nothing and a bad index there is a host segfault.  Here it would be a GPU
+// memory fault, which can take more than this process down, so every matrix is checked once when it is created:
+// columns in [0, ncol), COO rows in [0, nrow), row_ptr starting at 0, ending at nnz and never decreasing.
+__global__ void validate_kernel(int64_t nnz, int ncol, int nrow, const int *__restrict__ cols, const int *__restrict__ rows,
+                                const int *__restrict__ row_ptr, int *__restrict__ bad)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool b = false;
+  if (i < nnz) {
+    b = (unsigned)cols[i] >= (unsigned)ncol;
+    if (rows) b = b || (unsigned)rows[i] >= (unsigned)nrow;
+  }
+  if (row_ptr && i <= nrow) {
+    const int v = row_ptr[i];
+    if (i == 0 && v != 0) b = true;
+    if (i == nrow && (int64_t)v != nnz) b = true;
+    if (i < nrow && row_ptr[i + 1] < v) b = true;
+  }
+  if (b) *bad = 1;
+}
+
+int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, const int *rows_dev, const int *cols_dev,
+                     hipStream_t s)
+{
+  Scratch<int> bad;
+  FS_HIP(bad.alloc(1));
+  FS_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+  const int64_t n = nnz > (int64_t)nrow + 1 ? nnz : (int64_t)nrow + 1;
+  hipLaunchKernelGGL(validate_kernel, dim3(grid_for(n)), dim3(256), 0, s, nnz, ncol, nrow, cols_dev, rows_dev, row_ptr_dev, bad.p);
+  FS_HIP(hipGetLastError());
+  int h = 0;
+  FS_HIP(hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  if (h) {
+    set_error("matrix arrays are inconsistent: a column or row index is out of range, or row_ptr does not run from 0 to nnz "
+              "without decreasing");
+    return FS_ERR_ARG;
+  }
+  return FS_OK;
+}
+
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev, const int *cols_dev,
                       const double *vals_dev, hipStream_t s)
 {
@@ -217,6 +259,91 @@ int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int
   FS_HIP(hipGetLastError());
   FS_HIP(hipStreamSynchronize(s));
   return build_schedule(out, s);
+}
+
+// ---- the reference's format constructors on the device ----------------------------------------------------
+// new_csr / new_bcsr (csr.h:375-422, 30-67), new_cbcsr (cbcsr.h:16-65) and new_bsbm / new_bsdm (sparse.h:175-213,
+// dsparse.h:132-173) are all one operation: a STABLE bucketing of the COO entries by a key -- the row, the
+// (column block, row) cell, the row block -- followed by a copy of the payload arrays in bucket order.  On the host
+// that is a serial counting sort over nnz entries (seconds at config 3's 640 M); here the arrays are uploaded once,
+// ordered by a stable LSD radix sort of (key, entry index), gathered and downloaded.  Same arrays as the host
+// builders, element for element (tests/test_gpu_parity.py::test_device_constructors_match_oracle).
+__global__ void bucket_key_kernel(int64_t nnz, int kind, int param, int nrow, const int *__restrict__ rows,
+                                  const int *__restrict__ cols, int *__restrict__ keys)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  keys[i] = kind == 1 ? (cols[i] / param) * nrow + rows[i] : rows[i] / param;
+}
+
+__global__ void bucket_gather_kernel(int64_t nnz, const unsigned *__restrict__ perm, const int *__restrict__ rows,
+                                     const int *__restrict__ cols, const double *__restrict__ vals, int *__restrict__ rows_out,
+                                     int *__restrict__ cols_out, double *__restrict__ vals_out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const unsigned src = perm[i];
+  if (rows_out) rows_out[i] = rows[src];
+  cols_out[i] = cols[src];
+  if (vals_out) vals_out[i] = vals[src];
+}
+
+static int bucket_coo_impl(int kind, int param, int nrow, int ncol, int64_t nbuckets, int64_t nnz, const int *rows,
+                           const int *cols, const double *vals, int *offsets, int *rows_out, int *cols_out, double *vals_out)
+{
+  hipStream_t s = nullptr;
+  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+  Scratch<int> d_rows, d_cols, d_keys, d_skeys, d_off, d_rows_o, d_cols_o;
+  Scratch<double> d_vals, d_vals_o;
+  Scratch<unsigned> idx_in, idx_out;
+  Scratch<char> tmp;
+  FS_HIP(d_rows.alloc(n));
+  FS_HIP(d_cols.alloc(n));
+  FS_HIP(hipMemcpy(d_rows.p, rows, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+  FS_HIP(hipMemcpy(d_cols.p, cols, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+  if (int rc = validate_indices(nrow, ncol, nnz, nullptr, d_rows.p, d_cols.p, s)) return rc;
+  const int *keys = d_rows.p;
+  if (kind != 0) {
+    FS_HIP(d_keys.alloc(n));
+    hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, kind, param, nrow, d_rows.p, d_cols.p, d_keys.p);
+    FS_HIP(hipGetLastError());
+    keys = d_keys.p;
+  }
+  FS_HIP(d_skeys.alloc(n));
+  FS_HIP(idx_in.alloc(n));
+  FS_HIP(idx_out.alloc(n));
+  FS_HIP(d_off.alloc((size_t)nbuckets + 1));
+  if (nnz > 0) {
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_in.p);
+    FS_HIP(hipGetLastError());
+    int bits = 1;
+    while (bits < 31 && (1ll << bits) < (long long)nbuckets) ++bits;
+    size_t tmp_bytes = 0;
+    FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, d_skeys.p, idx_in.p, idx_out.p, (size_t)nnz, 0, bits, s));
+    FS_HIP(tmp.alloc(tmp_bytes));
+    FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, keys, d_skeys.p, idx_in.p, idx_out.p, (size_t)nnz, 0, bits, s));
+  }
+  hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(nbuckets + 1)), dim3(256), 0, s, (int)nbuckets, nnz, d_skeys.p, d_off.p);
+  FS_HIP(hipGetLastError());
+  FS_HIP(d_cols_o.alloc(n));
+  if (rows_out) FS_HIP(d_rows_o.alloc(n));
+  if (vals) {
+    FS_HIP(d_vals.alloc(n));
+    FS_HIP(d_vals_o.alloc(n));
+    FS_HIP(hipMemcpy(d_vals.p, vals, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+  }
+  if (nnz > 0) {
+    hipLaunchKernelGGL(bucket_gather_kernel, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, idx_out.p, d_rows.p, d_cols.p,
+                       vals ? d_vals.p : nullptr, rows_out ? d_rows_o.p : nullptr, d_cols_o.p, vals ? d_vals_o.p : nullptr);
+    FS_HIP(hipGetLastError());
+  }
+  FS_HIP(hipMemcpy(offsets, d_off.p, sizeof(int) * ((size_t)nbuckets + 1), hipMemcpyDeviceToHost));
+  if (nnz > 0) {
+    FS_HIP(hipMemcpy(cols_out, d_cols_o.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+    if (rows_out) FS_HIP(hipMemcpy(rows_out, d_rows_o.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+    if (vals) FS_HIP(hipMemcpy(vals_out, d_vals_o.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+  }
+  return FS_OK;
 }
 
 // ---- CSR -> CSR of the transpose -------------------------------------------------------------------
@@ -1055,6 +1182,31 @@ __global__ void synth_fill_kernel(int nrow, int ncol, uint64_t seed, int64_t row
 }  // namespace fs
 
 extern "C" {
+
+int fs_bucket_coo(int kind, int param, int nrow, int ncol, int64_t nbuckets, int64_t nnz, const int *rows, const int *cols,
+                  const double *vals, int *offsets, int *rows_out, int *cols_out, double *vals_out)
+{
+  if (kind < 0 || kind > 2 || (kind != 0 && param < 1) || nrow < 0 || nbuckets < 0 || nbuckets >= (1ll << 31) || nnz < 0 ||
+      nnz >= (1ll << 31) || !offsets || (nnz > 0 && (!rows || !cols || !cols_out)) || (vals && !vals_out)) {
+    fs::set_error("fs_bucket_coo: bad argument");
+    return FS_ERR_ARG;
+  }
+  return fs::bucket_coo_impl(kind, param, nrow, ncol, nbuckets, nnz, rows, cols, vals, offsets, rows_out, cols_out, vals_out);
+}
+
+/* should a constructor given nnz entries build on the device?  option device_build: 0 never, 1 when a device is
+ * visible and the matrix has at least 4 M entries (below that the host loop is faster than the PCIe round trip),
+ * 2 whenever a device is visible; the environment variable FS_DEVICE_BUILD sets the option's initial value */
+int fs_device_build_wanted(int64_t nnz)
+{
+  static const int env = [] { const char *v = getenv("FS_DEVICE_BUILD"); return v && *v ? atoi(v) : -1; }();
+  int mode = fs::options().device_build;
+  if (mode < 0) mode = env >= 0 ? env : 1;
+  if (mode == 0) return 0;
+  static const int ndev = [] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; } return n; }();
+  if (ndev < 1) return 0;
+  return mode == 2 || nnz >= (4 << 20);
+}
 
 int fs_synth_uniform(int nrow, int ncol, int per_row, uint64_t seed, int64_t row_offset, int *row_ptr_dev,
                      int *cols_dev, double *vals_dev, fs_stream_t stream)

@@ -24,6 +24,17 @@
 
 /* side table of device copies (fs_dropin.hip): a struct whose arrays go away or change roles drops its copy */
 void fs_invalidate(const void *host_struct);
+/* format construction on the device (fs_format.hip, include/fastsparse_hip.h) */
+int fs_bucket_coo(int kind, int param, int nrow, int ncol, int64_t nbuckets, int64_t nnz, const int *rows, const int *cols,
+                  const double *vals, int *offsets, int *rows_out, int *cols_out, double *vals_out);
+int fs_device_build_wanted(int64_t nnz);
+const char *fs_last_error(void);
+
+static void device_build_failed(const char *who)
+{
+  fprintf(stderr, "libfastsparse_hip: %s: building the format on the device failed: %s\n", who, fs_last_error());
+  exit(1);
+}
 
 static void *xmalloc(size_t bytes)
 {
@@ -181,9 +192,17 @@ FS_EXPORT struct SparseDoubleMatrix *read_sdm(const char *filename)
 }
 
 /* ---- CSR builders (csr.h:30-74, 375-422) ------------------------------------------------- */
-static void build_csr(int64_t nnz, int nrow, const int *rows, const int *cols, const double *vals, int **row_ptr,
+static void build_csr(int64_t nnz, int nrow, int ncol, const int *rows, const int *cols, const double *vals, int **row_ptr,
                       int **out_cols, double **out_vals)
 {
+  if (fs_device_build_wanted(nnz)) {   /* large matrices: upload once, stable device sort, download (fs_bucket_coo) */
+    *row_ptr = (int *)xmalloc(sizeof(int) * ((size_t)nrow + 1));
+    *out_cols = (int *)xmalloc(sizeof(int) * (size_t)nnz);
+    if (vals) *out_vals = (double *)xmalloc(sizeof(double) * (size_t)nnz);
+    if (fs_bucket_coo(0, 1, nrow, ncol, nrow, nnz, rows, cols, vals, *row_ptr, NULL, *out_cols, vals ? *out_vals : NULL))
+      device_build_failed("new_csr / new_bcsr");
+    return;
+  }
   int64_t *keys = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)nnz);
   int64_t *off = (int64_t *)xmalloc(sizeof(int64_t) * ((size_t)nrow + 1));
   for (int64_t k = 0; k < nnz; k++) keys[k] = rows[k];
@@ -202,7 +221,7 @@ static void build_csr(int64_t nnz, int nrow, const int *rows, const int *cols, c
 FS_EXPORT void new_bcsr(struct BinaryCSR *A, long nnz, int nrow, int ncol, int *rows, int *cols)
 {
   A->nnz = nnz; A->nrow = nrow; A->ncol = ncol;
-  build_csr(nnz, nrow, rows, cols, NULL, &A->row_ptr, &A->cols, NULL);
+  build_csr(nnz, nrow, ncol, rows, cols, NULL, &A->row_ptr, &A->cols, NULL);
 }
 
 FS_EXPORT void bcsr_from_sbm(struct BinaryCSR *A, struct SparseBinaryMatrix *sbm)
@@ -213,7 +232,7 @@ FS_EXPORT void bcsr_from_sbm(struct BinaryCSR *A, struct SparseBinaryMatrix *sbm
 FS_EXPORT void new_csr(struct CSR *A, long nnz, int nrow, int ncol, int *rows, int *cols, double *vals)
 {
   A->nnz = nnz; A->nrow = nrow; A->ncol = ncol;
-  build_csr(nnz, nrow, rows, cols, vals, &A->row_ptr, &A->cols, &A->vals);
+  build_csr(nnz, nrow, ncol, rows, cols, vals, &A->row_ptr, &A->cols, &A->vals);
 }
 
 /* ---- column-blocked binary CSR (cbcsr.h:16-73) ------------------------------------------- */
@@ -223,6 +242,13 @@ FS_EXPORT void new_cbcsr(struct ColBinaryCSR *A, int colblocksize, long nnz, int
   A->nblocks = blocks_for(ncol, colblocksize);
   A->colblocksize = colblocksize;
   int64_t ncell = (int64_t)A->nblocks * nrow;
+  if (fs_device_build_wanted(nnz) && ncell < ((int64_t)1 << 31) - 1) {
+    A->row_ptr = (int *)xmalloc(sizeof(int) * ((size_t)ncell + 1));
+    A->cols = (int *)xmalloc(sizeof(int) * (size_t)nnz);
+    if (fs_bucket_coo(1, colblocksize, nrow, ncol, ncell, nnz, rows, cols, NULL, A->row_ptr, NULL, A->cols, NULL))
+      device_build_failed("new_cbcsr");
+    return;
+  }
   int64_t *keys = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)nnz);
   int64_t *off = (int64_t *)xmalloc(sizeof(int64_t) * ((size_t)ncell + 1));
   for (int64_t k = 0; k < nnz; k++) keys[k] = (int64_t)(cols[k] / colblocksize) * nrow + rows[k];
@@ -240,7 +266,7 @@ FS_EXPORT void cbcsr_from_sbm(struct ColBinaryCSR *A, struct SparseBinaryMatrix 
 }
 
 /* ---- row-blocked COO (sparse.h:175-213, dsparse.h:132-173) --------------------------------- */
-static void build_blocks(int64_t nnz, int nrow, int block_size, const int *rows, const int *cols, const double *vals,
+static void build_blocks(int64_t nnz, int nrow, int ncol, int block_size, const int *rows, const int *cols, const double *vals,
                          int *nblocks, int **start_row, int **blk_nnz, int ***brows, int ***bcols, double ***bvals)
 {
   int nb = blocks_for(nrow, block_size);
@@ -250,6 +276,29 @@ static void build_blocks(int64_t nnz, int nrow, int block_size, const int *rows,
   *brows = (int **)xmalloc(sizeof(int *) * (size_t)nb);
   *bcols = (int **)xmalloc(sizeof(int *) * (size_t)nb);
   if (bvals) *bvals = (double **)xmalloc(sizeof(double *) * (size_t)nb);
+  if (fs_device_build_wanted(nnz)) {
+    /* entries in block order from the device, then cut into the per-block arrays the struct wants */
+    int *off32 = (int *)xmalloc(sizeof(int) * ((size_t)nb + 1));
+    int *sr = (int *)xmalloc(sizeof(int) * (size_t)nnz), *sc = (int *)xmalloc(sizeof(int) * (size_t)nnz);
+    double *sv = vals ? (double *)xmalloc(sizeof(double) * (size_t)nnz) : NULL;
+    if (fs_bucket_coo(2, block_size, nrow, ncol, nb, nnz, rows, cols, vals, off32, sr, sc, sv)) device_build_failed("new_bsbm / new_bsdm");
+    for (int b = 0; b < nb; b++) {
+      size_t n = (size_t)(off32[b + 1] - off32[b]);
+      (*start_row)[b] = b * block_size;
+      (*blk_nnz)[b] = (int)n;
+      (*brows)[b] = (int *)xmalloc(sizeof(int) * n);
+      (*bcols)[b] = (int *)xmalloc(sizeof(int) * n);
+      memcpy((*brows)[b], sr + off32[b], sizeof(int) * n);
+      memcpy((*bcols)[b], sc + off32[b], sizeof(int) * n);
+      if (bvals) {
+        (*bvals)[b] = (double *)xmalloc(sizeof(double) * n);
+        memcpy((*bvals)[b], sv + off32[b], sizeof(double) * n);
+      }
+    }
+    (*start_row)[nb] = nrow;
+    free(off32); free(sr); free(sc); free(sv);
+    return;
+  }
   int64_t *keys = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)nnz);
   int64_t *off = (int64_t *)xmalloc(sizeof(int64_t) * ((size_t)nb + 1));
   for (int64_t k = 0; k < nnz; k++) keys[k] = rows[k] / block_size;
@@ -277,7 +326,7 @@ FS_EXPORT struct BlockedSBM *new_bsbm(struct SparseBinaryMatrix *A, int block_si
 {
   struct BlockedSBM *B = (struct BlockedSBM *)xmalloc(sizeof *B);
   B->nrow = A->nrow; B->ncol = A->ncol;
-  build_blocks(A->nnz, A->nrow, block_size, A->rows, A->cols, NULL, &B->nblocks, &B->start_row, &B->nnz, &B->rows,
+  build_blocks(A->nnz, A->nrow, A->ncol, block_size, A->rows, A->cols, NULL, &B->nblocks, &B->start_row, &B->nnz, &B->rows,
                &B->cols, NULL);
   return B;
 }
@@ -286,7 +335,7 @@ FS_EXPORT struct BlockedSDM *new_bsdm(struct SparseDoubleMatrix *A, int block_si
 {
   struct BlockedSDM *B = (struct BlockedSDM *)xmalloc(sizeof *B);
   B->nrow = A->nrow; B->ncol = A->ncol;
-  build_blocks(A->nnz, A->nrow, block_size, A->rows, A->cols, A->vals, &B->nblocks, &B->start_row, &B->nnz, &B->rows,
+  build_blocks(A->nnz, A->nrow, A->ncol, block_size, A->rows, A->cols, A->vals, &B->nblocks, &B->start_row, &B->nnz, &B->rows,
                &B->cols, &B->vals);
   return B;
 }

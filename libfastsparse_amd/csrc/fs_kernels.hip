@@ -453,7 +453,12 @@ __device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, 
 // A workgroup takes one CHUNK: a contiguous range of the work items of one panel (normally the whole panel; panels
 // that hold far more than their share of the entries are cut into several chunks, whose y slices are added up in
 // HBM with atomics -- the launcher then routes the output through a zeroed scratch vector).
-template <bool VALUED, bool NT, int NSETS>
+// ATA = true turns the kernel into the fused y = A'A x of bcsr_AA_mul_B (csr.h:305-319): the sweep above leaves
+// t = (A x) of the panel's rows in the LDS slice; a second sweep over the same work items then scatters t back through
+// the tiles, y[col] += t[row], accumulating a band's slice of y in LDS (the buffer the x slices used) and adding it to
+// y in HBM with atomics whenever the sweep moves to another band.  One pass over A's copy per phase, no copy of A'.
+// Needs one chunk per panel (the launcher checks) and a zeroed y.
+template <bool VALUED, bool NT, int NSETS, bool ATA = false>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
@@ -528,11 +533,70 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     }
   }
   __syncthreads();
+  if (ATA) {
+    double *yb = xsl[0];                              // the band's slice of y (W <= kLdsxCols doubles)
+    for (int i = t; i < kLdsxCols; i += kTiledBlock) yb[i] = 0.0;
+    int band = it0 < it1 ? items[it0].z : 0;
+    __syncthreads();
+    for (int it = it0; it < it1; ++it) {
+      const int4 d = items[it];
+      if (d.z != band) {                              // wave-uniform: the sweep leaves the band, its slice goes to HBM
+        __syncthreads();
+        for (int lc = t; lc < W; lc += kTiledBlock) {
+          const double v = yb[lc];
+          if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
+          yb[lc] = 0.0;
+        }
+        band = d.z;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int q = 0; q < kLdsxPer; ++q) {
+        const int pos = q * kTiledBlock + t;
+        if (pos < d.y) {
+          const unsigned wq = pk[(int64_t)d.x + pos];
+          double pr = ytile[wq >> lcol_bits];
+          if (VALUED) pr *= vals[(int64_t)d.x + pos];
+          __hip_atomic_fetch_add(&yb[wq & cmask], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    __syncthreads();
+    for (int lc = t; lc < W; lc += kTiledBlock) {
+      const double v = yb[lc];
+      if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
+    }
+    return;
+  }
   if (shared) {
     for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
   } else {
     for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = A'A x, fused, on the plain CSR: one wave per row adds up xv = sum x[cols] and scatters it back,
+// y[cols] += xv, with HBM atomics (the loop nest of bcsr_AA_mul_B, csr.h:305-319, rows in parallel like
+// parallel_bcsr_AA_mul_B csr.h:323-355, whose per-thread replicas of y become atomics).  The general form of the
+// fused product: any matrix, no copy at all; y must be zeroed first.
+// ------------------------------------------------------------------------------------------
+template <bool VALUED>
+__global__ __launch_bounds__(kBlock) void ata_csr_kernel(int nrow, const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                        const double *__restrict__ vals, const double *__restrict__ x,
+                                                        double *__restrict__ y)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= nrow) return;
+  const int a = row_ptr[row], b = row_ptr[row + 1];
+  double acc = 0.0;
+  for (int i = a + lane; i < b; i += 64) {
+    const double xv = x[cols[i]];
+    acc += VALUED ? xv * vals[i] : xv;
+  }
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+  for (int i = a + lane; i < b; i += 64) unsafeAtomicAdd(&y[cols[i]], VALUED ? acc * vals[i] : acc);
 }
 
 // y[r * ys] = v[r] (output of a product that went through a contiguous scratch vector)
@@ -1167,6 +1231,29 @@ int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const 
       hipLaunchKernelGGL(tiled_combine_k_kernel<4>, dim3(grid), dim3(kBlock), 0, s, A.nrow, N.vfirst, N.yv, Y, ys);
     FS_HIP(hipGetLastError());
   }
+  return FS_OK;
+}
+
+// y = A'A x in one kernel (fs_ata_mul, option ata_kernel = 2): on the LDS-staged copy when the matrix has one with
+// one chunk per panel, else on the plain CSR.  y is zeroed here.
+int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
+{
+  if (A.ncol == 0) return FS_OK;
+  FS_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)A.ncol, s));
+  if (A.nrow == 0 || A.nnz == 0) return FS_OK;
+  const TiledCsr *T = A.tiledx;
+  if (T && T->built && !T->shared && T->nchunks > 0) {
+#define FS_ATA(V)                                                                                                        \
+  hipLaunchKernelGGL((spmv_ldsx_kernel<V, true, kLdsxSets, true>), dim3(T->nchunks), dim3(kTiledBlock), 0, s, T->panel_row, \
+                     T->W, T->lcol_bits, A.ncol, T->items, T->chunk_panel, T->chunk_item, T->pk, T->vals, x, y, 1, 1)
+    if (A.vals) FS_ATA(true); else FS_ATA(false);
+#undef FS_ATA
+  } else {
+    const unsigned grid = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
+    if (A.vals) hipLaunchKernelGGL(ata_csr_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.row_ptr, A.cols, A.vals, x, y);
+    else        hipLaunchKernelGGL(ata_csr_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.row_ptr, A.cols, A.vals, x, y);
+  }
+  FS_HIP(hipGetLastError());
   return FS_OK;
 }
 

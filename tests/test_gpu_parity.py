@@ -989,14 +989,16 @@ L.fs_release_all()
 libc = C.CDLL(None); libc.malloc.restype = C.c_void_p
 n = 5000
 pr = libc.malloc(4 * n); pc = libc.malloc(4 * n)
-C.memmove(pr, (np.arange(n) %% 100).astype(np.int32).ctypes.data, 4 * n)
-C.memmove(pc, (np.arange(n) * 7 %% 50).astype(np.int32).ctypes.data, 4 * n)
+a1 = (np.arange(n) %% 100).astype(np.int32); a2 = (np.arange(n) * 7 %% 50).astype(np.int32)   # named: alive during memmove
+C.memmove(pr, a1.ctypes.data, 4 * n)
+C.memmove(pc, a2.ctypes.data, 4 * n)
 L.new_sbm.restype = C.POINTER(H.SBM)
 L.new_sbm.argtypes = [C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
 S_ = L.new_sbm(100, 50, n, pr, pc)
 y1 = np.empty(100); y2 = np.empty(50)
 L.A_mul_B.restype = None; L.At_mul_B.restype = None
-L.A_mul_B(H._dp(y1), S_, H._dp(np.ones(50))); L.At_mul_B(H._dp(y2), S_, H._dp(np.ones(100)))
+o50 = np.ones(50); o100 = np.ones(100)
+L.A_mul_B(H._dp(y1), S_, H._dp(o50)); L.At_mul_B(H._dp(y2), S_, H._dp(o100))
 assert y1.sum() == n and y2.sum() == n and L.fs_cache_entries() == 2
 L.free_sbm.restype = None
 L.free_sbm(S_)
@@ -1064,3 +1066,132 @@ def test_two_host_threads_share_matrices(hip):
     ts[2].join()
     L.fs_release_all()
     assert not errors, errors
+
+
+def test_inconsistent_arrays_are_refused_at_creation(hip):
+    """the reference validates nothing (a bad index is a host segfault there); on the GPU it would be a memory fault,
+    so every matrix is checked once at creation: out-of-range columns / rows and a broken row_ptr give an error, not a
+    launch"""
+    import torch
+    from libfastsparse_amd import capi
+    rp = np.array([0, 2, 4], np.int32)
+    cc = np.array([0, 1, 2, 3], np.int32)
+    for bad_rp, bad_cc, ncol in ((rp, np.array([0, 1, 2, 4], np.int32), 4), (rp, np.array([0, -1, 2, 3], np.int32), 4),
+                                 (np.array([0, 3, 2], np.int32), cc, 4), (np.array([1, 2, 4], np.int32), cc, 4),
+                                 (np.array([0, 2, 5], np.int32), cc, 4)):
+        with pytest.raises(capi.FastsparseError, match="inconsistent"):
+            capi.Matrix.from_csr(2, ncol, bad_rp, bad_cc, None)
+    with pytest.raises(capi.FastsparseError, match="inconsistent"):
+        capi.Matrix.from_coo(2, 4, np.array([0, 2], np.int32), np.array([0, 1], np.int32), None)
+    with pytest.raises(capi.FastsparseError, match="inconsistent"):
+        capi.Matrix.from_coo(2, 4, torch.tensor([0, 1], dtype=torch.int32, device="cuda"),
+                             torch.tensor([0, 7], dtype=torch.int32, device="cuda"), None)
+    A = capi.Matrix.from_csr(2, 4, rp, cc, None)      # the consistent one still works
+    y = torch.empty(2, dtype=torch.float64, device="cuda")
+    A.spmv(y, torch.ones(4, dtype=torch.float64, device="cuda"), capi.current_stream())
+    assert y.tolist() == [2.0, 2.0]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_fused_ata_kernel_vs_reference_golden(hip, case):
+    """ata_kernel = 2: y = A'A x in ONE kernel (bcsr_AA_mul_B / parallel_bcsr_AA_mul_B, csr.h:305-355) against the
+    reference's golden outputs: 1e-12 bar, bit-exact for integer-valued x (small matrices run the CSR form)"""
+    from libfastsparse_amd import capi
+    gold = np.load(os.path.join(S.GOLDEN, case.name + ".npz"))
+    be = hip.HipDeviceBackend()
+    capi.set_option("ata_kernel", 2)
+    try:
+        out = {}
+        for tag, x in case.xs.items():
+            out["bcsr_AA_mul_B/" + tag] = be.aa_mul(case.nrow, case.ncol, case.rows, case.cols, x, False)
+    finally:
+        capi.set_option("ata_kernel", 0)
+    out = {k: v for k, v in out.items() if k.replace("/", "|") in gold}
+    assert out, "no golden bcsr_AA_mul_B output for this case"
+    _check(out, gold, case.name, exact=False)
+
+
+@pytest.mark.parametrize("valued", [False, True])
+def test_fused_ata_on_the_lds_staged_copy(hip, valued):
+    """the fused kernel's LDS-staged form (t = A x of a row panel kept in LDS, scattered back through the same tiles):
+    300 K x 40 K, 48 per row, 586 panels of 512 rows, against the oracle's two serial loops; pattern-only + integer x
+    bit for bit; the two-product form gives the same within the bar"""
+    import torch
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    nrow, ncol, per = 300_000, 40_000, 48
+    hrp, hcc, hvv = pysynth.uniform(nrow, ncol, per, 0xA7A, valued=valued)
+    capi.set_option("ldsx", 2)
+    capi.set_option("tile_rows", 512)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, hrp, hcc, hvv)
+    finally:
+        capi.set_option("ldsx", 1)
+        capi.set_option("tile_rows", 0)
+    assert A.kernel_name() == "lds-staged"
+    rows = np.repeat(np.arange(nrow, dtype=np.int32), per)
+    st = capi.current_stream()
+    y = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+    tmp = torch.empty(nrow, dtype=torch.float64, device="cuda")
+    for x in (S.x_int(8, ncol), S.x_sin(ncol)):
+        t_ref = O.csr_mul(nrow, hrp, hcc, hvv, x)
+        ref = O.coo_tmul(ncol, rows, hcc, hvv, t_ref)
+        absx = O.csr_mul(nrow, hrp, hcc, None if hvv is None else np.abs(hvv), np.abs(x))
+        scale = O.coo_tmul(ncol, rows, hcc, None if hvv is None else np.abs(hvv), absx)
+        for mode in (2, 0):
+            capi.set_option("ata_kernel", mode)
+            try:
+                A.ata(y, torch.from_numpy(x).cuda(), tmp, st)
+            finally:
+                capi.set_option("ata_kernel", 0)
+            got = y.cpu().numpy()
+            if not valued and np.all(x == np.round(x)):
+                assert np.array_equal(got, ref), mode
+            else:
+                assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300)), mode
+
+
+def test_device_constructors_match_oracle(hip):
+    """new_csr / new_bcsr / new_cbcsr / new_bsbm / new_bsdm building on the device (option device_build = 2:
+    upload, stable radix sort by row / cell / row block, download) give the reference's arrays element for element
+    (the oracle's constructors are pinned to the reference's, tests/test_oracle_vs_ref.py) -- every golden case plus a
+    5 M-entry matrix with empty rows, duplicates and a long row, which also takes the device path by default"""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    F = hip.HostFormats()
+    big_r, big_c, big_v = S.synth_coo(0xB16, 300_000, 200_000, 17, empty_frac=0.1, dup_frac=0.05, long_row=(7, 40_000))
+    cases = [(c.name, c.nrow, c.ncol, c.rows, c.cols, c.vals, c.block_sizes, c.colblocks) for c in CASES]
+    cases.append(("mid_300k", 300_000, 200_000, big_r, big_c, big_v, (4096,), (65_536,)))
+    for name, nrow, ncol, rows, cols, vals, block_sizes, colblocks in cases:
+        rows, cols = np.ascontiguousarray(rows), np.ascontiguousarray(cols)
+        v = np.ascontiguousarray(vals) if vals is not None else np.sin(np.arange(len(rows), dtype=np.float64))
+        for mode in ((2,) if name != "mid_300k" else (2, 1)):
+            capi.set_option("device_build", mode)
+            try:
+                assert capi.lib().fs_device_build_wanted(len(rows)) == 1, (name, mode)
+                A = F.csr(nrow, ncol, rows, cols, v)
+                B = F.bcsr(nrow, ncol, rows, cols)
+                rp, cc, vv = O.coo_to_csr(nrow, rows, cols, v)
+                n = len(rows)
+                assert np.array_equal(F.arr(A.row_ptr, nrow + 1, np.int32), rp) and np.array_equal(F.arr(A.cols, n, np.int32), cc)
+                assert np.array_equal(F.arr(A.vals, n, np.float64), vv), name
+                assert np.array_equal(F.arr(B.row_ptr, nrow + 1, np.int32), rp) and np.array_equal(F.arr(B.cols, n, np.int32), cc)
+                for cbs in colblocks:
+                    K = F.cbcsr(cbs, nrow, ncol, rows, cols)
+                    nb, krp, kcc = O.coo_to_cbcsr(cbs, nrow, ncol, rows, cols)
+                    assert K.nblocks == nb and np.array_equal(F.arr(K.row_ptr, nb * nrow + 1, np.int32), krp), (name, cbs)
+                    assert np.array_equal(F.arr(K.cols, n, np.int32), kcc), (name, cbs)
+                for bs in block_sizes:
+                    s_ = F.sdm(nrow, ncol, rows, cols, v)
+                    Bd = F.L.new_bsdm(C.byref(s_), bs).contents
+                    blk = O.coo_to_blocked(nrow, bs, rows, cols, v)
+                    assert Bd.nblocks == blk["nblocks"]
+                    assert np.array_equal(F.arr(Bd.start_row, Bd.nblocks + 1, np.int32), blk["start_row"])
+                    assert np.array_equal(F.arr(Bd.nnz, Bd.nblocks, np.int32), blk["blk_nnz"])
+                    for b in range(0, Bd.nblocks, max(1, Bd.nblocks // 50)):
+                        a, e = int(blk["blk_off"][b]), int(blk["blk_off"][b + 1])
+                        assert np.array_equal(F.arr(Bd.rows[b], e - a, np.int32), blk["rows"][a:e]), (name, bs, b)
+                        assert np.array_equal(F.arr(Bd.cols[b], e - a, np.int32), blk["cols"][a:e])
+                        assert np.array_equal(F.arr(Bd.vals[b], e - a, np.float64), blk["vals"][a:e])
+            finally:
+                capi.set_option("device_build", -1)

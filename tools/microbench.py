@@ -259,6 +259,92 @@ def main():
             report(out, f"c2_spmm_k{k}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
             del X, Y
         del A, rp, cc, vv
+    if "build" in what:
+        # new_bcsr on config 3's 640 M COO entries, host loop against the device build (upload + stable
+        # sort + download), host arrays in and out either way
+        import ctypes as C
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _hipbackend as H
+        nrow, ncol, per = n, max(n // 10, 1), 64
+        _, cc, _ = capi.synth_uniform(nrow, ncol, per, 0x5EED0003, valued=False)
+        hc = cc.cpu().numpy()
+        del cc
+        hr = np.repeat(np.arange(nrow, dtype=np.int32), per)
+        L = capi.lib()
+        for mode, label in ((2, "device"), (0, "host_loop"), (2, "device_again")):
+            capi.set_option("device_build", mode)
+            A = H.BCSR()
+            t0 = time.time()
+            L.new_bcsr(C.byref(A), C.c_long(len(hr)), nrow, ncol, H._ip(hr), H._ip(hc))
+            dt = time.time() - t0
+            rec = {"name": f"new_bcsr_{nrow}x{ncol}x{per}_{label}", "seconds": dt, "entries": int(len(hr))}
+            print(json.dumps(rec), flush=True)
+            out.write(json.dumps(rec) + "\n")
+            L.free_bcsr(C.byref(A))
+        capi.set_option("device_build", -1)
+    if "ata" in what:
+        # y = A'A x (bcsr_AA_mul_B): two products (A, cached A') against the fused single kernel, config 3's shape
+        nrow, ncol = n, max(n // 10, 1)
+        rp, cc, _ = capi.synth_uniform(nrow, ncol, 64, 0x5EED0003, valued=False)
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+        A.build_transpose(st)
+        x = torch.randint(-1000, 1001, (ncol,), device="cuda").to(torch.float64)
+        y = torch.empty(ncol, dtype=torch.float64, device="cuda")
+        y2 = torch.empty(ncol, dtype=torch.float64, device="cuda")
+        tmp = torch.empty(nrow, dtype=torch.float64, device="cuda")
+        B = 2 * 4 * nrow * 64 + 8 * (nrow + 1) + 16 * ncol
+        report(out, f"c3_ata_two_products_{A.kernel_name()}+{A.kernel_name(True)}", B, timeit(lambda: A.ata(y, x, tmp, st), iters=10))
+        capi.set_option("ata_kernel", 2)
+        report(out, "c3_ata_fused_single_kernel", B, timeit(lambda: A.ata(y2, x, tmp, st), iters=10))
+        capi.set_option("ata_kernel", 0)
+        print("fused == two products (integer x):", bool(torch.equal(y, y2)), flush=True)
+        del A
+    if "mall" in what:
+        # do row super-blocks whose products stay in the 256 MB Infinity Cache (with x, 80 MB, also
+        # resident) beat one sweep?  The config-2 matrix as S handles of n/S rows, each forced onto the two-pass kernels and
+        # run back to back (expand_s, reduce_s, expand_s+1, ...): the intermediate of one block is 1.31 GB / S
+        capi.set_option("binning", 2)
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        B = 12 * n * 16 + 4 * (n + 1) + 16 * n
+        for S_ in (1, 2, 4, 8, 16, 32):
+            hs = []
+            step = n // S_
+            for k in range(S_):
+                lo, hi = k * step, (n if k == S_ - 1 else (k + 1) * step)
+                rpk = (rp[lo:hi + 1] - rp[lo]).contiguous()
+                hs.append((capi.Matrix.from_csr(hi - lo, n, rpk, cc[lo * 16:hi * 16], vv[lo * 16:hi * 16], borrow=True), lo, hi))
+
+            def run():
+                for h, lo, hi in hs:
+                    h.spmv(y[lo:hi], x, st)
+            report(out, f"c2_two_pass_in_{S_}_row_superblocks_intermediate_{1311 // S_}MB", B, timeit(run))
+            del hs
+        capi.set_option("binning", 1)
+        del rp, cc, vv
+    if "spmmab" in what:
+        # multi-column products on the config-2 matrix: the k-column two-pass sweep against one sweep per column, the
+        # row kernel and (k = 32) the matrix-core experiment
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+        for k in (2, 3, 4, 8, 32):
+            X = torch.sin(torch.arange(n * k, device="cuda", dtype=torch.float64)).reshape(n, k)
+            Y = torch.empty(n, k, dtype=torch.float64, device="cuda")
+            modes = ((0, "auto"), (3, "per_column_sweeps"), (1, "row_kernel")) if k <= 4 else ((1, "row_kernel"), (4, "mfma_f64_16x16x4"))
+            for mode, label in modes:
+                capi.set_option("spmm_kernel", mode)
+                t0 = time.time()
+                A.spmm(Y, X, k, st)
+                torch.cuda.synchronize()
+                first = time.time() - t0
+                t = timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1)
+                print("first call s", first, flush=True)
+                report(out, f"c2_spmm_k{k}_{label}", A.algorithmic_bytes(k), t)
+            capi.set_option("spmm_kernel", 0)
+            del X, Y
+        del A, rp, cc, vv
     if "cbcsr" in what:
         # column-blocked binary CSR (cbcsr.h): 2 M x 1 M, 64 per row, 4 column blocks of 262144
         import numpy as np
