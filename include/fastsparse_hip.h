@@ -38,6 +38,8 @@ extern "C" {
 typedef struct fs_matrix_s *fs_matrix_t;   /* device-resident sparse matrix (CSR, valued or pattern-only) */
 typedef struct fs_cbcsr_s  *fs_cbcsr_t;    /* device-resident column-blocked binary CSR (cbcsr.h:5-14)   */
 typedef void *fs_stream_t;                 /* a hipStream_t; NULL = the legacy default stream            */
+typedef struct fs_dist_s *fs_dist_t;              /* the GPUs of one node as one context (one process, N devices, RCCL) */
+typedef struct fs_dist_matrix_s *fs_dist_matrix_t; /* a CSR row-sharded over the devices of an fs_dist_t              */
 
 enum fs_status {
   FS_OK = 0,
@@ -140,6 +142,34 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
 void fs_cbcsr_destroy(fs_cbcsr_t A);
 /* y[nrow] = A x: per column block the x tile is staged in LDS, cell sums are added block by block */
 int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream);
+
+/* ---- several GPUs, one process (fs_dist.hip) ------------------------------------------------
+ * Rows are cut into one contiguous shard per device with (almost) equal numbers of non-zeros, every device holds the
+ * whole x, multiplies its shard with the single-GPU kernels and the y shards are all-gathered over RCCL (xGMI), so that
+ * every device ends up with the whole y: the reference's row-parallel `omp parallel for` (csr.h:429) across devices
+ * (SURVEY.md 8e).  librccl.so is loaded with dlopen when a context with more than one distinct device is created.
+ * A C caller of csr_A_mul_B / bcsr_A_mul_B gets this path by setting FASTSPARSE_NGPU=N (optionally
+ * FASTSPARSE_DEVICES=0,1,...) in the environment.
+ * devices == NULL means devices 0 .. ndev-1; ndev < 1 means every visible device.  A device may be listed more than once
+ * ("virtual ranks" on one GPU, for testing the sharding on a one-GPU machine): such a context exchanges the shards
+ * with device-to-device copies, because RCCL refuses duplicate devices. */
+fs_dist_t fs_dist_create(int ndev, const int *devices);
+void fs_dist_destroy(fs_dist_t D);
+int  fs_dist_ndev(fs_dist_t D);
+int  fs_dist_uses_rccl(fs_dist_t D);
+/* host CSR arrays -> nnz-balanced row shards, one fs_matrix_t per device; vals == NULL: pattern-only */
+fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols,
+                                    const double *vals);
+void fs_dist_matrix_destroy(fs_dist_matrix_t M);
+int  fs_dist_matrix_bounds(fs_dist_matrix_t M, int *bounds /* ndev + 1 */);
+int64_t fs_dist_matrix_shard_nnz(fs_dist_matrix_t M, int rank);
+/* y[nrow] = A x[ncol] with HOST vectors: x goes to every device over its own PCIe link, y comes back from device 0 */
+int  fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host);
+/* device-resident form: fill fs_dist_x(M, r) (ncol doubles on rank r's device) on every rank, run, read fs_dist_y(M, r)
+ * (nrow doubles, complete on every rank when the call returns) */
+int  fs_dist_spmv_resident(fs_dist_matrix_t M);
+double *fs_dist_x(fs_dist_matrix_t M, int rank);
+double *fs_dist_y(fs_dist_matrix_t M, int rank);
 
 /* ---- format construction on the device ------------------------------------------------ */
 /* Stable bucketing of host COO entries, the operation behind new_csr / new_bcsr (csr.h:375-422, 30-67: kind 0, key =

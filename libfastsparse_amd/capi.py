@@ -23,6 +23,8 @@ DEVICE_API = [
     "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all", "fs_cache_entries",
     "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill", "fs_bucket_coo", "fs_device_build_wanted",
+    "fs_dist_create", "fs_dist_destroy", "fs_dist_ndev", "fs_dist_uses_rccl", "fs_dist_csr_create", "fs_dist_matrix_destroy",
+    "fs_dist_matrix_bounds", "fs_dist_matrix_shard_nnz", "fs_dist_spmv", "fs_dist_spmv_resident", "fs_dist_x", "fs_dist_y",
 ]
 REFERENCE_API = [
     # sparse.h
@@ -106,6 +108,24 @@ def lib():
     L.fs_synth_uniform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, vp, vp, vp, vp]
     L.fs_synth_powerlaw_lengths.argtypes = [C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int64, vp, vp]
     L.fs_synth_fill.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64, vp, vp, vp, vp]
+    L.fs_dist_create.restype = vp
+    L.fs_dist_create.argtypes = [C.c_int, vp]
+    L.fs_dist_destroy.argtypes = [vp]
+    L.fs_dist_destroy.restype = None
+    L.fs_dist_ndev.argtypes = [vp]
+    L.fs_dist_uses_rccl.argtypes = [vp]
+    L.fs_dist_csr_create.restype = vp
+    L.fs_dist_csr_create.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp, vp, vp]
+    L.fs_dist_matrix_destroy.argtypes = [vp]
+    L.fs_dist_matrix_destroy.restype = None
+    L.fs_dist_matrix_bounds.argtypes = [vp, vp]
+    L.fs_dist_matrix_shard_nnz.argtypes = [vp, C.c_int]
+    L.fs_dist_matrix_shard_nnz.restype = C.c_int64
+    L.fs_dist_spmv.argtypes = [vp, vp, vp]
+    L.fs_dist_spmv_resident.argtypes = [vp]
+    for f in ("fs_dist_x", "fs_dist_y"):
+        getattr(L, f).restype = vp
+        getattr(L, f).argtypes = [vp, C.c_int]
     _lib = L
     return L
 

@@ -123,6 +123,7 @@ struct KeyHash {
 struct Entry {
   fs_matrix_t m = nullptr;
   fs_cbcsr_t cb = nullptr;
+  fs_dist_matrix_t dm = nullptr;   // FASTSPARSE_NGPU > 1: the matrix row-sharded over the node's GPUs
   uint64_t print = 0;
   uint64_t tick = 0;          // last use, for eviction
   Entry() = default;
@@ -132,6 +133,7 @@ struct Entry {
   {
     if (m) fs_matrix_destroy(m);
     if (cb) fs_cbcsr_destroy(cb);
+    if (dm) fs_dist_matrix_destroy(dm);
   }
 };
 typedef std::shared_ptr<Entry> EntryP;
@@ -170,12 +172,12 @@ EntryP lookup(const void *host, int variant, uint64_t print, Build build, const 
   }
   EntryP e = std::make_shared<Entry>();
   build(*e);
-  if (!e->m && !e->cb) {
+  if (!e->m && !e->cb && !e->dm) {
     evict_lru(0);
     (void)hipGetLastError();
     build(*e);
   }
-  if (!e->m && !e->cb) die(who);
+  if (!e->m && !e->cb && !e->dm) die(who);
   e->print = print;
   e->tick = ++g_tick;
   g_table[key] = e;
@@ -236,6 +238,62 @@ void with_vectors(double *y, size_t ny, const double *x, size_t nx, Mul mul, con
     }
   } else if (hipStreamSynchronize(nullptr) != hipSuccess) {
     fs::set_error("stream synchronisation failed"); die(who);
+  }
+}
+
+// ---- several GPUs (FASTSPARSE_NGPU) ---------------------------------------------------------------------
+// csr_A_mul_B / bcsr_A_mul_B of a plain C caller across the GPUs of the node: FASTSPARSE_NGPU=N in the environment
+// (and optionally FASTSPARSE_DEVICES=0,1,...: the device of every rank).  One context for the process.
+enum { kDist = 2 };
+
+int dist_ranks() { static const int v = env_int("FASTSPARSE_NGPU", 1); return v; }
+
+fs_dist_t dist_context(const char *who)
+{
+  static std::mutex lock;
+  static fs_dist_t D = nullptr;
+  std::lock_guard<std::mutex> g(lock);
+  if (D) return D;
+  std::vector<int> devs;
+  if (const char *list = getenv("FASTSPARSE_DEVICES"))
+    for (const char *p = list; *p;) {
+      devs.push_back(atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  const int n = dist_ranks();
+  if (!devs.empty() && (int)devs.size() != n) {
+    fs::set_error("FASTSPARSE_DEVICES does not list FASTSPARSE_NGPU devices");
+    die(who);
+  }
+  D = fs_dist_create(n, devs.empty() ? nullptr : devs.data());
+  if (!D) die(who);
+  return D;
+}
+
+// y = A x on the node's GPUs: host vectors (device vectors are staged through the host: the multi-GPU entry point for
+// resident data is fs_dist_spmv_resident)
+void dist_csr_mul(double *y, const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols,
+                  const double *vals, double *x, const char *who)
+{
+  fs_dist_t D = dist_context(who);
+  const bool full = hash_in_full((int64_t)nnz * (vals ? 12 : 4) + 4 * ((int64_t)nrow + 1));
+  uint64_t h = mix(mix(mix(5, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
+  h = mix(mix(mix(h, (uint64_t)(uintptr_t)row_ptr), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
+  h = print_doubles(print_ints(print_ints(h, row_ptr, (int64_t)nrow + 1, full), cols, nnz, full), vals, nnz, full);
+  EntryP e = lookup(host, kDist, h, [&](Entry &n) { n.dm = fs_dist_csr_create(D, nrow, ncol, nnz, row_ptr, cols, vals); }, who);
+  std::vector<double> xs, ys;
+  const double *xh = x;
+  double *yh = y;
+  if (on_device(x)) {
+    xs.resize((size_t)ncol);
+    if (hipMemcpy(xs.data(), x, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost) != hipSuccess) { fs::set_error("copy of x failed"); die(who); }
+    xh = xs.data();
+  }
+  if (on_device(y)) { ys.resize((size_t)nrow); yh = ys.data(); }
+  FS_MUST(fs_dist_spmv(e->dm, yh, xh), who);
+  if (yh != y && hipMemcpy(y, yh, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice) != hipSuccess) {
+    fs::set_error("copy of y failed"); die(who);
   }
 }
 
@@ -325,7 +383,7 @@ extern "C" {
 void fs_invalidate(const void *host_struct)
 {
   std::lock_guard<std::mutex> g(g_table_lock);
-  for (int v = 0; v < 2; v++) g_table.erase(Key{host_struct, v});   // a product still running on the copy keeps it alive
+  for (int v = 0; v < 3; v++) g_table.erase(Key{host_struct, v});   // a product still running on the copy keeps it alive
 }
 
 void fs_release_all(void)
@@ -442,7 +500,11 @@ void free_csr(struct CSR *csr)
   free(csr->vals);
 }
 
-void bcsr_A_mul_B(double *y, struct BinaryCSR *A, double *x) { bcsr_mul_k(y, A, x, 1, "bcsr_A_mul_B"); }
+void bcsr_A_mul_B(double *y, struct BinaryCSR *A, double *x)
+{
+  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, x, "bcsr_A_mul_B"); return; }
+  bcsr_mul_k(y, A, x, 1, "bcsr_A_mul_B");
+}
 void bcsr_A_mul_B2(double *Y, struct BinaryCSR *A, double *X) { bcsr_mul_k(Y, A, X, 2, "bcsr_A_mul_B2"); }
 void bcsr_A_mul_B4(double *Y, struct BinaryCSR *A, double *X) { bcsr_mul_k(Y, A, X, 4, "bcsr_A_mul_B4"); }
 void bcsr_A_mul_B8(double *Y, struct BinaryCSR *A, double *X) { bcsr_mul_k(Y, A, X, 8, "bcsr_A_mul_B8"); }
@@ -486,6 +548,7 @@ void bcsr_At_mul_B(double *y, struct BinaryCSR *A, double *x)
 
 void csr_A_mul_B(double *y, struct CSR *A, double *x)
 {
+  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, x, "csr_A_mul_B"); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_B");
   fs_matrix_t m = e->m;
   with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "csr_A_mul_B");

@@ -1195,3 +1195,91 @@ def test_device_constructors_match_oracle(hip):
                         assert np.array_equal(F.arr(Bd.vals[b], e - a, np.float64), blk["vals"][a:e])
             finally:
                 capi.set_option("device_build", -1)
+
+
+def _dist_download(L, ptr, n):
+    out = np.empty(n)
+    assert L.fs_copy_to_host(out.ctypes.data, ptr, 8 * n) == 0
+    return out
+
+
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_native_multi_gpu_context_shards_by_nonzeros(hip, ranks):
+    """fs_dist_* (one process, N devices, RCCL): on this one-GPU box the ranks are virtual (device 0 listed N times,
+    shards exchanged by device copies -- RCCL refuses duplicate devices), which exercises everything but the collective:
+    the nnz-balanced cut of a power-law matrix, local row_ptr per shard, the products, the assembly of y on every rank"""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    L = capi.lib()
+    nrow = ncol = 200_000
+    rp, cc, vv = pysynth.powerlaw(nrow, ncol, 2.3, 50_000, 0xD157)
+    devs = (C.c_int * ranks)(*([0] * ranks))
+    D = L.fs_dist_create(ranks, devs)
+    assert D and L.fs_dist_ndev(D) == ranks and L.fs_dist_uses_rccl(D) == 0
+    try:
+        for vals, x in ((vv, S.x_sin(ncol)), (None, S.x_int(5, ncol))):
+            M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None if vals is None else vals.ctypes.data)
+            assert M, L.fs_last_error()
+            b = (C.c_int * (ranks + 1))()
+            assert L.fs_dist_matrix_bounds(M, b) == 0
+            b = list(b)
+            assert b[0] == 0 and b[-1] == nrow and all(b[i] <= b[i + 1] for i in range(ranks))
+            per = [int(rp[b[i + 1]] - rp[b[i]]) for i in range(ranks)]
+            assert per == [L.fs_dist_matrix_shard_nnz(M, r) for r in range(ranks)]
+            assert max(per) - min(per) <= 2 * int(np.diff(rp).max())
+            y = np.full(nrow, -1.0)
+            assert L.fs_dist_spmv(M, y.ctypes.data, x.ctypes.data) == 0, L.fs_last_error()
+            ref = O.csr_mul(nrow, rp, cc, vals, x)
+            if vals is None:
+                assert np.array_equal(y, ref)
+            else:
+                assert np.all(np.abs(y - ref) <= TOL * np.maximum(O.csr_abs_scale(nrow, rp, cc, vals, x), 1e-300))
+            for r in range(ranks):       # every rank holds the whole y
+                assert np.array_equal(_dist_download(L, L.fs_dist_y(M, r), nrow), y), r
+            L.fs_dist_matrix_destroy(M)
+    finally:
+        L.fs_dist_destroy(D)
+
+
+def test_dropin_csr_A_mul_B_across_ranks_and_rccl_on_one_device(hip):
+    """(1) FASTSPARSE_NGPU=3 FASTSPARSE_DEVICES=0,0,0: an unmodified caller of csr_A_mul_B / bcsr_A_mul_B gets the sharded
+    product.  (2) FS_DIST_FORCE_RCCL=1 with one device: librccl.so is dlopen'ed, a communicator is created and the all-gather
+    runs as a group call on the rank's stream -- the RCCL code path, as far as one GPU can take it."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _hipbackend as H
+from libfastsparse_amd import capi
+from oracle import pyoracle as O, pysynth
+L = capi.lib()
+nrow, ncol = 120_000, 90_000
+rp, cc, vv = pysynth.powerlaw(nrow, ncol, 2.3, 20_000, 77)
+x = np.sin(7.0 * np.arange(ncol) + 0.3)
+xi = (np.arange(ncol) %% 13 - 6).astype(np.float64)
+mode = sys.argv[1]
+if mode == "dropin":
+    A = H.CSR(nrow, ncol, len(cc), H._ip(rp), H._ip(cc), H._dp(vv))
+    B = H.BCSR(nrow, ncol, len(cc), H._ip(rp), H._ip(cc))
+    y = np.full(nrow, -1.0)
+    L.csr_A_mul_B.restype = None; L.bcsr_A_mul_B.restype = None
+    L.csr_A_mul_B(H._dp(y), C.byref(A), H._dp(x))
+    assert np.all(np.abs(y - O.csr_mul(nrow, rp, cc, vv, x)) <= 1e-12 * np.maximum(O.csr_abs_scale(nrow, rp, cc, vv, x), 1e-300))
+    L.bcsr_A_mul_B(H._dp(y), C.byref(B), H._dp(xi))
+    assert np.array_equal(y, O.csr_mul(nrow, rp, cc, None, xi))
+    L.fs_release_all()
+else:
+    D = L.fs_dist_create(1, None)
+    assert D and L.fs_dist_uses_rccl(D) == 1, L.fs_last_error()
+    M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None)
+    y = np.full(nrow, -1.0)
+    assert L.fs_dist_spmv(M, y.ctypes.data, xi.ctypes.data) == 0, L.fs_last_error()
+    assert np.array_equal(y, O.csr_mul(nrow, rp, cc, None, xi))
+    L.fs_dist_matrix_destroy(M); L.fs_dist_destroy(D)
+print("OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    for mode, extra in (("dropin", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}), ("rccl", {"FS_DIST_FORCE_RCCL": "1"})):
+        p = subprocess.run([sys.executable, "-c", code, mode], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, (mode, p.stdout[-1500:] + p.stderr[-1500:])
