@@ -653,6 +653,7 @@ def run_c4(args, prov, world, rank, nccl):
     X = make_x(k)
     Y = torch.empty(n, k, dtype=torch.float64, device=dev)
     nbytes = A.algorithmic_bytes(k)
+    capi.set_option("spmm_kernel", args.spmm_kernel)
 
     def step(ev=None):
         if ev is not None:
@@ -681,6 +682,7 @@ def run_c4(args, prov, world, rank, nccl):
     except Exception as ex:
         sc = {"ok": False, "error": repr(ex)}
     del X, Y
+    capi.set_option("spmm_kernel", 0)
     small = {}
     for kk in (2, 4, 8):
         Xk, Yk = make_x(kk), torch.empty(n, kk, dtype=torch.float64, device=dev)
@@ -702,8 +704,13 @@ def run_c4(args, prov, world, rank, nccl):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE config 4: CSR %d x %d, %d nnz/row, times X %d x %d row-major (csr_A_mul_Bn)" % (n, n, per, n, k),
                    "gather_traffic_model_bytes": n * per * 8 * k, "flops_per_product": 2 * k * n * per,
-                   "small_k": small, "mfma_instructions": 0, "self_check": sc},
-        "roofline": {"bound": "hbm", "kernel": "fs::spmm_kernel<valued, 5> (32 lanes per row)", "achieved": achieved,
+                   "small_k": small, "spmm_kernel_option": args.spmm_kernel,
+                   "mfma": "none: the product's k = 32 kernel is VALU (profiles/r02_c4_*: SQ_INSTS_VALU_MFMA_F64 = 0); "
+                           "--spmm-kernel 4 runs the v_mfma_f64_16x16x4_f64 experiment" if args.spmm_kernel != 4 else
+                           "v_mfma_f64_16x16x4_f64 row kernel (1/16 of each instruction's multiply-adds useful)",
+                   "self_check": sc},
+        "roofline": {"bound": "hbm", "kernel": "fs::spmm_kernel<valued, 5> (32 lanes per row)" if args.spmm_kernel != 4 else
+                     "fs::spmm_mfma_kernel<valued>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": _traffic(("spmm_k32",), "c4", n, per),
                      "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_timed": args.steps},
@@ -920,6 +927,8 @@ def main():
     ap.add_argument("--c5-rows", type=int, default=100_000_000, help="rows = columns of the config-5 matrix")
     ap.add_argument("--transpose", action="store_true", help="c5, N > 1: also time z = A' u")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spmm-kernel", type=int, default=0,
+                    help="c4: 0 the product's choice, 1 row kernel, 4 the matrix-core experiment (profiling runs)")
     args = ap.parse_args()
 
     # ---- ranks: a launcher's world must be the one asked for; without a launcher, start the ranks here, before this

@@ -70,6 +70,12 @@ def lib():
     L = C.CDLL(LIB_PATH)   # RTLD_LOCAL: the reference-named symbols must not interpose other libraries
     L.fs_version.restype = C.c_char_p
     L.fs_last_error.restype = C.c_char_p
+    L.fs_device_alloc.restype = vp
+    L.fs_device_alloc.argtypes = [C.c_int64]
+    L.fs_device_free.argtypes = [vp]
+    L.fs_device_free.restype = None
+    L.fs_copy_to_device.argtypes = [vp, vp, C.c_int64]
+    L.fs_copy_to_host.argtypes = [vp, vp, C.c_int64]
     L.fs_set_option.argtypes = [C.c_char_p, C.c_int]
     L.fs_get_option.argtypes = [C.c_char_p]
     L.fs_csr_create.restype = vp

@@ -85,7 +85,7 @@ struct TiledCsr {
   // cut into several, whose y slices are then added up in HBM.  Rows are never cut into virtual rows here.
   int nchunks = 0;
   int *chunk_panel = nullptr;  // nchunks: panel of the chunk; bit 31 set when the panel has more than one chunk
-  int *chunk_item = nullptr;   // nchunks + 1: first work item of every chunk
+  int *chunk_item = nullptr;   // 2 * nchunks: [first, one past the last) work item of every chunk
   bool shared = false;         // some panel has more than one chunk: products go through the zeroed scratch vector yv
 };
 

@@ -779,7 +779,9 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
       return a.first > b.first || (a.first == b.first && a.second < b.second);
     });
     for (size_t f = 0; f < frac.size() && given < total; ++f, ++given) ++k_p[frac[f].second];
-    std::vector<int> chunk_panel, chunk_item;
+    // chunk = (panel | shared flag, first item, one past the last item)
+    struct Chunk { int panel, first, last, ordinal; };
+    std::vector<Chunk> chunks;
     for (int p = 0; p < P; ++p) {
       const int i0 = item_ptr[p], i1 = item_ptr[p + 1], k = k_p[p];
       const int flag = k > 1 ? (int)0x80000000u : 0;
@@ -787,19 +789,33 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
       int i = i0;
       int64_t done = 0;
       for (int c = 0; c < k; ++c) {
-        chunk_panel.push_back(p | flag);
-        chunk_item.push_back(i);
+        const int first = i;
         const int64_t goal = nnz_p[p] * (c + 1) / k;
         while (i < i1 && (done < goal || c == k - 1)) done += items[i++].y;
+        chunks.push_back(Chunk{p | flag, first, i, c});
       }
     }
-    chunk_item.push_back((int)items.size());
+    // Launch order.  Workgroups that run together should sweep the SAME column bands, so that a band's slice of x
+    // comes out of the XCD's L2 for all but the first of them: with several chunks per panel (few, long rows: config
+    // 3 transposed, 66 panels x 31 chunks) the c-th chunks of all panels -- the same stretch of bands -- are launched
+    // next to each other instead of panel by panel.  Blocks b and b + 8 share an XCD, so every XCD gets a share of
+    // each stretch.  (Panel-major order read every slice from the Infinity Cache 66 times: 5.3 GB of slices against
+    // 2.6 GB of entries, 1.84 ms; this order 1.06 ms.)
+    if (T->shared)
+      std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.ordinal < b.ordinal; });
+    std::vector<int> chunk_panel, chunk_item;
+    for (const Chunk &c : chunks) {
+      chunk_panel.push_back(c.panel);
+      chunk_item.push_back(c.first);
+      chunk_item.push_back(c.last);
+    }
     T->nchunks = (int)chunk_panel.size();
     FS_HIP(hipMalloc(&T->chunk_panel, sizeof(int) * (chunk_panel.size() ? chunk_panel.size() : 1)));
-    FS_HIP(hipMalloc(&T->chunk_item, sizeof(int) * chunk_item.size()));
-    if (!chunk_panel.empty())
+    FS_HIP(hipMalloc(&T->chunk_item, sizeof(int) * (chunk_item.size() ? chunk_item.size() : 2)));
+    if (!chunk_panel.empty()) {
       FS_HIP(hipMemcpy(T->chunk_panel, chunk_panel.data(), sizeof(int) * chunk_panel.size(), hipMemcpyHostToDevice));
-    FS_HIP(hipMemcpy(T->chunk_item, chunk_item.data(), sizeof(int) * chunk_item.size(), hipMemcpyHostToDevice));
+      FS_HIP(hipMemcpy(T->chunk_item, chunk_item.data(), sizeof(int) * chunk_item.size(), hipMemcpyHostToDevice));
+    }
     if (T->shared && !T->yv) FS_HIP(hipMalloc(&T->yv, sizeof(double) * (size_t)A.nrow));
   }
   T->built = true;

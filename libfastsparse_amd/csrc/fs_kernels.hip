@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
   const int nr = panel_row[p + 1] - row0;
   for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
   const unsigned cmask = (1u << lcol_bits) - 1u;
-  const int it0 = chunk_item[blockIdx.x], it1 = chunk_item[blockIdx.x + 1];
+  const int it0 = chunk_item[2 * blockIdx.x], it1 = chunk_item[2 * blockIdx.x + 1];   // [first, last) work item of the chunk
   // descriptor reads outside the chunk are clamped to its items (an empty chunk reads the item in front of it; the
   // array always holds at least one) ...
   const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
@@ -521,6 +521,11 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
         if (pos < dset[s0].y) {
           double pr = xsl[buf][w[s0][q] & cmask];
           if (VALUED) pr *= v[s0][q];
+#ifdef FS_EXP_VALU
+          { unsigned dummy = w[s0][q];
+#pragma unroll
+            for (int z = 0; z < FS_EXP_VALU; ++z) asm volatile("v_xor_b32 %0, %0, %0" : "+v"(dummy)); }
+#endif
           __hip_atomic_fetch_add(&ytile[w[s0][q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }

@@ -104,6 +104,73 @@ def main():
         report(out, f"c2_hybrid_tiled_part_alone", B, timeit(lambda: A1.spmv(y[:n1], x, st)))
         report(out, f"c2_hybrid_two_pass_part_alone", B, timeit(lambda: A2.spmv(y[n1:], x, st)))
         del A1, A2
+    if "hybridmask" in what:
+        # Two different bottlenecks at once?  The tiled kernel is bound by L2 gather requests, the two-pass pair by HBM bytes.
+        # Rows split between a tiled handle and a two-pass handle, each on a stream masked to its own set of CUs
+        # (hipExtStreamCreateWithCUMask), so that the two really run side by side (unmasked, two 1024-thread workgroups
+        # with > 100 KB of LDS each cannot share a CU and the launches take turns).
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
+        x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        B = 12 * n * 16 + 4 * (n + 1) + 16 * n
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        words = (ncu + 31) // 32
+
+        def masked_stream(pred):
+            m = (C.c_uint32 * words)()
+            for cu in range(ncu):
+                if pred(cu):
+                    m[cu // 32] |= 1 << (cu % 32)
+            st_ = C.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(st_), words, m)
+            assert rc == 0, rc
+            return st_
+
+        for frac, cu_share, pattern in ((0.45, 0.5, "alt"), (0.45, 0.5, "half"), (0.35, 0.375, "alt"), (0.55, 0.625, "alt"), (0.5, 0.5, "alt")):
+            n1 = int(n * frac) // 1024 * 1024
+            capi.set_option("tiling", 2)
+            A1 = capi.Matrix.from_csr(n1, n, rp[:n1 + 1].contiguous(), cc[:n1 * 16], vv[:n1 * 16], borrow=True)
+            capi.set_option("tiling", 1)
+            capi.set_option("binning", 2)
+            A2 = capi.Matrix.from_csr(n - n1, n, (rp[n1:] - rp[n1]).contiguous(), cc[n1 * 16:], vv[n1 * 16:], borrow=True)
+            capi.set_option("binning", 1)
+            k8 = int(round(cu_share * 8))
+            if pattern == "alt":      # cu % 8 < k8 -> tiled: the same share of every XCD under either CU numbering
+                s1 = masked_stream(lambda cu: cu % 8 < k8)
+                s2 = masked_stream(lambda cu: cu % 8 >= k8)
+            else:                     # contiguous halves
+                s1 = masked_stream(lambda cu: cu < int(ncu * cu_share))
+                s2 = masked_stream(lambda cu: cu >= int(ncu * cu_share))
+            torch.cuda.synchronize()
+
+            def both():
+                A1.spmv(y[:n1], x, s1.value)
+                A2.spmv(y[n1:], x, s2.value)
+
+            def wall(fn, iters=20):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / iters * 1e3
+            t_both = wall(both)
+            t1 = wall(lambda: A1.spmv(y[:n1], x, s1.value))
+            t2 = wall(lambda: A2.spmv(y[n1:], x, s2.value))
+            t1f = wall(lambda: A1.spmv(y[:n1], x, st))
+            t2f = wall(lambda: A2.spmv(y[n1:], x, st))
+            rec = {"name": f"c2_hybrid_cu_masked_rows{frac}_cus{cu_share}_{pattern}", "ms_both_concurrent": t_both,
+                   "ms_tiled_part_on_its_cus": t1, "ms_two_pass_part_on_its_cus": t2, "ms_tiled_part_all_cus": t1f,
+                   "ms_two_pass_part_all_cus": t2f, "kernels": [A1.kernel_name(), A2.kernel_name()],
+                   "GBs_both": B / t_both / 1e6, "frac_of_8TBs": B / t_both / 1e6 / 8000}
+            print(json.dumps(rec), flush=True)
+            out.write(json.dumps(rec) + "\n")
+            del A1, A2
+        del rp, cc, vv
     if "wgs" in what:
         # pass-1 time of the two-pass pair against the number of persistent workgroups (= the share size): HBM channel camping?
         capi.set_option("binning", 2)

@@ -4,7 +4,8 @@
     python tools/pmc_summary.py gpurun_out/prof_v4/fetch gpurun_out/prof_v4/write gpurun_out/prof_v4/tcc > profiles/xyz.csv
 
 Counter values of one dispatch are summed over the rows rocprofv3 writes for it (one per counter instance), then
-averaged over the dispatches of a kernel.  Only kernels of namespace fs:: are listed."""
+averaged over the dispatches of a kernel with the same grid (the same kernel runs on A and on A', whose grids differ).
+Only the product kernels of namespace fs:: (spmv_*, spmm_*, cbcsr_*, ata_*) are listed unless --all is given."""
 import csv
 import glob
 import os
@@ -19,19 +20,22 @@ def short(name):
 
 
 def main():
-    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> dispatch -> value
-    for d in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if a != "--all"]
+    everything = "--all" in sys.argv
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # (kernel, grid) -> counter -> dispatch -> value
+    for d in args:
         for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
             for row in csv.DictReader(open(f)):
                 k = short(row["Kernel_Name"])
-                if k:
-                    per[k][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                if k and (everything or re.match(r"fs::(spmv_|spmm_|cbcsr_|ata_|tiled_combine|strided_copy)", k)):
+                    per[(k, int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1))][row["Counter_Name"]][row["Dispatch_Id"]] \
+                        += float(row["Counter_Value"])
     counters = sorted({c for k in per for c in per[k]})
     w = csv.writer(sys.stdout)
-    w.writerow(["kernel", "dispatches"] + ["mean_" + c for c in counters])
+    w.writerow(["kernel", "workgroups", "dispatches"] + ["mean_" + c for c in counters])
     for k in sorted(per):
         n = max(len(v) for v in per[k].values())
-        w.writerow([k, n] + ["%.3f" % (sum(per[k][c].values()) / len(per[k][c])) if per[k][c] else "" for c in counters])
+        w.writerow([k[0], k[1], n] + ["%.3f" % (sum(per[k][c].values()) / len(per[k][c])) if per[k][c] else "" for c in counters])
 
 
 if __name__ == "__main__":
