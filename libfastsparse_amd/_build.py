@@ -40,6 +40,8 @@ def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libfastsparse_hip.so."""
     os.makedirs(OBJ, exist_ok=True)
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    extra = os.environ.get("FS_HIPCC_EXTRA", "").split()      # experiments (e.g. -DFS_EXP_VALU=8); implies a full rebuild
+    force = force or bool(extra)
     objs = []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
@@ -47,7 +49,7 @@ def build(force=False, verbose=False):
         if force or _stale(o, [s] + HEADERS):
             # -ffp-contract=off: products and sums round separately, like the strict CPU loops
             _run([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                  "-Wall", "-Wno-unused-result"] + inc + ["-c", s, "-o", o], verbose)
+                  "-Wall", "-Wno-unused-result"] + extra + inc + ["-c", s, "-o", o], verbose)
         objs.append(o)
     for src in C_SOURCES:
         s = os.path.join(CSRC, src)

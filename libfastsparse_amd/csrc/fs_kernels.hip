@@ -1112,16 +1112,34 @@ static int ceil_log2(int v)
   return lg;
 }
 
-// y[r] = sum of the virtual rows of row r, in storage order (rows that were not cut: a copy)
+// y[r] = sum of the virtual rows of row r (rows that were not cut: a copy).  Up to 32 pieces: one thread, in storage
+// order.  Longer rows (a power-law matrix has rows of 10^5..10^6 entries = thousands of pieces) are summed by the whole
+// wave, 64 pieces per step and a butterfly at the end -- a fixed order, so still reproducible run to run; one thread
+// walking 3 900 dependent loads made this pass 0.49 ms of a 2.9 ms product on a config-5 shard
+// (profiles/r02_c5_pmc_summary.csv).
 __global__ __launch_bounds__(kBlock) void tiled_combine_kernel(int nrow, const int *__restrict__ vfirst,
                                                               const double *__restrict__ yv, double *__restrict__ y, int ys)
 {
   const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= nrow) return;
-  const int a = vfirst[r], b = vfirst[r + 1];
-  double acc = yv[a];
-  for (int v = a + 1; v < b; ++v) acc += yv[v];
-  y[r * ys] = acc;
+  const int lane = threadIdx.x & 63;
+  int a = 0, b = 0;
+  if (r < nrow) { a = vfirst[r]; b = vfirst[r + 1]; }
+  const bool long_row = b - a > 32;
+  if (r < nrow && !long_row) {
+    double acc = yv[a];
+    for (int v = a + 1; v < b; ++v) acc += yv[v];
+    y[r * ys] = acc;
+  }
+  unsigned long long todo = __ballot(long_row);
+  while (todo) {                                   // wave-uniform
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int ra = __shfl(a, src), rb = __shfl(b, src);
+    double acc = 0.0;
+    for (int v = ra + lane; v < rb; v += 64) acc += yv[v];
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == src) y[r * ys] = acc;
+  }
 }
 
 int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs, int ys)
