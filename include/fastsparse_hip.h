@@ -66,10 +66,15 @@ int  fs_set_device(int device);
  * and at every product).
  * Options are process-wide.
  *
- * Threads and streams: every entry point may be called from several host threads.  A handle keeps scratch
- * vectors for some kernels (rows that cross chunks in the streaming kernel, sums of cut rows in the tiled
- * kernel, products of the two-pass kernels), so SpMV launches on ONE handle must not overlap in time on different streams: order them, or use
- * one handle per stream.  The multi-column products (k >= 3) and distinct handles are unrestricted.
+ * Threads and streams: every entry point may be called from several host threads; launches on one handle are serialised by
+ * a lock.  A handle keeps scratch vectors for some kernels (rows that cross chunks in the streaming kernel, sums of cut rows in
+ * the tiled kernel, the products of the two-pass kernels for k = 1 and for the k-column sweeps k = 2..4, the cell sums of a
+ * column-blocked matrix), so products on ONE handle must not overlap in time on different streams: order them, or use one
+ * handle per stream.  Only the row kernel (multi-column products with k >= 5, or option "spmm_kernel" = 1) and distinct handles
+ * are unrestricted.
+ * "spmm_kernel" (multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep for k = 2..4, 3 one single-vector sweep
+ * per column, 4 the v_mfma_f64_16x16x4_f64 experiment), "ata_kernel" (fs_ata_mul: 0 two products, 2 the fused single kernel),
+ * "device_build" (format constructors: 0 host loops, 1 on the device from 4 M entries, 2 on the device always).
  * "tile_split": rows longer than this are cut into virtual rows in the tiled copy (0 = 256). */
 int  fs_set_option(const char *name, int value);
 int  fs_get_option(const char *name);

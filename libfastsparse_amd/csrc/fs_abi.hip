@@ -383,6 +383,7 @@ void fs_cbcsr_destroy(fs_cbcsr_t A)
 int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream)
 {
   if (!A || !y || !x) { set_error("fs_cbcsr_spmv: NULL argument"); return FS_ERR_ARG; }
+  std::lock_guard<std::mutex> g(A->lock);
   return fs::launch_cbcsr(*A, y, x, (hipStream_t)stream);
 }
 

@@ -61,7 +61,7 @@ constexpr int kTiledItem = 2048;       // entries per work item (4 per producer 
 constexpr int kTiledRowsMax = 13056;   // R <= this: 102 KiB of y per workgroup
 constexpr int kTiledColBits = 18;      // W <= 262144 columns (2 MiB of x); the other 14 bits are the local row
 
-constexpr int kLdsxRows = 15360;       // LDS-staged kernel: rows per panel (120 KiB of y in LDS)
+constexpr int kLdsxRows = 14336;       // LDS-staged kernel: rows per panel (112 KiB of y in LDS, + 3 x 16 KiB slices = 160 KiB)
 constexpr int kLdsxCols = 2048;        //                    columns per band: one 16 KiB slice of x, two slices in LDS
 
 struct TiledCsr {
@@ -154,6 +154,7 @@ struct fs_cbcsr_s {
   // product runs on whatever kernel the format builder measures fastest (the LDS-staged kernel for dense tiles)
   fs::DeviceCsr rows;
   bool use_rows = false;
+  std::mutex lock;             // serialises products (cell sums and the chunk scratch are per handle)
 };
 
 namespace fs {

@@ -559,6 +559,12 @@ __global__ __launch_bounds__(256) void ldsx_reorder_kernel(const int4 *__restric
     int pos = 0;
 #pragma unroll
     for (int k = 0; k < 32; ++k) pos += (cnt[k] < r ? cnt[k] : r) + ((k < c && cnt[k] > r) ? 1 : 0);
+    // `pos` is the place in the round-robin sequence.  The kernel's thread t takes the ADJACENT entries 2t and 2t+1 (one
+    // 8-byte load), so the lanes of a wave see, for their first entry, every other stored position: the first half of
+    // the sequence goes to the even positions, the second half to the odd ones, and each of the two adds of a wave
+    // still walks consecutive members of the sequence.
+    const int half = (n + 1) >> 1;
+    pos = pos < half ? 2 * pos : 2 * (pos - half) + 1;
     pk[(int64_t)d.x + pos] = w[i];
     if (vals) vals[(int64_t)d.x + pos] = v[i];
   }
@@ -673,6 +679,7 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   }
   if (W > w_max) W = w_max;
   if (W > A.ncol) W = A.ncol;
+  if (ldsx && (W & 1) && W < w_max) ++W;   // slices are loaded two columns per thread
   const int J = (A.ncol + W - 1) / W;
   const int64_t ntiles = (int64_t)P * J;
   if (mode == 1 && ldsx) {
@@ -710,8 +717,8 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   FS_HIP(idx_in.alloc(n));
   FS_HIP(idx_out.alloc(n));
   FS_HIP(tile_ptr.alloc((size_t)ntiles + 1));
-  FS_HIP(hipMalloc(&T->pk, sizeof(unsigned) * n));
-  if (A.vals) FS_HIP(hipMalloc(&T->vals, sizeof(double) * n));
+  FS_HIP(hipMalloc(&T->pk, sizeof(unsigned) * (n + 8)));          // + slack: the LDS-staged kernel loads entries in pairs
+  if (A.vals) FS_HIP(hipMalloc(&T->vals, sizeof(double) * (n + 8)));
   hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, nvrow, A.nnz, P, W, J, vrow_ptr, T->panel_row,
                      A.cols, vrows.p, keys.p);
   hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
@@ -1128,9 +1135,14 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   if (t_tiled < best) best = t_tiled;
   if (t_ldsx < best) best = t_ldsx;
   if (t_bin < best) best = t_bin;
-  if (!(hb && t_bin == best)) free_binned(A);
-  if (!(hx && t_ldsx == best) || A.binned) free_tiledx(A);
-  if (!(ht && t_tiled == best) || A.binned || A.tiledx) free_tiled(A);
+  // Candidates within 5 % of the fastest count as equal (box-to-box and run-to-run differences are of that size) and a
+  // fixed priority decides between them -- two-pass, LDS-staged, L2-tiled, streaming -- so that the same matrix gets the
+  // same kernel (and the same summation order) on every run and for A as for A' unless one kernel really is faster.
+  const float tie = best * 1.05f;
+  const int keep = (hb && t_bin <= tie) ? 3 : (hx && t_ldsx <= tie) ? 2 : (ht && t_tiled <= tie) ? 1 : 0;
+  if (keep != 3) free_binned(A);
+  if (keep != 2) free_tiledx(A);
+  if (keep != 1) free_tiled(A);
   return FS_OK;
 }
 

@@ -604,6 +604,145 @@ __global__ __launch_bounds__(kBlock) void ata_csr_kernel(int nrow, const int *__
   for (int i = a + lane; i < b; i += 64) unsafeAtomicAdd(&y[cols[i]], VALUED ? acc * vals[i] : acc);
 }
 
+// The same sweep with (1) the LDS work of consecutive items overlapped and (2) half as many vector-memory instructions.
+//
+// (1) In spmv_ldsx_kernel a phase is a dependency chain per wave -- gather, wait, add, gather, wait, add, publish, drain,
+// barrier -- that all 16 waves walk in step.  Here item k's slice is published in phase k-2, its x values are gathered in
+// phase k-1 and added in phase k: nothing inside a phase waits for anything issued in it.  Costs a third slice buffer
+// (panels of <= 14336 rows) and two more register sets.  Worth 2 % (A) to 8 % (A') on config 3.
+// (2) What the kernel was really bound by (ablation, gpurun_out/r2n: without its global loads 0.52 ms, with them 0.88 ms,
+// while dropping the atomics, the gathers or the slice writes gained 4-5 % each and deeper pipelines nothing): the number
+// of vector-memory INSTRUCTIONS.  A wave64 memory instruction occupies the CU's address unit for ~16 cycles whatever its
+// width, and a phase issued 64 of them (two 4-byte entry loads and two 8-byte slice loads per thread): ~1000 of the
+// phase's ~1400 cycles.  Now a thread loads its two entries -- adjacent ones, the builder arranges the items for that
+// (ldsx_reorder_kernel) -- with ONE 8-byte load and its two slice values with ONE 16-byte load.
+typedef unsigned v2u_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool XS1>
+__device__ __forceinline__ void ldsx_load2_slice(const int4 d, int t, int W, int ncol, const double *__restrict__ x, int xs,
+                                                 double (&xr)[2])
+{
+  const int c0 = d.z * W + 2 * t;
+  // the pair clamped into the vector: past the end it is (ncol-2, ncol-1), so the LAST column arrives in the second value
+  // when c0 == ncol - 1; which value is which is sorted out when the slice is published -- no select next to the load
+  const int cc = c0 + 1 < ncol ? c0 : (ncol >= 2 ? ncol - 2 : 0);
+  if (XS1) {
+    const v2d_a8 p = *reinterpret_cast<const v2d_a8 *>(x + cc);
+    xr[0] = p.x; xr[1] = p.y;
+  } else {
+    xr[0] = x[(int64_t)cc * xs];
+    xr[1] = x[(int64_t)(cc + 1 < ncol ? cc + 1 : cc) * xs];
+  }
+}
+
+template <bool VALUED, bool NT>
+__device__ __forceinline__ void ldsx_load2_entries(const int4 d, int t, const unsigned *__restrict__ pk,
+                                                   const double *__restrict__ vals, unsigned (&w)[2], double (&v)[2])
+{
+  // entries 2t, 2t+1 of the item; threads wholly past its end re-read its first pair (masked at the add), the thread
+  // on an odd end reads one entry of the next item (or of the slack behind the array), masked too
+  const int64_t e = (int64_t)d.x + (2 * t < d.y ? 2 * t : 0);
+  const v2u_a4 pw = stream_load<NT>(reinterpret_cast<const v2u_a4 *>(pk + e));
+  w[0] = pw.x; w[1] = pw.y;
+  if (VALUED) {
+    const v2d_a8 pv = stream_load<NT>(reinterpret_cast<const v2d_a8 *>(vals + e));
+    v[0] = pv.x; v[1] = pv.y;
+  }
+}
+
+#ifndef FS_PIPE_SETS
+#define FS_PIPE_SETS 6
+#endif
+constexpr int kLdsxPipeSets = FS_PIPE_SETS;       // item k requested in phase k-5, its slice needed in phase k-2
+
+template <bool VALUED, bool NT, bool XS1, int NSETS>
+__global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_pipe_kernel(
+    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
+    const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
+    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
+{
+  static_assert(kLdsxPer == 2 && kLdsxXPer == 2, "pair loads assume two entries and two slice values per thread");
+  __shared__ double ytile[kLdsxRows];
+  __shared__ __attribute__((aligned(16))) double xsl[3][kLdsxCols];
+  const int t = threadIdx.x;
+  const int cp = chunk_panel[blockIdx.x];
+  const int p = cp & 0x7fffffff;
+  const bool shared = cp < 0;
+  const int row0 = panel_row[p];
+  const int nr = panel_row[p + 1] - row0;
+  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
+  const unsigned cmask = (1u << lcol_bits) - 1u;
+  const int it0 = chunk_item[2 * blockIdx.x], it1 = chunk_item[2 * blockIdx.x + 1];
+  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
+  const int itf = it1 > it0 ? it0 : itl;
+  auto item = [&](int i) {
+    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
+    if (i < it0 || i >= it1) d.y = 0;
+    return d;
+  };
+  int4 dset[NSETS];
+  unsigned w[NSETS][2];
+  double v[NSETS][2];
+  double xr[NSETS][2];
+#pragma unroll
+  for (int k = 0; k < NSETS; ++k) {
+    dset[k] = item(it0 - 1);
+    w[k][0] = w[k][1] = 0;
+    v[k][0] = v[k][1] = 0.0;
+    xr[k][0] = xr[k][1] = 0.0;
+  }
+  double gcur[2] = {0.0, 0.0};
+  const int first = it0 - (NSETS - 1);
+  int4 dN = item(first + NSETS - 1);
+  int bi = 0;                                     // slice buffer of item IT: (IT - first) % 3
+  __syncthreads();
+  // phase IT: request item IT+NSETS-1; gather item IT+1 (slice published a phase ago); add item IT (values gathered a
+  // phase ago); publish the slice of item IT+2; barrier
+  for (int it = first; it < it1; it += NSETS) {
+#pragma unroll
+    for (int ph = 0; ph < NSETS; ++ph) {
+      const int IT = it + ph;
+      const int s0 = ph, s1 = (ph + 1) % NSETS, s2 = (ph + 2) % NSETS, sl = (ph + NSETS - 1) % NSETS;
+      dset[sl] = dN;
+      dN = item(IT + NSETS);
+      // the phase's memory instructions are spread between its LDS work (slice first: needed a phase before the
+      // entries, and vmcnt retires in order): issued in one burst at the top, the 32 wave-instructions of a phase queue up
+      // in front of the address unit and the waves stall at issue while the LDS array idles
+      const int b1 = bi == 2 ? 0 : bi + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+      double gnew[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) gnew[q] = xsl[b1][w[s1][q] & cmask];
+      ldsx_load2_slice<XS1>(dset[sl], t, W, ncol, x, xs, xr[sl]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (2 * t + q < dset[s0].y) {
+          double pr = gcur[q];
+          if (VALUED) pr *= v[s0][q];
+          __hip_atomic_fetch_add(&ytile[w[s0][q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
+      {
+        const int lc = 2 * t, c = dset[s2].z * W + lc;
+        v2d sv;
+        sv.x = (lc < W && c < ncol) ? ((c + 1 == ncol && ncol >= 2) ? xr[s2][1] : xr[s2][0]) : 0.0;   // see ldsx_load2
+        sv.y = (lc + 1 < W && c + 1 < ncol) ? xr[s2][1] : 0.0;
+        *reinterpret_cast<v2d *>(&xsl[b2][lc]) = sv;
+      }
+      __syncthreads();
+      gcur[0] = gnew[0]; gcur[1] = gnew[1];
+      bi = b1;
+    }
+  }
+  __syncthreads();
+  if (shared) {
+    for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
+  } else {
+    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+  }
+}
+
 // y[r * ys] = v[r] (output of a product that went through a contiguous scratch vector)
 __global__ __launch_bounds__(kBlock) void strided_copy_kernel(int n, const double *__restrict__ v, double *__restrict__ y, int ys)
 {
@@ -1158,9 +1297,20 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
 #define FS_LDSX(V, N)                                                                                              \
   hipLaunchKernelGGL((spmv_ldsx_kernel<V, N, kLdsxSets>), dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
                      T.lcol_bits, A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
-      if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
-      else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
+#define FS_LDSXP(V, N, X1)                                                                                         \
+  hipLaunchKernelGGL((spmv_ldsx_pipe_kernel<V, N, X1, kLdsxPipeSets>), dim3(T.nchunks), dim3(kTiledBlock), 0, s,     \
+                     T.panel_row, T.W, T.lcol_bits, A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
+      if (options().tiled_flags & 2) {             // bit 1: the first version (gather and add of an item in one phase)
+        if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
+        else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
+      } else if (xs == 1 && A.ncol >= 2) {
+        if (A.vals) { if (nt) FS_LDSXP(true, true, true); else FS_LDSXP(true, false, true); }
+        else        { if (nt) FS_LDSXP(false, true, true); else FS_LDSXP(false, false, true); }
+      } else {                                     // one column of a row-major X: strided slice loads
+        if (A.vals) FS_LDSXP(true, true, false); else FS_LDSXP(false, true, false);
+      }
 #undef FS_LDSX
+#undef FS_LDSXP
       FS_HIP(hipGetLastError());
     }
     if (T.shared) {
