@@ -147,6 +147,7 @@ fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, c
   }
   if (!rc) rc = fs::validate_indices(nrow, ncol, nnz, A.row_ptr, nullptr, A.cols, nullptr);
   if (!rc) rc = fs::build_schedule(A, nullptr);
+  fs::pool_trim();
   if (rc) { fs::free_csr(A); delete M; return nullptr; }
   return M;
 }
@@ -177,6 +178,7 @@ fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, cons
     if (c) (void)hipFree(c);
     if (v) (void)hipFree(v);
   }
+  fs::pool_trim();
   if (rc) { fs::free_csr(M->a); delete M; return nullptr; }
   return M;
 }
@@ -195,6 +197,7 @@ int fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream)
   std::lock_guard<std::mutex> g(A->lock);
   if (A->has_t) return FS_OK;
   const int rc = fs::transpose_device(A->a, A->at, (hipStream_t)stream);
+  fs::pool_trim();
   if (rc) { fs::free_csr(A->at); return rc; }
   A->has_t = true;
   return FS_OK;
@@ -365,6 +368,7 @@ fs_cbcsr_t fs_cbcsr_create(int nrow, int ncol, int nblocks, int colblocksize, co
       (void)hipGetLastError();
     }
   }
+  fs::pool_trim();
   if (rc) { fs_cbcsr_destroy(M); return nullptr; }
   return M;
 }

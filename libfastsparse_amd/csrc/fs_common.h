@@ -219,6 +219,7 @@ int cbcsr_rows_device(DeviceCsr &out, int nrow, int ncol, int nblocks, int64_t n
                       const int *cols_dev, hipStream_t s);
 int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, const int *rows_dev, const int *cols_dev,
                      hipStream_t s);   // FS_ERR_ARG (with a message) when an index is out of range
+void pool_trim(bool everything = false);   // frees the format builders' idle scratch beyond FS_SCRATCH_POOL_MB (or all of it)
 void free_csr(DeviceCsr &A);
 
 }  // namespace fs

@@ -388,8 +388,11 @@ void fs_invalidate(const void *host_struct)
 
 void fs_release_all(void)
 {
-  std::lock_guard<std::mutex> g(g_table_lock);
-  g_table.clear();
+  {
+    std::lock_guard<std::mutex> g(g_table_lock);
+    g_table.clear();
+  }
+  fs::pool_trim(true);   // and the format builders' idle scratch
 }
 
 // number of device copies in the side table (tests, diagnostics)

@@ -21,15 +21,100 @@
 namespace fs {
 
 // ---- small helpers -------------------------------------------------------------------------
-// device scratch that is released on every exit path
+// hipMalloc / hipFree with a stopwatch: with FS_TRACE_BUILD set, any single call that takes longer than 50 ms is reported
+static bool trace_build() { static const bool v = getenv("FS_TRACE_BUILD") != nullptr; return v; }
+
+template <typename T>
+static hipError_t traced_malloc(T **p, size_t bytes)
+{
+  if (!trace_build()) return hipMalloc(p, bytes);
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipMalloc(p, bytes);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ms > 50.0) fprintf(stderr, "[fastsparse] hipMalloc of %.1f MB took %.0f ms\n", bytes / 1048576.0, ms);
+  return e;
+}
+
+static hipError_t traced_free(void *p)
+{
+  if (!trace_build()) return hipFree(p);
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipFree(p);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ms > 50.0) fprintf(stderr, "[fastsparse] hipFree took %.0f ms\n", ms);
+  return e;
+}
+
+// Device scratch of the format builders goes through a small pool: building one matrix takes three candidate copies,
+// each with half a dozen temporaries of nnz elements, and hipMalloc of a multi-GB block now and then stalls for SECONDS on
+// this platform (FS_TRACE_BUILD: "hipMalloc of 4921.0 MB took 4160 ms"; a copy that usually builds in 71 ms then takes
+// 3.4 s).  Blocks freed by one builder are reused by the next, and up to FS_SCRATCH_POOL_MB of idle blocks stay for the
+// next creation (pool_trim).
+struct PoolBlock { void *p; size_t bytes; bool used; };
+static std::mutex g_pool_lock;
+static std::vector<PoolBlock> g_pool;
+
+static hipError_t pool_alloc(void **out, size_t bytes)
+{
+  if (bytes == 0) bytes = 1;
+  std::lock_guard<std::mutex> g(g_pool_lock);
+  int best = -1;
+  for (int i = 0; i < (int)g_pool.size(); ++i)
+    if (!g_pool[i].used && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 4 * bytes + (1 << 20) &&
+        (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+  if (best >= 0) { g_pool[best].used = true; *out = g_pool[best].p; return hipSuccess; }
+  void *p = nullptr;
+  hipError_t e = traced_malloc(&p, bytes);
+  if (e != hipSuccess) {                      // out of memory: give back what the pool holds idle and try once more
+    (void)hipGetLastError();
+    for (size_t i = 0; i < g_pool.size();) {
+      if (!g_pool[i].used) { (void)traced_free(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else ++i;
+    }
+    e = traced_malloc(&p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  g_pool.push_back(PoolBlock{p, bytes, true});
+  *out = p;
+  return hipSuccess;
+}
+
+static void pool_free(void *p)
+{
+  std::lock_guard<std::mutex> g(g_pool_lock);
+  for (PoolBlock &b : g_pool)
+    if (b.p == p) { b.used = false; return; }
+  (void)traced_free(p);
+}
+
+// End of a top-level creation: idle blocks are kept for the next one up to FS_SCRATCH_POOL_MB (default 8192; 0 keeps
+// nothing), the rest is freed, smallest first -- the big blocks are the ones hipMalloc stalls on.  fs_release_all() empties it.
+void pool_trim(bool everything)
+{
+  static const size_t cap = [] { const char *v = getenv("FS_SCRATCH_POOL_MB"); return (size_t)(v && *v ? atoll(v) : 8192) << 20; }();
+  std::lock_guard<std::mutex> g(g_pool_lock);
+  for (;;) {
+    size_t idle = 0;
+    int smallest = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+      if (!g_pool[i].used) {
+        idle += g_pool[i].bytes;
+        if (smallest < 0 || g_pool[i].bytes < g_pool[smallest].bytes) smallest = i;
+      }
+    if (smallest < 0 || (!everything && idle <= cap)) return;
+    (void)traced_free(g_pool[smallest].p);
+    g_pool.erase(g_pool.begin() + smallest);
+  }
+}
+
+// device scratch that is released (to the pool) on every exit path
 template <typename T>
 struct Scratch {
   T *p = nullptr;
   Scratch() = default;
   Scratch(const Scratch &) = delete;
   Scratch &operator=(const Scratch &) = delete;
-  ~Scratch() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * (n ? n : 1)); }
+  ~Scratch() { if (p) pool_free(p); }
+  hipError_t alloc(size_t n) { return pool_alloc(reinterpret_cast<void **>(&p), sizeof(T) * (n ? n : 1)); }
   operator T *() const { return p; }
 };
 
@@ -38,7 +123,7 @@ static void free_tiled_slot(TiledCsr *&T)
   if (!T) return;
   void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item};
   for (void *q : owned)
-    if (q) (void)hipFree(q);
+    if (q) (void)traced_free(q);
   delete T;
   T = nullptr;
 }
@@ -51,7 +136,7 @@ static void free_binned_slot(BinnedCsr *&N)
   if (!N) return;
   void *owned[] = {N->lcol, N->vals, N->gdst, N->lrow, N->prod, N->band_ptr, N->bin_ptr, N->panel_row, N->vfirst, N->yv};
   for (void *q : owned)
-    if (q) (void)hipFree(q);
+    if (q) (void)traced_free(q);
   delete N;
   N = nullptr;
 }
@@ -61,13 +146,13 @@ static void free_binned(DeviceCsr &A) { free_binned_slot(A.binned); }
 void free_csr(DeviceCsr &A)
 {
   if (A.owns) {
-    if (A.row_ptr) (void)hipFree(A.row_ptr);
-    if (A.cols) (void)hipFree(A.cols);
-    if (A.vals) (void)hipFree(A.vals);
+    if (A.row_ptr) (void)traced_free(A.row_ptr);
+    if (A.cols) (void)traced_free(A.cols);
+    if (A.vals) (void)traced_free(A.vals);
   }
-  if (A.first_row) (void)hipFree(A.first_row);
-  if (A.head) (void)hipFree(A.head);
-  if (A.tail) (void)hipFree(A.tail);
+  if (A.first_row) (void)traced_free(A.first_row);
+  if (A.head) (void)traced_free(A.head);
+  if (A.tail) (void)traced_free(A.tail);
   free_tiled(A);
   free_tiledx(A);
   free_binned(A);
@@ -111,9 +196,9 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
 {
   A.nchunks = (int)((A.nnz + kChunk - 1) / kChunk);
   if (A.nchunks < 1) A.nchunks = 1;
-  FS_HIP(hipMalloc(&A.first_row, sizeof(int) * ((size_t)A.nchunks + 1)));
-  FS_HIP(hipMalloc(&A.head, sizeof(double) * (size_t)A.nchunks));
-  FS_HIP(hipMalloc(&A.tail, sizeof(double) * (size_t)A.nchunks));
+  FS_HIP(traced_malloc(&A.first_row, sizeof(int) * ((size_t)A.nchunks + 1)));
+  FS_HIP(traced_malloc(&A.head, sizeof(double) * (size_t)A.nchunks));
+  FS_HIP(traced_malloc(&A.tail, sizeof(double) * (size_t)A.nchunks));
   FS_HIP(hipMemsetAsync(A.head, 0, sizeof(double) * (size_t)A.nchunks, s));
   FS_HIP(hipMemsetAsync(A.tail, 0, sizeof(double) * (size_t)A.nchunks, s));
   const int n = A.nchunks + 1;
@@ -143,6 +228,7 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
   if (int rc = build_tiledx(A, s)) return rc;
   const auto t3 = trace ? now() : t0;
   const int rc = choose_copy(A, s);
+  pool_trim();
   if (trace) {
     const auto t4 = now();
     fprintf(stderr, "[fastsparse] %d x %d, %lld nnz: two-pass copy %.1f ms, tiled copy %.1f ms, LDS-staged copy %.1f ms, "
@@ -232,9 +318,9 @@ int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int
   out = DeviceCsr();
   out.nrow = nrow; out.ncol = ncol; out.nnz = nnz; out.owns = true;
   const size_t n = (size_t)(nnz > 0 ? nnz : 1);
-  FS_HIP(hipMalloc(&out.row_ptr, sizeof(int) * ((size_t)nrow + 1)));
-  FS_HIP(hipMalloc(&out.cols, sizeof(int) * n));
-  if (vals_dev) FS_HIP(hipMalloc(&out.vals, sizeof(double) * n));
+  FS_HIP(traced_malloc(&out.row_ptr, sizeof(int) * ((size_t)nrow + 1)));
+  FS_HIP(traced_malloc(&out.cols, sizeof(int) * n));
+  if (vals_dev) FS_HIP(traced_malloc(&out.vals, sizeof(double) * n));
   Scratch<int> keys_out;
   Scratch<unsigned> idx_in, idx_out;
   Scratch<char> tmp;
@@ -258,7 +344,8 @@ int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int
                      out.row_ptr);
   FS_HIP(hipGetLastError());
   FS_HIP(hipStreamSynchronize(s));
-  return build_schedule(out, s);
+  return build_schedule(out, s);   // the temporaries above go back to the pool when this function returns; the next
+                                   // creation's pool_trim (or fs_release_all) frees them
 }
 
 // ---- the reference's format constructors on the device ----------------------------------------------------
@@ -496,7 +583,7 @@ static int make_virtual_rows(const DeviceCsr &A, int split, hipStream_t s, Scrat
   size_t tmp_bytes = 0;
   int nvrow = 0;
   FS_HIP(cnt.alloc((size_t)A.nrow + 1));
-  FS_HIP(hipMalloc(vfirst_out, sizeof(int) * ((size_t)A.nrow + 1)));
+  FS_HIP(traced_malloc(vfirst_out, sizeof(int) * ((size_t)A.nrow + 1)));
   int *vfirst = *vfirst_out;
   hipLaunchKernelGGL(piece_count_kernel, dim3(grid_for((int64_t)A.nrow + 1)), dim3(256), 0, s, A.nrow, split, A.row_ptr,
                      cnt.p);
@@ -510,7 +597,7 @@ static int make_virtual_rows(const DeviceCsr &A, int split, hipStream_t s, Scrat
   hipLaunchKernelGGL(vrow_fill_kernel, dim3(grid_for((int64_t)A.nrow + 1)), dim3(256), 0, s, A.nrow, split, A.row_ptr,
                      vfirst, vrow_ptr.p);
   FS_HIP(hipGetLastError());
-  FS_HIP(hipMalloc(yv_out, sizeof(double) * (size_t)nvrow * (size_t)kw));
+  FS_HIP(traced_malloc(yv_out, sizeof(double) * (size_t)nvrow * (size_t)kw));
   *nvrow_out = nvrow;
   return FS_OK;
 }
@@ -702,7 +789,7 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   }
   if (ntiles >= (1ll << 31)) return FS_OK;
   T->R = R; T->W = W; T->P = P; T->J = J;
-  FS_HIP(hipMalloc(&T->panel_row, sizeof(int) * panel_row.size()));
+  FS_HIP(traced_malloc(&T->panel_row, sizeof(int) * panel_row.size()));
   FS_HIP(hipMemcpyAsync(T->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
 
   // ---- sort the entries by (panel, band), pack them, cut the work items -----------------------------------
@@ -717,20 +804,24 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   FS_HIP(idx_in.alloc(n));
   FS_HIP(idx_out.alloc(n));
   FS_HIP(tile_ptr.alloc((size_t)ntiles + 1));
-  FS_HIP(hipMalloc(&T->pk, sizeof(unsigned) * (n + 8)));          // + slack: the LDS-staged kernel loads entries in pairs
-  if (A.vals) FS_HIP(hipMalloc(&T->vals, sizeof(double) * (n + 8)));
+  FS_HIP(traced_malloc(&T->pk, sizeof(unsigned) * (n + 8)));          // + slack: the LDS-staged kernel loads entries in pairs
+  if (A.vals) FS_HIP(traced_malloc(&T->vals, sizeof(double) * (n + 8)));
   hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, nvrow, A.nnz, P, W, J, vrow_ptr, T->panel_row,
                      A.cols, vrows.p, keys.p);
   hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
   FS_HIP(hipGetLastError());
   int bits = 1;
   while (bits < 32 && (1ll << bits) < ntiles) ++bits;
-  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
+  // ping-pong sort between the two key / index buffers we already hold (rocprim's plain form would allocate a third
+  // pair as temporary storage: 4.9 GB at config 3's size, and hipMalloc of such a block was caught taking 4 s)
+  rocprim::double_buffer<unsigned> dk(keys.p, skeys.p), dv(idx_in.p, idx_out.p);
+  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, 0, bits, s));
   FS_HIP(tmp.alloc(tmp_bytes));
-  FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, W, J, T->lcol_bits, skeys.p, idx_out.p,
+  FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, dk, dv, n, 0, bits, s));
+  const unsigned *sorted_keys = dk.current(), *perm = dv.current();
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, W, J, T->lcol_bits, sorted_keys, perm,
                      vrows.p, T->panel_row, A.cols, A.vals, T->pk, T->vals);
-  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, s, ntiles, A.nnz, skeys.p, tile_ptr.p);
+  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, s, ntiles, A.nnz, sorted_keys, tile_ptr.p);
   FS_HIP(hipGetLastError());
   // work items are cut on the host from the tile pointers (P*J ints)
   std::vector<int> tp((size_t)ntiles + 1);
@@ -752,8 +843,8 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   }
   item_ptr[P] = (int)items.size();
   T->nitems = (int)items.size();
-  FS_HIP(hipMalloc(&T->items, sizeof(int4) * (items.size() ? items.size() : 1)));
-  FS_HIP(hipMalloc(&T->item_ptr, sizeof(int) * item_ptr.size()));
+  FS_HIP(traced_malloc(&T->items, sizeof(int4) * (items.size() ? items.size() : 1)));
+  FS_HIP(traced_malloc(&T->item_ptr, sizeof(int) * item_ptr.size()));
   if (!items.empty()) FS_HIP(hipMemcpy(T->items, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
   if (ldsx && T->nitems > 0) {
@@ -817,13 +908,13 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
       chunk_item.push_back(c.last);
     }
     T->nchunks = (int)chunk_panel.size();
-    FS_HIP(hipMalloc(&T->chunk_panel, sizeof(int) * (chunk_panel.size() ? chunk_panel.size() : 1)));
-    FS_HIP(hipMalloc(&T->chunk_item, sizeof(int) * (chunk_item.size() ? chunk_item.size() : 2)));
+    FS_HIP(traced_malloc(&T->chunk_panel, sizeof(int) * (chunk_panel.size() ? chunk_panel.size() : 1)));
+    FS_HIP(traced_malloc(&T->chunk_item, sizeof(int) * (chunk_item.size() ? chunk_item.size() : 2)));
     if (!chunk_panel.empty()) {
       FS_HIP(hipMemcpy(T->chunk_panel, chunk_panel.data(), sizeof(int) * chunk_panel.size(), hipMemcpyHostToDevice));
       FS_HIP(hipMemcpy(T->chunk_item, chunk_item.data(), sizeof(int) * chunk_item.size(), hipMemcpyHostToDevice));
     }
-    if (T->shared && !T->yv) FS_HIP(hipMalloc(&T->yv, sizeof(double) * (size_t)A.nrow));
+    if (T->shared && !T->yv) FS_HIP(traced_malloc(&T->yv, sizeof(double) * (size_t)A.nrow));
   }
   T->built = true;
   return FS_OK;
@@ -992,7 +1083,7 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   // padding would dominate (a run is padded to whole groups: (ge - 1) / 2 entries on average)
   if (o.binning == 1 && (double)A.nnz / (double)nruns < 1.5 * ge) return FS_OK;
   N->P = P; N->B = B;
-  FS_HIP(hipMalloc(&N->panel_row, sizeof(int) * panel_row.size()));
+  FS_HIP(traced_malloc(&N->panel_row, sizeof(int) * panel_row.size()));
   FS_HIP(hipMemcpyAsync(N->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
 
   // ---- sort the entries by (band, panel) and size the padded runs ------------------------------------------
@@ -1011,18 +1102,20 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   FS_HIP(g2.alloc((size_t)nruns + 1));
   FS_HIP(start1.alloc((size_t)nruns + 1));
   FS_HIP(start2.alloc((size_t)nruns + 1));
-  FS_HIP(hipMalloc(&N->band_ptr, sizeof(unsigned) * ((size_t)B + 1)));
-  FS_HIP(hipMalloc(&N->bin_ptr, sizeof(unsigned) * ((size_t)P + 1)));
+  FS_HIP(traced_malloc(&N->band_ptr, sizeof(unsigned) * ((size_t)B + 1)));
+  FS_HIP(traced_malloc(&N->bin_ptr, sizeof(unsigned) * ((size_t)P + 1)));
   hipLaunchKernelGGL(bin_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, nvrow, A.nnz, P, bcols, vrow_ptr, N->panel_row,
                      A.cols, vrows.p, keys.p);
   hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
   FS_HIP(hipGetLastError());
   int bits = 1;
   while (bits < 32 && (1ll << bits) < nruns) ++bits;
-  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
+  rocprim::double_buffer<unsigned> dk(keys.p, skeys.p), dv(idx_in.p, idx_out.p);   // ping-pong: see build_tiled_impl
+  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, 0, bits, s));
   FS_HIP(tmp.alloc(tmp_bytes));
-  FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, keys.p, skeys.p, idx_in.p, idx_out.p, n, 0, bits, s));
-  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, nruns, A.nnz, skeys.p, run_ptr.p);
+  FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, dk, dv, n, 0, bits, s));
+  const unsigned *sorted_keys = dk.current(), *perm = dv.current();
+  hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, nruns, A.nnz, sorted_keys, run_ptr.p);
   hipLaunchKernelGGL(bin_groups_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, B, P, ge, run_ptr.p, g1.p, g2.p);
   FS_HIP(hipGetLastError());
   tmp_bytes = 0;
@@ -1051,17 +1144,17 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
 
   // ---- lay out both orders ------------------------------------------------------------------------------------
   const size_t np = (size_t)N->n;
-  FS_HIP(hipMalloc(&N->lcol, sizeof(uint16_t) * np));
-  FS_HIP(hipMalloc(&N->lrow, sizeof(uint16_t) * np));
-  FS_HIP(hipMalloc(&N->gdst, sizeof(unsigned) * (size_t)groups));
-  FS_HIP(hipMalloc(&N->prod, sizeof(double) * np * (size_t)kw));
+  FS_HIP(traced_malloc(&N->lcol, sizeof(uint16_t) * np));
+  FS_HIP(traced_malloc(&N->lrow, sizeof(uint16_t) * np));
+  FS_HIP(traced_malloc(&N->gdst, sizeof(unsigned) * (size_t)groups));
+  FS_HIP(traced_malloc(&N->prod, sizeof(double) * np * (size_t)kw));
   if (A.vals) {
-    FS_HIP(hipMalloc(&N->vals, sizeof(double) * np));
+    FS_HIP(traced_malloc(&N->vals, sizeof(double) * np));
     FS_HIP(hipMemsetAsync(N->vals, 0, sizeof(double) * np, s));
   }
   FS_HIP(hipMemsetD16Async((hipDeviceptr_t)N->lcol, (unsigned short)bcols, np, s));   // padding: the zero row behind the band
   FS_HIP(hipMemsetAsync(N->lrow, 0, sizeof(uint16_t) * np, s));
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, bcols, ge, skeys.p, idx_out.p, vrows.p,
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, bcols, ge, sorted_keys, perm, vrows.p,
                      N->panel_row, A.cols, A.vals, run_ptr.p, start1.p, start2.p, N->lcol, N->vals, N->lrow);
   hipLaunchKernelGGL(bin_gdst_kernel, dim3(grid_for(nruns)), dim3(256), 0, s, B, P, start1.p, start2.p, N->gdst);
   FS_HIP(hipGetLastError());
@@ -1219,7 +1312,9 @@ int fs_bucket_coo(int kind, int param, int nrow, int ncol, int64_t nbuckets, int
     fs::set_error("fs_bucket_coo: bad argument");
     return FS_ERR_ARG;
   }
-  return fs::bucket_coo_impl(kind, param, nrow, ncol, nbuckets, nnz, rows, cols, vals, offsets, rows_out, cols_out, vals_out);
+  const int rc = fs::bucket_coo_impl(kind, param, nrow, ncol, nbuckets, nnz, rows, cols, vals, offsets, rows_out, cols_out, vals_out);
+  fs::pool_trim();
+  return rc;
 }
 
 /* should a constructor given nnz entries build on the device?  option device_build: 0 never, 1 when a device is
