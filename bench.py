@@ -333,6 +333,23 @@ def cpu_baseline_c3(nrow, ncol, per_row, sample_rows=2_500_000, reps=3):
     return rec
 
 
+def cpu_baseline_c5(lo, ncol, sample_rows=1_000_000, reps=3):
+    """csr_A_mul_B restated (OpenMP as csr.h:429) on the first `sample_rows` rows of the shard (power-law lengths, x over all
+    100 M columns), generated by the CPU twin of the device generator"""
+    import numpy as np
+    from oracle import pysynth
+    fast, ncpu = _fast_oracle()
+    rp, cc, vv = pysynth.powerlaw(sample_rows, ncol, C5_SCALE, C5_MAXLEN, SEED_C5, row_offset=lo)
+    x = np.sin(7.0 * np.arange(ncol, dtype=np.float64) + 0.3)
+    y = np.empty(sample_rows)
+    dt = _time_calls(lambda: fast.fso_csr_mul(y, sample_rows, rp, cc, vv.ctypes.data, x), reps)
+    nbytes = csr_bytes(len(cc), sample_rows, ncol)
+    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": ncpu, "kind": "port", "ms_per_product": dt * 1e3,
+            "sample": "csr_A_mul_B restated (OpenMP schedule(dynamic,256)) on rows %d..%d of the config-5 matrix (%d non-zeros, x over "
+                      "all %d columns: the 8 bytes per column are part of the byte count), 1 warm-up + mean of %d, gcc -O3 "
+                      "-march=native -ffast-math" % (lo, lo + sample_rows, len(cc), ncol, reps)}
+
+
 def cpu_baseline_c4(n, per_row, k, sample_rows=400_000, reps=2):
     """csr_A_mul_Bn on the first `sample_rows` rows (X over all columns), both ways SURVEY note N4 asks for: with the
     reference's own nested `omp parallel` + `omp parallel for` (csr.h:445-448: every thread walks all rows) and with
@@ -394,10 +411,16 @@ def run_c2(args, prov, world, rank, nccl):
     from libfastsparse_amd import capi
     from libfastsparse_amd import dist as fsd
     dev = prov.dev
-    n_local, per = args.rows, args.per_row
-    ncol = n_local                      # column space stays config 2's: every rank's shard is a config-2 matrix
-    n_global = n_local * world          # global rows
-    lo = rank * n_local
+    per = args.per_row
+    ncol = args.rows                    # column space stays config 2's at every N
+    if args.strong and world > 1:       # strong scaling: the one 10 M-row matrix cut into equal row shards
+        n_global = args.rows
+        sb = fsd.even_row_partition(n_global, world)
+        lo, n_local = sb[rank], sb[rank + 1] - sb[rank]
+    else:                               # weak scaling: every rank's shard is a config-2 matrix
+        n_local = args.rows
+        n_global = n_local * world
+        lo = rank * n_local
     st = capi.current_stream()
 
     # ---- this rank's shard: rows lo .. lo+n_local of the (N*10M) x 10M matrix ------------------------
@@ -406,7 +429,7 @@ def run_c2(args, prov, world, rank, nccl):
     A.build_transpose(st)
     bounds = fsd.even_row_partition(n_global, world)
     bytes_a = A.algorithmic_bytes()
-    bytes_t = bytes_a                   # same entries, nrow and ncol swap roles (both 10M here)
+    bytes_t = csr_bytes(n_local * per, ncol, n_local)   # same entries, nrow and ncol swap roles
     op_a = fsd.ShardedOperator(fsd.hip_local_spmv(A), bounds)
     op_t = fsd.TransposedShardedOperator(
         lambda z, u_local: A.spmv(z, u_local, capi.current_stream(), transposed=True), bounds)
@@ -469,7 +492,10 @@ def run_c2(args, prov, world, rank, nccl):
     avg_ms = (sum(ka) + sum(kt)) / launches
     bytes_per_launch = (bytes_a + bytes_t) / 2.0
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    total_bytes = float(world) * (bytes_a + bytes_t) * args.steps
+    tb = torch.tensor([float(bytes_a + bytes_t)], dtype=torch.float64, device=dev if (nccl and world > 1) else "cpu")
+    if world > 1:
+        dist.all_reduce(tb)             # shards may differ by a row under --strong
+    total_bytes = float(tb.item()) * args.steps
     value = total_bytes / elapsed / 1e9
 
     # self-check outside the timed region (no oracle here: that is the tests' job): the products the timed loop left in
@@ -512,11 +538,14 @@ def run_c2(args, prov, world, rank, nccl):
     rec = {
         "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B"
                                % (n_global, ncol, per) if world == 1 else
-                               "config-2 shards, weak scaling by rows: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
-                               "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (n_global, ncol, n_local, per),
+                               ("BASELINE config 2 cut over %d GPUs (strong scaling): CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
+                                "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (world, n_global, ncol, n_local, per)
+                                if args.strong else
+                                "config-2 shards, weak scaling by rows: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
+                                "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (n_global, ncol, n_local, per)),
                    "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
                    "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
                    "stream_read_GBs_measured": stream_gbs,
@@ -913,6 +942,11 @@ def run_c5(args, prov, world, rank, nccl, out=None):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic((kname,), "c5", n_local, 0) if world == 1 else None,
                      "algorithmic_bytes_per_launch": bytes_local, "avg_launch_ms": local_ms, "launches_timed": args.steps},
     }
+    if world == 1 and not args.no_cpu_baseline and hasattr(prov, "capi"):
+        try:
+            rec["cpu_baseline"] = cpu_baseline_c5(lo, ncol)
+        except Exception as ex:
+            rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     return rec
 
 
@@ -926,6 +960,9 @@ def main():
     ap.add_argument("--per-row", type=int, default=16)
     ap.add_argument("--c5-rows", type=int, default=100_000_000, help="rows = columns of the config-5 matrix")
     ap.add_argument("--transpose", action="store_true", help="c5, N > 1: also time z = A' u")
+    ap.add_argument("--strong", action="store_true",
+                    help="c2, N > 1: strong scaling -- the ONE config-2 matrix (--rows rows in all) cut over the ranks (default: weak "
+                         "scaling, --rows rows per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spmm-kernel", type=int, default=0,
                     help="c4: 0 the product's choice, 1 row kernel, 4 the matrix-core experiment (profiling runs)")

@@ -27,6 +27,8 @@
 //   spmv_vector_kernel   classic G-lanes-per-row CSR kernel (A/B alternative, option spmv_kernel=2)
 //   spmm_kernel          Y = A X, k row-major right-hand sides, one lane per output column
 //   cbcsr_kernel         column-blocked binary CSR, x tile staged in LDS per column block
+#include <stdlib.h>
+
 #include "fs_common.h"
 
 namespace fs {
@@ -1461,6 +1463,18 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
     return launch_spmv_tiled(A, *A.tiledx, y, x, s);
   if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6))
     return launch_spmv_tiled(A, *A.tiled, y, x, s);
+  // "reproducible" / "strict_order" set AFTER the matrix was created leave its kept copy unusable: the product then runs on
+  // the chunk-streaming kernel (correct, but slow on large matrices).  Said once under FS_TRACE_BUILD.
+  if ((o.reproducible || o.strict_order) && o.spmv_kernel == 0 && ((A.binned && A.binned->built) || (A.tiledx && A.tiledx->built))) {
+    static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
+    static bool said = false;
+    if (trace && !said) {
+      said = true;
+      fprintf(stderr, "[fastsparse] %d x %d: option %s was set after this matrix was created with a %s copy; its products run on "
+              "the chunk-streaming kernel (set the option before creating the matrix to get a fixed-order copy)\n", A.nrow, A.ncol,
+              o.strict_order ? "strict_order" : "reproducible", A.binned && A.binned->built ? "two-pass" : "LDS-staged");
+    }
+  }
   if (o.spmv_kernel == 2) {
     const double avg = A.nrow ? (double)A.nnz / A.nrow : 0.0;
     int lg = o.strict_order ? 0 : ceil_log2((int)(avg < 1 ? 1 : (avg > 64 ? 64 : avg)));
