@@ -899,8 +899,22 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     // next to each other instead of panel by panel.  Blocks b and b + 8 share an XCD, so every XCD gets a share of
     // each stretch.  (Panel-major order read every slice from the Infinity Cache 66 times: 5.3 GB of slices against
     // 2.6 GB of entries, 1.84 ms; this order 1.06 ms.)
-    if (T->shared)
-      std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.ordinal < b.ordinal; });
+    // (second refinement: blocks b, b + 8, b + 16, ... land on the same XCD, so within a group of eight stretches the
+    // order is panel-major with the stretch as the fastest index: an XCD then sees ONE stretch of bands for all panels
+    // and is the only XCD that fetches its slices.  FS_LDSX_ORDER=1 keeps the plain stretch-major order.)
+    if (T->shared) {
+      static const bool plain = [] { const char *v = getenv("FS_LDSX_ORDER"); return v && *v == '1'; }();
+      if (plain)
+        std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.ordinal < b.ordinal; });
+      else
+        std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) {
+          const int ga = a.ordinal >> 3, gb = b.ordinal >> 3;
+          if (ga != gb) return ga < gb;
+          const int pa = a.panel & 0x7fffffff, pb = b.panel & 0x7fffffff;
+          if (pa != pb) return pa < pb;
+          return (a.ordinal & 7) < (b.ordinal & 7);
+        });
+    }
     std::vector<int> chunk_panel, chunk_item;
     for (const Chunk &c : chunks) {
       chunk_panel.push_back(c.panel);
