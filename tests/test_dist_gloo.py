@@ -237,3 +237,15 @@ def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check: on a GPU box the ranks would really run")
+def test_bench_starts_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 3` without a launcher: the parent starts 3 rank processes itself (each with RANK /
+    WORLD_SIZE / MASTER_* set) and returns their failure; here, without a GPU, every rank stops at the "needs a GPU" check"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert (p.stderr + p.stdout).count("bench.py needs a GPU") == 3
