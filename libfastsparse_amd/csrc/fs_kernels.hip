@@ -379,17 +379,20 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
   __syncthreads();  // ytile zeroed
   // phase IT: producers stage item IT (register set 0) into buffer IT&1, then issue the loads of IT+3
   // (set 3) and the gathers of IT+2 (set 2); consumers reduce item IT-1 from the other buffer.
+#ifndef FS_TABL
+#define FS_TABL 0
+#endif
 #define FS_PHASE(IT, D0, W0, V0, X0, D2, W2, X2, D3, W3, V3)                                   \
   if (producer) {                                                                              \
     if (DEBUG && t == 0 && (IT) >= it0 && (IT) < it1) dbg_time[(IT)] = (long long)wall_clock64(); \
-    if ((IT) >= it0 && (IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
+    if (FS_TABL != 4 && (IT) >= it0 && (IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
     D3 = FS_ITEM((IT) + 3);                                                                    \
-    tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                                          \
-    tiled_gather<VALUED>(D2, W, cmask, x, xs, W2, X2);                                                 \
-  } else if ((IT) > it0 && (IT) <= it1) {                                                      \
+    if (FS_TABL != 2) tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                        \
+    if (FS_TABL != 1) tiled_gather<VALUED>(D2, W, cmask, x, xs, W2, X2);                       \
+  } else if (FS_TABL != 3 && (IT) > it0 && (IT) <= it1) {                                      \
     tiled_reduce(ytile, sprod[((IT) - 1) & 1], spk[((IT) - 1) & 1], tr, items[(IT) - 1].y, lcol_bits); \
   }                                                                                            \
-  __syncthreads();
+  if (FS_TABL != 5) __syncthreads();
   // whole rounds of four phases (no early exit: a loop body with one way through is what lets the compiler count
   // the loads in flight); phases past the last item stage and reduce nothing
   for (int it = it0 - 3; it <= it1; it += 4) {
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(kBinBlock) void spmm_expand_kernel(
   constexpr int GE = kBinGroup / K;      // entries per group
   constexpr int LP = K / 2;              // lanes per entry: every lane owns two neighbouring products (one 16-byte store)
   constexpr int EPS = kBinBlock / LP;    // entries per step of the workgroup
-  __shared__ double xband[kBinCols + 8];  // [BC][K]; row BC is the zero row the padding entries point at
+  __shared__ __attribute__((aligned(16))) double xband[kBinCols + 8];  // [BC][K]; row BC is the zero row the padding entries point at
   const int t = threadIdx.x;
   const int le = t / LP, h = t % LP;
   const uint64_t groups = band_ptr[B];
