@@ -526,11 +526,6 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
         if (pos < dset[s0].y) {
           double pr = xsl[buf][w[s0][q] & cmask];
           if (VALUED) pr *= v[s0][q];
-#ifdef FS_EXP_VALU
-          { unsigned dummy = w[s0][q];
-#pragma unroll
-            for (int z = 0; z < FS_EXP_VALU; ++z) asm volatile("v_xor_b32 %0, %0, %0" : "+v"(dummy)); }
-#endif
           __hip_atomic_fetch_add(&ytile[w[s0][q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
