@@ -1070,7 +1070,8 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   std::vector<int> vp((size_t)nvrow + 1);
   FS_HIP(hipMemcpyAsync(vp.data(), vrow_ptr, sizeof(int) * vp.size(), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
-  int64_t want = (int64_t)((double)nvrow / (0.8 * R)) + 1;
+  static const double fill = [] { const char *v = getenv("FS_BIN_FILL"); return v && *v ? atof(v) / 100.0 : 0.8; }();
+  int64_t want = (int64_t)((double)nvrow / (fill * R)) + 1;
   if (want > slots) want = (want + slots - 1) / slots * slots;
   std::vector<int> panel_row;
   {
