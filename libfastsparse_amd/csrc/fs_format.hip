@@ -833,10 +833,12 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   for (int p = 0; p < P; ++p) {
     item_ptr[p] = (int)items.size();
     for (int j = 0; j < J; ++j) {
-      const int a = tp[(size_t)p * J + j], b = tp[(size_t)p * J + j + 1];
-      for (int off = a; off < b; off += kTiledItem) {
+      // 64-bit offsets: with nnz within 2 047 of INT_MAX `off += cap` wrapped around and this loop never ended
+      // (caught by test_pattern_matrix_at_the_int32_limit: 270 GB of work items on the host)
+      const int64_t a = tp[(size_t)p * J + j], b = tp[(size_t)p * J + j + 1];
+      for (int64_t off = a; off < b; off += kTiledItem) {
         int4 it;
-        it.x = off; it.y = (b - off < kTiledItem) ? b - off : kTiledItem; it.z = j; it.w = 0;
+        it.x = (int)off; it.y = (int)((b - off < kTiledItem) ? b - off : kTiledItem); it.z = j; it.w = 0;
         items.push_back(it);
       }
     }
@@ -1307,9 +1309,9 @@ __global__ void synth_fill_kernel(int nrow, int ncol, uint64_t seed, int64_t row
   const int lane = threadIdx.x & 63;
   if (w >= nrow) return;
   const int a = row_ptr[w], b = row_ptr[w + 1];
-  for (int i = a + lane; i < b; i += 64) {
+  for (int64_t i = (int64_t)a + lane; i < b; i += 64) {
     int c; double v;
-    synth_entry(seed, row_offset + w, i - a, ncol, &c, &v);
+    synth_entry(seed, row_offset + w, (int)(i - a), ncol, &c, &v);
     cols[i] = c;
     if (vals) vals[i] = v;
   }

@@ -596,12 +596,12 @@ __global__ __launch_bounds__(kBlock) void ata_csr_kernel(int nrow, const int *__
   if (row >= nrow) return;
   const int a = row_ptr[row], b = row_ptr[row + 1];
   double acc = 0.0;
-  for (int i = a + lane; i < b; i += 64) {
+  for (int64_t i = (int64_t)a + lane; i < b; i += 64) {
     const double xv = x[cols[i]];
     acc += VALUED ? xv * vals[i] : xv;
   }
   for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
-  for (int i = a + lane; i < b; i += 64) unsafeAtomicAdd(&y[cols[i]], VALUED ? acc * vals[i] : acc);
+  for (int64_t i = (int64_t)a + lane; i < b; i += 64) unsafeAtomicAdd(&y[cols[i]], VALUED ? acc * vals[i] : acc);
 }
 
 // The same sweep with (1) the LDS work of consecutive items overlapped and (2) half as many vector-memory instructions.
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(int nrow, int lg, c
   if (row >= nrow) return;
   const int a = row_ptr[row], b = row_ptr[row + 1];
   double acc = 0.0;
-  for (int i = a + gl; i < b; i += G) {
+  for (int64_t i = (int64_t)a + gl; i < b; i += G) {
     const double xv = x[cols[i]];
     acc += VALUED ? xv * vals[i] : xv;
   }
@@ -801,19 +801,19 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(int nrow, int k, const int
     const bool act = col < k;
     const int colc = act ? col : k - 1;          // lanes past the last column read a valid address and store nothing
     double acc = 0.0;
-    for (int base = a; base < b; base += EB) {
+    for (int64_t base = a; base < b; base += EB) {   // 64-bit: a row may end within EB of INT_MAX
       // the step's (column, value) pairs, spread over the row's lanes; positions past the row's end re-read its last
       // entry so that every load below is unconditional (no load sits behind a branch: see spmv_tiled_kernel)
       int myc[EPL];
       double myv[EPL];
 #pragma unroll
       for (int q = 0; q < EPL; ++q) {
-        const int e = base + q * KP + j;
-        const int ec = e < b ? e : b - 1;
+        const int64_t e = base + q * KP + j;
+        const int64_t ec = e < b ? e : b - 1;
         myc[q] = cols[ec];
         if (VALUED) myv[q] = vals[ec];
       }
-      const int n = (b - base < EB) ? b - base : EB;
+      const int n = (b - base < EB) ? (int)(b - base) : EB;
 #pragma unroll
       for (int i0 = 0; i0 < EB; i0 += 8) {
         if (i0 < n) {
@@ -862,13 +862,13 @@ __global__ __launch_bounds__(kBlock) void spmm_mfma_kernel(int nrow, int k, cons
     const int c0 = j0 + jj, c1 = j0 + 16 + jj;
     const int c0c = c0 < k ? c0 : k - 1, c1c = c1 < k ? c1 : k - 1;   // clamped: loads stay unconditional
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int base = a; base < b; base += 16) {
+    for (int64_t base = a; base < b; base += 16) {
       // 16 entries per round: four MFMA steps, eight X loads per lane in flight
       double av[4], b0[4], b1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = base + 4 * u + kk;
-        const int ec = e < b ? e : b - 1;
+        const int64_t e = base + 4 * u + kk;
+        const int64_t ec = e < b ? e : b - 1;
         const int c = cols[ec];
         const double v = VALUED ? vals[ec] : 1.0;
         av[u] = (jj == 0 && e < b) ? v : 0.0;     // row 0 of A; entries past the row's end contribute 0

@@ -272,3 +272,37 @@ def test_config3_through_its_own_entry_points_coo(hip_env):
           % (t_first, t_again))
     L.fs_invalidate(C.byref(S))
     assert np.array_equal(yh, y_dev) and np.array_equal(zh, z_dev)
+
+
+def test_pattern_matrix_at_the_int32_limit(hip_env):
+    """The largest matrix a struct BinaryCSR can describe: `int* row_ptr` (csr.h:19) caps nnz at 2^31 - 1.  134 217 720 rows
+    x 16 entries = 2 147 483 520 non-zeros (127 short of the cap), 50 M columns, pattern-only, integer-valued x: every offset
+    computed in the kernels and the format builders must survive the top of the 32-bit range.  Row windows against the
+    oracle (bit-exact), the builder's choice against the storage-order kernel on every row, the integer checksum of
+    checksums."""
+    torch, capi, O = hip_env
+    nrow, ncol, per = 134_217_720, 50_000_000, 16
+    nnz = nrow * per
+    assert 2**31 - 1 - nnz == 127
+    rp, cc, _ = capi.synth_uniform(nrow, ncol, per, 0x5EED00FF, valued=False)
+    assert int(rp[-1].item()) == nnz
+    A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+    st = capi.current_stream()
+    x = _int_x(ncol, "cuda", 11)
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    A.spmv(y, x, st)
+    for lo in (0, 77_777_777, nrow - 3000):
+        _window_check(capi, O, rp, cc, None, x, y, lo, lo + 3000, exact=True)
+    y2 = torch.empty_like(y)
+    capi.set_option("strict_order", 1)
+    try:
+        A.spmv(y2, x, st)
+    finally:
+        capi.set_option("strict_order", 0)
+    assert torch.equal(y, y2), A.kernel_name()
+    del y2
+    xl = x.to(torch.int64)
+    total = 0
+    for a in range(0, nnz, 100_000_000):
+        total += int(xl[cc[a:a + 100_000_000].long()].sum().item())
+    assert int(y.to(torch.int64).sum().item()) == total, A.kernel_name()
