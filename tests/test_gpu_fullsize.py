@@ -306,3 +306,32 @@ def test_pattern_matrix_at_the_int32_limit(hip_env):
     for a in range(0, nnz, 100_000_000):
         total += int(xl[cc[a:a + 100_000_000].long()].sum().item())
     assert int(y.to(torch.int64).sum().item()) == total, A.kernel_name()
+
+
+def test_spmm_where_the_reference_overflows_int(hip_env):
+    """csr_A_mul_Bn / bcsr_A_mul_Bn compute `int col = cols[i] * ncol` (csr.h:452, :268): with k = 32 that overflows for
+    column ids >= 67 108 864.  100 M columns x k = 32 (X of 25.6 GB): every column of Y against the
+    single-vector product of that column of X in storage order -- bit-identical -- and an oracle window of the latter."""
+    torch, capi, O = hip_env
+    nrow, ncol, per, k = 1_000_000, 100_000_000, 16, 32
+    rp, cc, vv = capi.synth_uniform(nrow, ncol, per, 0x5EED0032)
+    assert int(cc.max().item()) * k > 2**31
+    A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+    X = torch.empty(ncol, k, dtype=torch.float64, device="cuda")
+    i = torch.arange(ncol, device="cuda", dtype=torch.float64)
+    for j in range(k):
+        X[:, j] = torch.sin(7.0 * i + 17.0 * j + 0.3)
+    del i
+    Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+    st = capi.current_stream()
+    A.spmm(Y, X, k, st)
+    y = torch.empty(nrow, dtype=torch.float64, device="cuda")
+    capi.set_option("strict_order", 1)
+    try:
+        for j in (0, 9, 31):
+            xj = X[:, j].contiguous()
+            A.spmv(y, xj, st)
+            assert torch.equal(Y[:, j], y), j
+        _window_check(capi, O, rp, cc, vv, xj, y, 500_000, 502_000, exact=True)
+    finally:
+        capi.set_option("strict_order", 0)
