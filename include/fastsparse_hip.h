@@ -130,6 +130,13 @@ int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stre
 /* y[ncol] = A'A x[ncol]; tmp is caller scratch of nrow doubles in HBM   (bcsr_AA_mul_B, parallel_bcsr_AA_mul_B) */
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream);
 
+/* ---- products on HOST vectors (what a caller of the reference's csr_A_mul_B(y, A, x) holds: csr.h:149) -----
+ * Synchronous: y_host is complete on return.  The handle keeps its own staging vectors, stream and events.  With a
+ * two-pass copy (the default for large x) x goes up band range by band range and y comes down panel range by panel
+ * range while the kernels of the other ranges run (FS_HOST_CHUNKS ranges, default 8; 1 = copy, product, copy). */
+int fs_spmv_host(fs_matrix_t A, double *y_host, const double *x_host);
+int fs_spmv_t_host(fs_matrix_t A, double *y_host, const double *x_host);
+
 /* ---- consumers of the path, device resident (cg.h of the reference) -------------------- */
 /* (A'A + lambda I) x = b by conjugate gradients; A and the handle of its transpose as the reference passes
  * them (bsbm_cg cg.h:25); x, b: F = ncol(A) doubles in HBM; stops at ||r|| <= tol ||b|| or after F iterations */

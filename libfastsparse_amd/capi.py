@@ -20,7 +20,7 @@ DEVICE_API = [
     "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
     "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel", "fs_matrix_candidate_ms",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
-    "fs_spmv", "fs_spmv_t", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
+    "fs_spmv", "fs_spmv_t", "fs_spmv_host", "fs_spmv_t_host", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all", "fs_cache_entries",
     "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill", "fs_bucket_coo", "fs_device_build_wanted",
     "fs_dist_create", "fs_dist_destroy", "fs_dist_ndev", "fs_dist_uses_rccl", "fs_dist_csr_create", "fs_dist_matrix_destroy",
@@ -97,6 +97,8 @@ def lib():
     L.fs_matrix_download.argtypes = [vp, C.c_int, vp, vp, vp]
     for f in ("fs_spmv", "fs_spmv_t"):
         getattr(L, f).argtypes = [vp, vp, vp, vp]
+    for f in ("fs_spmv_host", "fs_spmv_t_host"):
+        getattr(L, f).argtypes = [vp, vp, vp]
     for f in ("fs_spmm", "fs_spmm_t"):
         getattr(L, f).argtypes = [vp, vp, vp, C.c_int, vp]
     L.fs_ata_mul.argtypes = [vp, vp, vp, vp, vp]
@@ -214,6 +216,11 @@ class Matrix:
     def spmv(self, y, x, stream=None, transposed=False):
         f = lib().fs_spmv_t if transposed else lib().fs_spmv
         check(f(self.h, _ptr(y), _ptr(x), stream), "fs_spmv")
+
+    def spmv_host(self, y, x, transposed=False):
+        """y, x: contiguous float64 numpy arrays in host memory (fs_spmv_host: copies overlapped with the kernels)"""
+        f = lib().fs_spmv_t_host if transposed else lib().fs_spmv_host
+        check(f(self.h, y.ctypes.data, x.ctypes.data), "fs_spmv_host")
 
     def spmm(self, Y, X, k, stream=None, transposed=False):
         f = lib().fs_spmm_t if transposed else lib().fs_spmm

@@ -188,6 +188,7 @@ void fs_matrix_destroy(fs_matrix_t A)
   if (!A) return;
   fs::free_csr(A->a);
   if (A->has_t) fs::free_csr(A->at);
+  fs::free_host_pipe(A->pipe);
   delete A;
 }
 
@@ -288,6 +289,22 @@ int fs_debug_tiled_trace(fs_matrix_t A, double *y, const double *x, long long *t
   FS_HIP(hipFree(td));
   FS_HIP(hipFree(xd));
   return FS_OK;
+}
+
+// products with HOST vectors: synchronous; the copies of x and y overlap the kernels where the kept copy allows it
+int fs_spmv_host(fs_matrix_t A, double *y_host, const double *x_host)
+{
+  if (int rc = check_mul(A, y_host, x_host, "fs_spmv_host")) return rc;
+  std::lock_guard<std::mutex> g(A->lock);
+  return fs::spmv_host_vectors(A->a, A->pipe, y_host, x_host);
+}
+
+int fs_spmv_t_host(fs_matrix_t A, double *y_host, const double *x_host)
+{
+  if (int rc = check_mul(A, y_host, x_host, "fs_spmv_t_host")) return rc;
+  if (!A->has_t) { set_error("fs_spmv_t_host: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  return fs::spmv_host_vectors(A->at, A->pipe, y_host, x_host);
 }
 
 int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)

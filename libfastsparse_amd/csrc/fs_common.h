@@ -126,7 +126,22 @@ struct BinnedCsr {
   int split = 0, nvrow = 0;    // virtual rows, as in TiledCsr
   int *vfirst = nullptr;
   double *yv = nullptr;
+  // host mirrors of band_ptr / panel_row / bin_ptr, fetched on the first product with host vectors (fs_spmv_host
+  // cuts both passes into ranges of bands / panels so that the PCIe copies of x and y overlap them)
+  unsigned *h_band_ptr = nullptr;
+  int *h_panel_row = nullptr;
 };
+
+// staging vectors, stream and events of products with HOST vectors (fs_spmv_host); one set per handle, made on first use
+struct HostPipe {
+  double *sx = nullptr, *sy = nullptr;
+  size_t cx = 0, cy = 0;
+  hipStream_t stream = nullptr;
+  static constexpr int kMaxChunks = 32;
+  hipEvent_t ev[kMaxChunks] = {};
+  int nev = 0;
+};
+void free_host_pipe(HostPipe &H);
 
 }  // namespace fs
 
@@ -136,6 +151,7 @@ struct fs_matrix_s {
   bool has_t = false;
   int device = 0;
   std::mutex lock;             // serialises products that share head/tail scratch
+  fs::HostPipe pipe;           // fs_spmv_host / fs_spmv_t_host
 };
 
 struct fs_cbcsr_s {
@@ -198,6 +214,8 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // may build a k-column copy
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
 int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
+// y_host = A x_host: copies and kernels overlapped where the kept copy allows it (two-pass copy without cut rows)
+int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const double *x_host);
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);

@@ -241,6 +241,17 @@ void with_vectors(double *y, size_t ny, const double *x, size_t nx, Mul mul, con
   }
 }
 
+// y = A x (or A' x) of one handle: vectors both in host memory take fs_spmv_host, whose copies overlap the kernels
+void product(fs_matrix_t m, bool transposed, double *y, size_t ny, const double *x, size_t nx, const char *who)
+{
+  if (ny && nx && !on_device(x) && !on_device(y)) {
+    FS_MUST(transposed ? fs_spmv_t_host(m, y, x) : fs_spmv_host(m, y, x), who);
+    return;
+  }
+  with_vectors(y, ny, x, nx, [&](double *yd, const double *xd) {
+    return transposed ? fs_spmv_t(m, yd, xd, nullptr) : fs_spmv(m, yd, xd, nullptr); }, who);
+}
+
 // ---- several GPUs (FASTSPARSE_NGPU) ---------------------------------------------------------------------
 // csr_A_mul_B / bcsr_A_mul_B of a plain C caller across the GPUs of the node: FASTSPARSE_NGPU=N in the environment
 // (and optionally FASTSPARSE_DEVICES=0,1,...: the device of every rank).  One context for the process.
@@ -365,6 +376,7 @@ EntryP blocked_entry(const void *host, int nrow, int ncol, int nblocks, const in
 void bcsr_mul_k(double *Y, struct BinaryCSR *A, double *X, int k, const char *who)
 {
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, false, who);
+  if (k == 1) { product(e->m, false, Y, A->nrow, X, A->ncol, who); return; }
   with_vectors(Y, (size_t)A->nrow * k, X, (size_t)A->ncol * k,
                [&](double *yd, const double *xd) { return fs_spmm(e->m, yd, xd, k, nullptr); }, who);
 }
@@ -372,6 +384,7 @@ void bcsr_mul_k(double *Y, struct BinaryCSR *A, double *X, int k, const char *wh
 void bsbm_mul_k(double *Y, struct BlockedSBM *B, double *X, int k, const char *who)
 {
   EntryP e = blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, nullptr, who);
+  if (k == 1) { product(e->m, false, Y, B->nrow, X, B->ncol, who); return; }
   with_vectors(Y, (size_t)B->nrow * k, X, (size_t)B->ncol * k,
                [&](double *yd, const double *xd) { return fs_spmm(e->m, yd, xd, k, nullptr); }, who);
 }
@@ -406,13 +419,13 @@ int fs_cache_entries(void)
 void A_mul_B(double *y, struct SparseBinaryMatrix *A, double *x)
 {
   EntryP e = coo_entry(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "A_mul_B");
-  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "A_mul_B");
+  product(e->m, false, y, A->nrow, x, A->ncol, "A_mul_B");
 }
 
 void At_mul_B(double *y, struct SparseBinaryMatrix *A, double *x)
 {
   EntryP e = coo_entry(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "At_mul_B");
-  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "At_mul_B");
+  product(e->m, false, y, A->ncol, x, A->nrow, "At_mul_B");
 }
 
 void bsbm_A_mul_B(double *y, struct BlockedSBM *B, double *x) { bsbm_mul_k(y, B, x, 1, "bsbm_A_mul_B"); }
@@ -472,19 +485,19 @@ void bsbm_cg2(double *X, struct BlockedSBM *A, struct BlockedSBM *At, double *B,
 void sdm_A_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)
 {
   EntryP e = coo_entry(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_A_mul_B");
-  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "sdm_A_mul_B");
+  product(e->m, false, y, A->nrow, x, A->ncol, "sdm_A_mul_B");
 }
 
 void sdm_At_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)
 {
   EntryP e = coo_entry(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_At_mul_B");
-  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "sdm_At_mul_B");
+  product(e->m, false, y, A->ncol, x, A->nrow, "sdm_At_mul_B");
 }
 
 void bsdm_A_mul_B(double *y, struct BlockedSDM *B, double *x)
 {
   EntryP e = blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, B->vals, "bsdm_A_mul_B");
-  with_vectors(y, B->nrow, x, B->ncol, [&](double *yd, const double *xd) { return fs_spmv(e->m, yd, xd, nullptr); }, "bsdm_A_mul_B");
+  product(e->m, false, y, B->nrow, x, B->ncol, "bsdm_A_mul_B");
 }
 
 // ---- csr.h ---------------------------------------------------------------------------------------------
@@ -546,7 +559,7 @@ void bcsr_At_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_At_mul_B");
   fs_matrix_t m = e->m;
-  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv_t(m, yd, xd, nullptr); }, "bcsr_At_mul_B");
+  product(m, true, y, A->ncol, x, A->nrow, "bcsr_At_mul_B");
 }
 
 void csr_A_mul_B(double *y, struct CSR *A, double *x)
@@ -554,14 +567,14 @@ void csr_A_mul_B(double *y, struct CSR *A, double *x)
   if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, x, "csr_A_mul_B"); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_B");
   fs_matrix_t m = e->m;
-  with_vectors(y, A->nrow, x, A->ncol, [&](double *yd, const double *xd) { return fs_spmv(m, yd, xd, nullptr); }, "csr_A_mul_B");
+  product(m, false, y, A->nrow, x, A->ncol, "csr_A_mul_B");
 }
 
 void csr_At_mul_B(double *y, struct CSR *A, double *x)
 {
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, true, "csr_At_mul_B");
   fs_matrix_t m = e->m;
-  with_vectors(y, A->ncol, x, A->nrow, [&](double *yd, const double *xd) { return fs_spmv_t(m, yd, xd, nullptr); }, "csr_At_mul_B");
+  product(m, true, y, A->ncol, x, A->nrow, "csr_At_mul_B");
 }
 
 void csr_A_mul_Bn(double *Y, struct CSR *A, double *X, const int ncol)

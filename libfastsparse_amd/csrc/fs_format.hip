@@ -137,6 +137,8 @@ static void free_binned_slot(BinnedCsr *&N)
   void *owned[] = {N->lcol, N->vals, N->gdst, N->lrow, N->prod, N->band_ptr, N->bin_ptr, N->panel_row, N->vfirst, N->yv};
   for (void *q : owned)
     if (q) (void)traced_free(q);
+  free(N->h_band_ptr);
+  free(N->h_panel_row);
   delete N;
   N = nullptr;
 }

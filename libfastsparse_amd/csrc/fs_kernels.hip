@@ -949,12 +949,13 @@ template <bool VALUED, int U, bool NTLD, bool NTST>
 __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
     int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
     const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
-    double *__restrict__ prod)
+    double *__restrict__ prod, unsigned gbeg, unsigned gend)
 {
   __shared__ double xband[kBinCols + 8];   // slot kBinCols is the zero the padding entries point at
   const int t = threadIdx.x;
-  const uint64_t groups = band_ptr[B];
-  const unsigned g0 = (unsigned)(groups * blockIdx.x / gridDim.x), g1 = (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
+  // this launch covers the groups gbeg .. gend (everything, or the bands whose part of x has arrived: fs_spmv_host)
+  const uint64_t groups = gend - gbeg;
+  const unsigned g0 = gbeg + (unsigned)(groups * blockIdx.x / gridDim.x), g1 = gbeg + (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
   if (g0 >= g1) return;
   // band of the first group: last b with band_ptr[b] <= g0
   int b;
@@ -1033,14 +1034,15 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
 template <bool NTLD>
 __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
     const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ y, int ys)
+    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
 {
   __shared__ double ytile[kBinRowsMax];
   const int t = threadIdx.x;
-  const int r0 = panel_row[blockIdx.x], nr = panel_row[blockIdx.x + 1] - r0;
+  const int panel = pbase + blockIdx.x;
+  const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
   for (int i = t; i < nr; i += kBinBlock) ytile[i] = 0.0;
   __syncthreads();
-  const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * kBinGroup, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * kBinGroup;
+  const int64_t e0 = (int64_t)bin_ptr[panel] * kBinGroup, e1 = (int64_t)bin_ptr[panel + 1] * kBinGroup;
   // 8 entries (64 bytes of products) per lane and step, two steps in flight in whole rounds (straight-line code:
   // see spmv_expand_kernel); the last, partial round is guarded
 #define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -1355,7 +1357,7 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   } while (0)
 #define FS_EXPAND(V, U, NL, NS)                                                                                    \
   hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
-                     N.lcol, N.vals, N.gdst, x, xs, N.prod)
+                     N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog))
     if (A.vals) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
     else        { if ((flags & 3) == 1) FS_EXPAND4(false, 8); else if ((flags & 3) == 2) FS_EXPAND4(false, 2); else FS_EXPAND4(false, 4); }
 #undef FS_EXPAND4
@@ -1363,9 +1365,9 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
     FS_HIP(hipGetLastError());
   }
   if (options().bin_flags & 4)
-    hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+    hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, 0);
   else
-    hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
+    hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, 0);
   FS_HIP(hipGetLastError());
   if (N.split) {
     hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
@@ -1510,6 +1512,115 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
     hipLaunchKernelGGL(spmv_fixup_kernel, dim3((A.nchunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, A.nchunks,
                        A.nnz, A.row_ptr, A.first_row, A.head, A.tail, y);
     FS_HIP(hipGetLastError());
+  }
+  return FS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// y_host = A x_host: what the reference's callers hand over (csr_A_mul_B(y, A, x) with malloc'ed vectors).  The two
+// 8-byte-per-element copies over PCIe cost more than the product (config 2: 1.43 ms each against 0.9 ms), and y needs
+// all of x -- but the two-pass kernels do not: pass 1 needs the band of x a group belongs to, pass 2 finishes y panel
+// by panel.  So x goes up in C ranges of bands and the pass-1 groups of a range are launched (on the handle's own
+// non-blocking stream) as soon as its part of x has landed; pass 2 is launched in C ranges of panels and every range
+// of y goes down as soon as its event fires, while the later ranges still run.  Only the last pass-1 range and the
+// first pass-2 range are left outside the copies.  Other kept copies (LDS-staged, tiled, stream), cut rows and
+// strict_order / reproducible: copy, product, copy.
+// ------------------------------------------------------------------------------------------
+void free_host_pipe(HostPipe &H)
+{
+  if (H.sx) (void)hipFree(H.sx);
+  if (H.sy) (void)hipFree(H.sy);
+  for (int i = 0; i < H.nev; ++i) (void)hipEventDestroy(H.ev[i]);
+  if (H.stream) (void)hipStreamDestroy(H.stream);
+  H = HostPipe();
+}
+
+static int host_pipe_ready(HostPipe &H, size_t nx, size_t ny, int nev)
+{
+  if (H.cx < nx) {
+    if (H.sx) (void)hipFree(H.sx);
+    H.sx = nullptr; H.cx = 0;
+    FS_HIP(hipMalloc(&H.sx, sizeof(double) * nx));
+    H.cx = nx;
+  }
+  if (H.cy < ny) {
+    if (H.sy) (void)hipFree(H.sy);
+    H.sy = nullptr; H.cy = 0;
+    FS_HIP(hipMalloc(&H.sy, sizeof(double) * ny));
+    H.cy = ny;
+  }
+  if (!H.stream) FS_HIP(hipStreamCreateWithFlags(&H.stream, hipStreamNonBlocking));
+  for (; H.nev < nev; ++H.nev) FS_HIP(hipEventCreateWithFlags(&H.ev[H.nev], hipEventDisableTiming));
+  return FS_OK;
+}
+
+int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const double *x_host)
+{
+  if (A.nrow == 0) return FS_OK;
+  static const int want_chunks = [] {
+    const char *e = getenv("FS_HOST_CHUNKS");
+    const int v = e ? atoi(e) : 8;
+    return v < 1 ? 1 : (v > HostPipe::kMaxChunks ? HostPipe::kMaxChunks : v);
+  }();
+  const Options &o = options();
+  const size_t nx = A.ncol > 0 ? (size_t)A.ncol : 1, ny = (size_t)A.nrow;
+  if (int rc = host_pipe_ready(H, nx, ny, want_chunks)) return rc;
+  const bool two_pass = A.binned && A.binned->built && !A.binned->split && A.binned->nwg1 > 0 && !o.strict_order &&
+                        !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7) && o.bin_flags == 0 && want_chunks > 1;
+  if (!two_pass) {
+    if (A.ncol > 0) FS_HIP(hipMemcpy(H.sx, x_host, sizeof(double) * (size_t)A.ncol, hipMemcpyHostToDevice));
+    if (int rc = launch_spmv(A, H.sy, H.sx, H.stream)) return rc;
+    FS_HIP(hipStreamSynchronize(H.stream));
+    FS_HIP(hipMemcpy(y_host, H.sy, sizeof(double) * ny, hipMemcpyDeviceToHost));
+    return FS_OK;
+  }
+  BinnedCsr &N = *A.binned;
+  if (!N.h_band_ptr) {
+    unsigned *hb = (unsigned *)malloc(sizeof(unsigned) * ((size_t)N.B + 1));
+    int *hp = (int *)malloc(sizeof(int) * ((size_t)N.P + 1));
+    if (!hb || !hp) { free(hb); free(hp); set_error("out of host memory"); return FS_ERR_HIP; }
+    hipError_t e = hipMemcpy(hb, N.band_ptr, sizeof(unsigned) * ((size_t)N.B + 1), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hp, N.panel_row, sizeof(int) * ((size_t)N.P + 1), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(hb); free(hp); return hip_fail(e, "hipMemcpy(two-pass tables)", __FILE__, __LINE__); }
+    N.h_band_ptr = hb; N.h_panel_row = hp;
+  }
+  const int nwg1 = (o.bin_wgs > 0 && o.bin_wgs < N.nwg1) ? o.bin_wgs : N.nwg1;
+  // pass 1, band range by band range
+  const int c1 = want_chunks < N.B ? want_chunks : N.B;
+  for (int j = 0; j < c1; ++j) {
+    const int b0 = (int)((int64_t)N.B * j / c1), b1 = (int)((int64_t)N.B * (j + 1) / c1);
+    const int64_t x0 = (int64_t)b0 * kBinCols;
+    int64_t x1 = (int64_t)b1 * kBinCols;
+    if (x1 > A.ncol || j == c1 - 1) x1 = A.ncol;
+    if (x1 > x0) FS_HIP(hipMemcpy(H.sx + x0, x_host + x0, sizeof(double) * (size_t)(x1 - x0), hipMemcpyHostToDevice));
+    const unsigned g0 = N.h_band_ptr[b0], g1 = N.h_band_ptr[b1];
+    if (g1 <= g0) continue;
+    // a range holds 1 / c1 of the groups: fewer persistent workgroups than CUs only when a share would fall under the minimum
+    int wgs = nwg1;
+    const int64_t cap = ((int64_t)(g1 - g0) * kBinGroup + kBinShareMin - 1) / kBinShareMin;
+    if (cap < wgs) wgs = (int)(cap < 1 ? 1 : cap);
+    if (A.vals)
+      hipLaunchKernelGGL((spmv_expand_kernel<true, 4, false, true>), dim3(wgs), dim3(kBinBlock), 0, H.stream, A.ncol, N.B,
+                         N.band_ptr, N.lcol, N.vals, N.gdst, H.sx, 1, N.prod, g0, g1);
+    else
+      hipLaunchKernelGGL((spmv_expand_kernel<false, 4, false, true>), dim3(wgs), dim3(kBinBlock), 0, H.stream, A.ncol, N.B,
+                         N.band_ptr, N.lcol, N.vals, N.gdst, H.sx, 1, N.prod, g0, g1);
+    FS_HIP(hipGetLastError());
+  }
+  // pass 2, panel range by panel range, an event behind each
+  const int c2 = want_chunks < N.P ? want_chunks : N.P;
+  for (int j = 0; j < c2; ++j) {
+    const int p0 = (int)((int64_t)N.P * j / c2), p1 = (int)((int64_t)N.P * (j + 1) / c2);
+    hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, H.stream, N.bin_ptr, N.panel_row, N.lrow,
+                       N.prod, H.sy, 1, p0);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipEventRecord(H.ev[j], H.stream));
+  }
+  for (int j = 0; j < c2; ++j) {
+    const int p0 = (int)((int64_t)N.P * j / c2), p1 = (int)((int64_t)N.P * (j + 1) / c2);
+    const int64_t r0 = N.h_panel_row[p0], r1 = N.h_panel_row[p1];
+    FS_HIP(hipEventSynchronize(H.ev[j]));
+    if (r1 > r0) FS_HIP(hipMemcpy(y_host + r0, H.sy + r0, sizeof(double) * (size_t)(r1 - r0), hipMemcpyDeviceToHost));
   }
   return FS_OK;
 }

@@ -1283,3 +1283,61 @@ print("OK")
     for mode, extra in (("dropin", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}), ("rccl", {"FS_DIST_FORCE_RCCL": "1"})):
         p = subprocess.run([sys.executable, "-c", code, mode], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, (mode, p.stdout[-1500:] + p.stderr[-1500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("valued", [True, False])
+def test_products_with_host_vectors_overlap_copies(hip, valued):
+    """fs_spmv_host / fs_spmv_t_host (what csr_A_mul_B does with malloc'ed vectors): with a two-pass copy x goes up band
+    range by band range and y comes down panel range by panel range around the kernels; with cut rows, or any other
+    kept copy, it is copy + product + copy.  Every row against the oracle, y pre-poisoned, both directions."""
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(41)
+    nrow, ncol = 60_000, 100_000          # 7 bands (the last partial), 120 panels of 500 rows
+    for long_row in (False, True):
+        lens = rng.integers(0, 61, nrow)
+        lens[rng.uniform(size=nrow) < 0.1] = 0
+        if long_row:
+            lens[777] = 5000               # cut into virtual rows: the two-pass copy is kept but the ranges are not used
+        rp = np.zeros(nrow + 1, np.int64)
+        np.cumsum(lens, out=rp[1:])
+        rp = rp.astype(np.int32)
+        nnz = int(rp[-1])
+        cc = rng.integers(0, ncol, nnz).astype(np.int32)
+        cc[-50:] = ncol - 1
+        vv = rng.uniform(-1, 1, nnz) if valued else None
+        capi.set_option("binning", 2)
+        capi.set_option("bin_rows", 500)
+        try:
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+            A.build_transpose(capi.current_stream())
+            assert A.kernel_name() == "two-pass" and A.kernel_name(True) == "two-pass"
+            rows = np.repeat(np.arange(nrow, dtype=np.int32), lens)
+            for x in (S.x_sin(ncol), S.x_int(4, ncol)):
+                y = np.full(nrow, -7.0)
+                A.spmv_host(y, x)
+                ref = O.csr_mul(nrow, rp, cc, vv, x)
+                if not valued and np.all(x == np.round(x)):
+                    assert np.array_equal(y, ref)
+                else:
+                    scale = O.csr_abs_scale(nrow, rp, cc, vv, x)
+                    assert np.all(np.abs(y - ref) <= TOL * np.maximum(scale, 1e-300))
+            for u in (S.x_sin(nrow, 11.0, -0.2), S.x_int(5, nrow)):
+                z = np.full(ncol, -7.0)
+                A.spmv_host(z, u, transposed=True)
+                zref = O.coo_tmul(ncol, rows, cc, vv, u)
+                if not valued and np.all(u == np.round(u)):
+                    assert np.array_equal(z, zref)
+                else:
+                    zscale = O.coo_tmul(ncol, rows, cc, None if vv is None else np.abs(vv), np.abs(u))
+                    assert np.all(np.abs(z - zref) <= TOL * np.maximum(zscale, 1e-300))
+            A.close()
+        finally:
+            capi.set_option("binning", 1)
+            capi.set_option("bin_rows", 0)
+    # a small matrix (chunk-streaming kernel) takes the plain path
+    rp, cc, vv = (np.array([0, 2, 2, 3], np.int32), np.array([0, 2, 1], np.int32), np.array([1.5, -2.0, 4.0]))
+    A = capi.Matrix.from_csr(3, 3, rp, cc, vv)
+    y = np.full(3, -7.0)
+    A.spmv_host(y, np.array([1.0, 2.0, 3.0]))
+    assert np.array_equal(y, [1.5 - 6.0, 0.0, 8.0])

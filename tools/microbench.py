@@ -502,7 +502,9 @@ def main():
             L.csr_A_mul_B(C.c_void_p(yd.data_ptr()), C.byref(A), C.c_void_p(xd.data_ptr()))
             ts.append((time.time() - t0) * 1e3)
         ts.sort()
-        rec = {"name": "dropin_csr_A_mul_B_device_vectors", "ms_min": ts[0], "ms_med": ts[5], "GBs_med": B / ts[5] / 1e6}
+        rec = {"name": "dropin_csr_A_mul_B_device_vectors", "ms_min": ts[0], "ms_med": ts[5], "GBs_med": B / ts[5] / 1e6,
+               "host_chunks": os.environ.get("FS_HOST_CHUNKS", "8"),
+               "max_abs_diff_host_vs_device_vectors": float(np.abs(yd.cpu().numpy() - yh).max())}
         print(json.dumps(rec), flush=True)
         out.write(json.dumps(rec) + "\n")
     if "c5" in what:
