@@ -123,7 +123,9 @@ class HipProvider:
         import torch
         from libfastsparse_amd import capi
         self.torch, self.capi, self.dev = torch, capi, dev
-        capi.lib()
+        # the library allocates and launches on the calling thread's current HIP device: make it this rank's, whatever
+        # torch has done about it so far
+        capi.check(capi.lib().fs_set_device(dev.index if dev.index is not None else 0), "fs_set_device")
 
     def stream(self):
         return self.capi.current_stream()

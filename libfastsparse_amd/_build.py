@@ -59,7 +59,7 @@ def build(force=False, verbose=False):
         objs.append(o)
     if force or _stale(LIB, objs):
         _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs +
-             ["-o", LIB, "-lm", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+             ["-o", LIB, "-lm", "-ldl", "-pthread", "-Wl,-rpath,/opt/rocm/lib"], verbose)
     return LIB
 
 

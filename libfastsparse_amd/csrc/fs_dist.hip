@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -67,6 +68,13 @@ int nccl_fail(ncclResult_t e, const char *what)
     if (e_ != ncclSuccess) return nccl_fail(e_, what);            \
   } while (0)
 
+// the calling thread gets its current device back however the function leaves
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 }  // namespace
 
 struct fs_dist_s {
@@ -95,6 +103,7 @@ fs_dist_t fs_dist_create(int ndev, const int *devices)
   int visible = 0;
   if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { fs::set_error("fs_dist_create: no HIP device"); return nullptr; }
   if (ndev < 1) ndev = visible;
+  DeviceGuard guard;
   fs_dist_t D = new fs_dist_s();
   D->n = ndev;
   bool distinct = true;
@@ -123,13 +132,13 @@ fs_dist_t fs_dist_create(int ndev, const int *devices)
     if (e != ncclSuccess) { nccl_fail(e, "ncclCommInitAll"); D->comm.clear(); fs_dist_destroy(D); return nullptr; }
     D->use_rccl = true;
   }
-  (void)hipSetDevice(D->dev[0]);
   return D;
 }
 
 void fs_dist_destroy(fs_dist_t D)
 {
   if (!D) return;
+  DeviceGuard guard;
   for (ncclComm_t c : D->comm)
     if (c) (void)rccl().CommDestroy(c);
   for (size_t r = 0; r < D->stream.size(); ++r) {
@@ -145,13 +154,13 @@ int fs_dist_uses_rccl(fs_dist_t D) { return D ? (int)D->use_rccl : FS_ERR_ARG; }
 void fs_dist_matrix_destroy(fs_dist_matrix_t M)
 {
   if (!M) return;
+  DeviceGuard guard;
   for (size_t r = 0; r < M->shard.size(); ++r) {
     (void)hipSetDevice(M->D->dev[r]);
     if (M->shard[r]) fs_matrix_destroy(M->shard[r]);
     if (r < M->x.size() && M->x[r]) (void)hipFree(M->x[r]);
     if (r < M->y.size() && M->y[r]) (void)hipFree(M->y[r]);
   }
-  (void)hipSetDevice(M->D->dev[0]);
   delete M;
 }
 
@@ -161,6 +170,7 @@ fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz
                                     const double *vals)
 {
   if (!D || nrow < 0 || ncol < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !cols)) { fs::set_error("fs_dist_csr_create: bad argument"); return nullptr; }
+  DeviceGuard guard;
   fs_dist_matrix_t M = new fs_dist_matrix_s();
   M->D = D; M->nrow = nrow; M->ncol = ncol; M->nnz = nnz;
   const int n = D->n;
@@ -173,7 +183,7 @@ fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz
   }
   M->bounds[n] = nrow;
   M->equal = true;
-  for (int r = 0; r < n; ++r) M->equal = M->equal && (M->bounds[r + 1] - M->bounds[r]) * n == nrow;
+  for (int r = 0; r < n; ++r) M->equal = M->equal && (int64_t)(M->bounds[r + 1] - M->bounds[r]) * n == nrow;
   M->shard.assign((size_t)n, nullptr);
   M->x.assign((size_t)n, nullptr);
   M->y.assign((size_t)n, nullptr);
@@ -198,7 +208,6 @@ fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz
       return nullptr;
     }
   }
-  (void)hipSetDevice(D->dev[0]);
   return M;
 }
 
@@ -265,7 +274,6 @@ static int dist_sync(fs_dist_matrix_t M)
     FS_HIP(hipSetDevice(M->D->dev[r]));
     FS_HIP(hipStreamSynchronize(M->D->stream[r]));
   }
-  FS_HIP(hipSetDevice(M->D->dev[0]));
   return FS_OK;
 }
 
@@ -273,9 +281,24 @@ int fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host)
 {
   if (!M || !y_host || !x_host) { fs::set_error("fs_dist_spmv: NULL argument"); return FS_ERR_ARG; }
   fs_dist_t D = M->D;
-  for (int r = 0; r < D->n; ++r) {     // x to every device over its own PCIe link
-    FS_HIP(hipSetDevice(D->dev[r]));
-    FS_HIP(hipMemcpyAsync(M->x[r], x_host, sizeof(double) * (size_t)M->ncol, hipMemcpyHostToDevice, D->stream[r]));
+  DeviceGuard guard;
+  // x to every device over its own PCIe link.  A copy from pageable memory returns when it is done, so one host thread
+  // per device: N uploads at once instead of N in a row (config 5: 800 MB per device)
+  if (D->n == 1) {
+    FS_HIP(hipSetDevice(D->dev[0]));
+    FS_HIP(hipMemcpyAsync(M->x[0], x_host, sizeof(double) * (size_t)M->ncol, hipMemcpyHostToDevice, D->stream[0]));
+  } else {
+    std::vector<hipError_t> err((size_t)D->n, hipSuccess);
+    std::vector<std::thread> up;
+    for (int r = 0; r < D->n; ++r)
+      up.emplace_back([&, r] {
+        hipError_t e = hipSetDevice(D->dev[r]);
+        if (e == hipSuccess) e = hipMemcpyAsync(M->x[r], x_host, sizeof(double) * (size_t)M->ncol, hipMemcpyHostToDevice, D->stream[r]);
+        if (e == hipSuccess) e = hipStreamSynchronize(D->stream[r]);
+        err[(size_t)r] = e;
+      });
+    for (std::thread &t : up) t.join();
+    for (hipError_t e : err) FS_HIP(e);
   }
   if (int rc = dist_spmv_on_device(M)) return rc;
   FS_HIP(hipSetDevice(D->dev[0]));
@@ -288,6 +311,7 @@ int fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host)
 int fs_dist_spmv_resident(fs_dist_matrix_t M)
 {
   if (!M) { fs::set_error("fs_dist_spmv_resident: NULL handle"); return FS_ERR_ARG; }
+  DeviceGuard guard;
   if (int rc = dist_spmv_on_device(M)) return rc;
   return dist_sync(M);
 }

@@ -50,17 +50,19 @@ static hipError_t traced_free(void *p)
 // this platform (FS_TRACE_BUILD: "hipMalloc of 4921.0 MB took 4160 ms"; a copy that usually builds in 71 ms then takes
 // 3.4 s).  Blocks freed by one builder are reused by the next, and up to FS_SCRATCH_POOL_MB of idle blocks stay for the
 // next creation (pool_trim).
-struct PoolBlock { void *p; size_t bytes; bool used; };
+struct PoolBlock { void *p; size_t bytes; bool used; int device; };   // a block serves its own device only (fs_dist_*)
 static std::mutex g_pool_lock;
 static std::vector<PoolBlock> g_pool;
 
 static hipError_t pool_alloc(void **out, size_t bytes)
 {
   if (bytes == 0) bytes = 1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> g(g_pool_lock);
   int best = -1;
   for (int i = 0; i < (int)g_pool.size(); ++i)
-    if (!g_pool[i].used && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 4 * bytes + (1 << 20) &&
+    if (!g_pool[i].used && g_pool[i].device == dev && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 4 * bytes + (1 << 20) &&
         (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
   if (best >= 0) { g_pool[best].used = true; *out = g_pool[best].p; return hipSuccess; }
   void *p = nullptr;
@@ -73,7 +75,7 @@ static hipError_t pool_alloc(void **out, size_t bytes)
     e = traced_malloc(&p, bytes);
     if (e != hipSuccess) return e;
   }
-  g_pool.push_back(PoolBlock{p, bytes, true});
+  g_pool.push_back(PoolBlock{p, bytes, true, dev});
   *out = p;
   return hipSuccess;
 }
