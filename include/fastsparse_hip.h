@@ -133,7 +133,9 @@ int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream
 /* ---- products on HOST vectors (what a caller of the reference's csr_A_mul_B(y, A, x) holds: csr.h:149) -----
  * Synchronous: y_host is complete on return.  The handle keeps its own staging vectors, stream and events.  With a
  * two-pass copy (the default for large x) x goes up band range by band range and y comes down panel range by panel
- * range while the kernels of the other ranges run (FS_HOST_CHUNKS ranges, default 8; 1 = copy, product, copy). */
+ * range while the kernels of the other ranges run (FS_HOST_CHUNKS ranges, default 8; 1 = copy, product, copy); the
+ * panel kernels are launched in ranges of workgroups with y coming down behind each (tall matrices) or, when chunks
+ * share panels (few long rows), with x going up in the ranges the launch order needs. */
 int fs_spmv_host(fs_matrix_t A, double *y_host, const double *x_host);
 int fs_spmv_t_host(fs_matrix_t A, double *y_host, const double *x_host);
 

@@ -260,7 +260,9 @@ int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
   return fs::launch_spmv(A->a, y, x, (hipStream_t)stream);
 }
 
-// ---- diagnostics (not part of include/fastsparse_hip.h; used by tools/trace_tiled.py) ---------------------
+// ---- diagnostics (not part of include/fastsparse_hip.h; used by tools/trace_tiled.py and the tests) --------
+int fs_debug_last_host_path(void) { return fs::last_host_path(); }
+
 int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
 {
   if (!A || !A->a.tiled || !A->a.tiled->built) { set_error("no tiled copy"); return FS_ERR_ARG; }

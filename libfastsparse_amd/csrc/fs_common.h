@@ -80,6 +80,9 @@ struct TiledCsr {
   int *vfirst = nullptr;       // nrow + 1: first virtual row of every row (only when split > 0)
   double *yv = nullptr;        // nvrow: sums of the virtual rows, combined per row after the kernel
   int slots = 256;             // workgroups resident together (1 per CU)
+  int *h_panel_row = nullptr;  // host mirrors of panel_row / chunk_panel, fetched by the first product with host vectors
+  int *h_chunk_panel = nullptr;
+  int *h_chunk_need = nullptr; // nchunks: columns of x the chunks 0 .. w of the launch order read (chunks sharing panels)
   // LDS-staged kernel only: a workgroup takes a CHUNK = a contiguous range of one panel's work items.  Normally a
   // panel is one chunk; a panel that holds far more than its share of the entries (few, long rows; a monster row) is
   // cut into several, whose y slices are then added up in HBM.  Rows are never cut into virtual rows here.
@@ -216,13 +219,14 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
 // y_host = A x_host: copies and kernels overlapped where the kept copy allows it (two-pass copy without cut rows)
 int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const double *x_host);
+int last_host_path();
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it
 int build_tiledx(DeviceCsr &A, hipStream_t s);      // the same for the LDS-staged kernel's geometry
 int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs = 1,
-                      int ys = 1);                  // T.ldsx selects the LDS-staged kernel
+                      int ys = 1, int c0 = 0, int c1 = -1);                  // T.ldsx selects the LDS-staged kernel
 int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heuristic ask for it
 int build_binned_k(DeviceCsr &A, int kw, hipStream_t s);   // the k-column copy (kw = 2 or 4) into A.binned2 / A.binned4
 int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys);

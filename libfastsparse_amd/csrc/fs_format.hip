@@ -126,6 +126,9 @@ static void free_tiled_slot(TiledCsr *&T)
   void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item};
   for (void *q : owned)
     if (q) (void)traced_free(q);
+  free(T->h_panel_row);
+  free(T->h_chunk_panel);
+  free(T->h_chunk_need);
   delete T;
   T = nullptr;
 }

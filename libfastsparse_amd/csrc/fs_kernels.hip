@@ -29,6 +29,9 @@
 //   cbcsr_kernel         column-blocked binary CSR, x tile staged in LDS per column block
 #include <stdlib.h>
 
+#include <chrono>
+#include <vector>
+
 #include "fs_common.h"
 
 namespace fs {
@@ -1283,25 +1286,34 @@ __global__ __launch_bounds__(kBlock) void tiled_combine_kernel(int nrow, const i
   }
 }
 
-int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs, int ys)
+// c0 .. c1: the workgroups of this launch (chunks of the LDS-staged kernel, panels of the L2-tiled one); c1 < 0 = all.
+// A part launch needs every workgroup to own its rows (no chunks sharing a panel, no cut rows): spmv_host_vectors
+int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs, int ys,
+                      int c0, int c1)
 {
   const bool nt = !(options().tiled_flags & 1);  // bit 0: cached (not nt) entry loads
   double *out = T.split ? T.yv : y;              // cut rows: virtual sums first, combined below
   const int os = T.split ? 1 : ys;
+  const bool part = c1 >= 0;
+  if (part && T.split) { set_error("launch_spmv_tiled: a copy with cut rows cannot be launched in parts"); return FS_ERR_ARG; }
+  if (!part) { c0 = 0; c1 = T.ldsx ? T.nchunks : T.P; }
+  if (c1 <= c0) return FS_OK;
   if (T.ldsx) {
-    // chunks of one panel add into the same rows: the output then goes through the zeroed scratch vector
+    // chunks of one panel add into the same rows: the output then goes through the zeroed scratch vector (a part launch
+    // adds into T.yv as it is and leaves the copy to y to its caller, who zeroed T.yv before the first part)
     if (T.shared) {
-      FS_HIP(hipMemsetAsync(T.yv, 0, sizeof(double) * (size_t)A.nrow, s));
+      if (!part) FS_HIP(hipMemsetAsync(T.yv, 0, sizeof(double) * (size_t)A.nrow, s));
       out = T.yv;
     }
     const int ost = T.shared ? 1 : ys;
     if (T.nchunks > 0) {
 #define FS_LDSX(V, N)                                                                                              \
-  hipLaunchKernelGGL((spmv_ldsx_kernel<V, N, kLdsxSets>), dim3(T.nchunks), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
-                     T.lcol_bits, A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
+  hipLaunchKernelGGL((spmv_ldsx_kernel<V, N, kLdsxSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
+                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, xs, ost)
 #define FS_LDSXP(V, N, X1)                                                                                         \
-  hipLaunchKernelGGL((spmv_ldsx_pipe_kernel<V, N, X1, kLdsxPipeSets>), dim3(T.nchunks), dim3(kTiledBlock), 0, s,     \
-                     T.panel_row, T.W, T.lcol_bits, A.ncol, T.items, T.chunk_panel, T.chunk_item, T.pk, T.vals, x, out, xs, ost)
+  hipLaunchKernelGGL((spmv_ldsx_pipe_kernel<V, N, X1, kLdsxPipeSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s,       \
+                     T.panel_row, T.W, T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, \
+                     out, xs, ost)
       if (options().tiled_flags & 2) {             // bit 1: the first version (gather and add of an item in one phase)
         if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
         else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
@@ -1315,7 +1327,7 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
 #undef FS_LDSXP
       FS_HIP(hipGetLastError());
     }
-    if (T.shared) {
+    if (T.shared && !part) {
       hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                          A.nrow, T.yv, y, ys);
       FS_HIP(hipGetLastError());
@@ -1323,8 +1335,8 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
     return FS_OK;   // rows are never cut for this kernel: no combine pass
   } else {
 #define FS_TILED(V, N)                                                                                         \
-  hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W, T.lcol_bits, \
-                     T.items, T.item_ptr, T.pk, T.vals, x, out, xs, os)
+  hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row + c0, T.W, T.lcol_bits, \
+                     T.items, T.item_ptr + c0, T.pk, T.vals, x, out, xs, os)
     if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
     else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
 #undef FS_TILED
@@ -1554,8 +1566,14 @@ static int host_pipe_ready(HostPipe &H, size_t nx, size_t ny, int nev)
   return FS_OK;
 }
 
+// which way the last product with host vectors went (diagnostics / tests): 0 copy + product + copy, 1 two-pass in ranges
+// of bands and panels, 2 a panel kernel in ranges of workgroups
+static int g_last_host_path = 0;
+int last_host_path() { return g_last_host_path; }
+
 int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const double *x_host)
 {
+  g_last_host_path = 0;
   if (A.nrow == 0) return FS_OK;
   static const int want_chunks = [] {
     const char *e = getenv("FS_HOST_CHUNKS");
@@ -1568,12 +1586,122 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
   const bool two_pass = A.binned && A.binned->built && !A.binned->split && A.binned->nwg1 > 0 && !o.strict_order &&
                         !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7) && o.bin_flags == 0 && want_chunks > 1;
   if (!two_pass) {
+    // the panel kernels (LDS-staged, L2-tiled) need all of x, but a workgroup that owns its rows finishes them: launched in
+    // ranges of workgroups, y comes down range by range under the later ranges (a tall matrix: config 3, y 80 MB, x 8 MB)
+    const TiledCsr *T = nullptr;
+    if (!(A.binned && A.binned->built) && !o.strict_order && want_chunks > 1) {
+      if (A.tiledx && A.tiledx->built && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) T = A.tiledx;
+      else if (A.tiled && A.tiled->built && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) T = A.tiled;
+    }
+    if (T && T->ldsx && T->shared && T->nchunks >= 2 * want_chunks && A.ncol >= (1 << 20)) {
+      // Few, long rows (config 3 transposed: x 80 MB, y 8 MB): several chunks per panel, launched stretch of bands by
+      // stretch of bands (fs_format.hip "Launch order"), so the chunks at the front of the order only read the front of x.
+      // need[w] = columns the chunks 0 .. w read; x goes up in ranges and the chunks a range completes are launched behind it.
+      TiledCsr &M = const_cast<TiledCsr &>(*T);
+      if (!M.h_chunk_need) {
+        std::vector<int> ci(2 * (size_t)M.nchunks);
+        std::vector<int4> it((size_t)M.nitems > 0 ? (size_t)M.nitems : 1);
+        int *need = (int *)malloc(sizeof(int) * (size_t)M.nchunks);
+        if (!need) { set_error("out of host memory"); return FS_ERR_HIP; }
+        hipError_t e = hipMemcpy(ci.data(), M.chunk_item, sizeof(int) * ci.size(), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && M.nitems > 0) e = hipMemcpy(it.data(), M.items, sizeof(int4) * (size_t)M.nitems, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(need); return hip_fail(e, "hipMemcpy(chunk tables)", __FILE__, __LINE__); }
+        int64_t most = 0;
+        for (int w = 0; w < M.nchunks; ++w) {
+          for (int i = ci[2 * (size_t)w]; i < ci[2 * (size_t)w + 1]; ++i) {
+            const int64_t end = ((int64_t)it[(size_t)i].z + 1) * M.W;
+            if (end > most) most = end;
+          }
+          need[w] = (int)(most < A.ncol ? most : A.ncol);
+        }
+        int *hc = (int *)malloc(sizeof(int) * (size_t)M.nchunks);
+        if (!hc) { free(need); set_error("out of host memory"); return FS_ERR_HIP; }
+        e = hipMemcpy(hc, M.chunk_panel, sizeof(int) * (size_t)M.nchunks, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(need); free(hc); return hip_fail(e, "hipMemcpy(chunk tables)", __FILE__, __LINE__); }
+        free(M.h_chunk_panel);
+        M.h_chunk_panel = hc;
+        M.h_chunk_need = need;
+      }
+      g_last_host_path = 3;
+      FS_HIP(hipMemsetAsync(M.yv, 0, sizeof(double) * (size_t)A.nrow, H.stream));
+      // a range = one or more whole stretch groups of the launch order (the panel id falls back where the next group starts),
+      // at least one generation of resident workgroups long
+      const int slots = M.slots > 0 ? M.slots : 256;
+      int64_t have = 0;
+      int w0 = 0;
+      static const bool trace = getenv("FS_HOST_TRACE") != nullptr;   // the timeline of the call on stderr
+      const auto tt0 = std::chrono::steady_clock::now();
+      auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
+      while (w0 < M.nchunks) {
+        int w1 = w0 + 1;
+        while (w1 < M.nchunks &&
+               ((M.h_chunk_panel[w1] & 0x7fffffff) >= (M.h_chunk_panel[w1 - 1] & 0x7fffffff) || w1 - w0 < slots)) ++w1;
+        // no short tail, and nothing is cut once all of x is needed (every launch ends in a partly filled generation)
+        if (M.nchunks - w1 < slots || M.h_chunk_need[w1 - 1] >= A.ncol) w1 = M.nchunks;
+        const int64_t upto = M.h_chunk_need[w1 - 1];
+        if (upto > have) {
+          FS_HIP(hipMemcpy(H.sx + have, x_host + have, sizeof(double) * (size_t)(upto - have), hipMemcpyHostToDevice));
+          have = upto;
+        }
+        if (trace) fprintf(stderr, "[host] %.3f ms: x up to %lld, chunks %d..%d\n", now_ms(), (long long)have, w0, w1);
+        if (int rc = launch_spmv_tiled(A, M, H.sy, H.sx, H.stream, 1, 1, w0, w1)) return rc;
+        w0 = w1;
+      }
+      hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, H.stream,
+                         A.nrow, M.yv, H.sy, 1);
+      FS_HIP(hipGetLastError());
+      FS_HIP(hipStreamSynchronize(H.stream));
+      if (trace) fprintf(stderr, "[host] %.3f ms: kernels done\n", now_ms());
+      FS_HIP(hipMemcpy(y_host, H.sy, sizeof(double) * ny, hipMemcpyDeviceToHost));
+      if (trace) fprintf(stderr, "[host] %.3f ms: y down\n", now_ms());
+      return FS_OK;
+    }
     if (A.ncol > 0) FS_HIP(hipMemcpy(H.sx, x_host, sizeof(double) * (size_t)A.ncol, hipMemcpyHostToDevice));
+    if (T && !T->split && !(T->ldsx && T->shared) && T->P >= 2 * want_chunks) {
+      TiledCsr &M = const_cast<TiledCsr &>(*T);
+      if (!M.h_panel_row) {
+        int *hp = (int *)malloc(sizeof(int) * ((size_t)M.P + 1));
+        int *hc = (int *)malloc(sizeof(int) * (size_t)(M.nchunks > 0 ? M.nchunks : 1));
+        if (!hp || !hc) { free(hp); free(hc); set_error("out of host memory"); return FS_ERR_HIP; }
+        hipError_t e = hipMemcpy(hp, M.panel_row, sizeof(int) * ((size_t)M.P + 1), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && M.ldsx && M.nchunks > 0)
+          e = hipMemcpy(hc, M.chunk_panel, sizeof(int) * (size_t)M.nchunks, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(hp); free(hc); return hip_fail(e, "hipMemcpy(panel tables)", __FILE__, __LINE__); }
+        M.h_panel_row = hp; M.h_chunk_panel = hc;
+      }
+      // workgroup w owns panel w (LDS-staged: one chunk per panel when no panel is shared)
+      const int nwg = M.P;
+      bool own = !M.ldsx || M.nchunks == M.P;
+      for (int w = 0; own && M.ldsx && w < nwg; ++w) own = M.h_chunk_panel[w] == w;
+      // One workgroup per CU and launches of one stream run one after the other, so a range is a whole number of
+      // generations of resident workgroups (config 3: 698 panels = 256 + 256 + 186; eight ranges of 87 were measured to
+      // take eight generations, 2.42 ms per call against 1.87): y starts to come down after the first generation
+      const int slots = M.slots > 0 ? M.slots : 256;
+      const int gens = (nwg + slots - 1) / slots;
+      const int c = want_chunks < gens ? want_chunks : gens;
+      if (own && c >= 2) {
+        g_last_host_path = 2;
+        auto cut = [&](int j) { const int64_t w = (int64_t)slots * ((int64_t)gens * j / c); return (int)(w < nwg ? w : nwg); };
+        for (int j = 0; j < c; ++j) {
+          const int w0 = cut(j), w1 = j == c - 1 ? nwg : cut(j + 1);
+          if (int rc = launch_spmv_tiled(A, M, H.sy, H.sx, H.stream, 1, 1, w0, w1)) return rc;
+          FS_HIP(hipEventRecord(H.ev[j], H.stream));
+        }
+        for (int j = 0; j < c; ++j) {
+          const int w0 = cut(j), w1 = j == c - 1 ? nwg : cut(j + 1);
+          const int64_t r0 = M.h_panel_row[w0], r1 = M.h_panel_row[w1];
+          FS_HIP(hipEventSynchronize(H.ev[j]));
+          if (r1 > r0) FS_HIP(hipMemcpy(y_host + r0, H.sy + r0, sizeof(double) * (size_t)(r1 - r0), hipMemcpyDeviceToHost));
+        }
+        return FS_OK;
+      }
+    }
     if (int rc = launch_spmv(A, H.sy, H.sx, H.stream)) return rc;
     FS_HIP(hipStreamSynchronize(H.stream));
     FS_HIP(hipMemcpy(y_host, H.sy, sizeof(double) * ny, hipMemcpyDeviceToHost));
     return FS_OK;
   }
+  g_last_host_path = 1;
   BinnedCsr &N = *A.binned;
   if (!N.h_band_ptr) {
     unsigned *hb = (unsigned *)malloc(sizeof(unsigned) * ((size_t)N.B + 1));

@@ -1316,6 +1316,7 @@ def test_products_with_host_vectors_overlap_copies(hip, valued):
             for x in (S.x_sin(ncol), S.x_int(4, ncol)):
                 y = np.full(nrow, -7.0)
                 A.spmv_host(y, x)
+                assert capi.lib().fs_debug_last_host_path() == (0 if long_row else 1)
                 ref = O.csr_mul(nrow, rp, cc, vv, x)
                 if not valued and np.all(x == np.round(x)):
                     assert np.array_equal(y, ref)
@@ -1335,9 +1336,78 @@ def test_products_with_host_vectors_overlap_copies(hip, valued):
         finally:
             capi.set_option("binning", 1)
             capi.set_option("bin_rows", 0)
+    # the panel kernels (LDS-staged, L2-tiled): every workgroup owns its rows when no panel is shared and no row is cut,
+    # and y comes down in ranges of panels; config 3's density, 400 panels of 1000 rows
+    nrow, ncol = 400_000, 100_000
+    lens = rng.integers(40, 90, nrow)
+    lens[rng.uniform(size=nrow) < 0.05] = 0
+    lens[:3] = 0
+    lens[-2:] = 0
+    lens[5000] = 200
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    vv = rng.uniform(-1, 1, nnz) if valued else None
+    xs_, xi_ = S.x_sin(ncol), S.x_int(4, ncol)
+    ref_s, ref_i = O.csr_mul(nrow, rp, cc, vv, xs_), O.csr_mul(nrow, rp, cc, vv, xi_)
+    sc_s = O.csr_abs_scale(nrow, rp, cc, vv, xs_)
+    for opts, name in (({"ldsx": 2, "tiling": 0, "binning": 0, "tile_rows": 1000}, "lds-staged"),
+                       ({"ldsx": 0, "tiling": 2, "binning": 0, "tile_rows": 1000}, "tiled")):
+        for k, v in opts.items():
+            capi.set_option(k, v)
+        try:
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+        finally:
+            for k, v in (("ldsx", 1), ("tiling", 1), ("binning", 1), ("tile_rows", 0)):
+                capi.set_option(k, v)
+        assert A.kernel_name() == name
+        y = np.full(nrow, -7.0)
+        A.spmv_host(y, xs_)
+        assert capi.lib().fs_debug_last_host_path() == 2, name
+        assert np.all(np.abs(y - ref_s) <= TOL * np.maximum(sc_s, 1e-300)), name
+        y[:] = -7.0
+        A.spmv_host(y, xi_)
+        if valued:
+            assert np.all(np.abs(y - ref_i) <= TOL * np.maximum(O.csr_abs_scale(nrow, rp, cc, vv, xi_), 1e-300)), name
+        else:
+            assert np.array_equal(y, ref_i), name
+        A.close()
+    # few, long rows (config 3 transposed in small: 50 k x 1.2 M, 960 per row): chunks share panels and are launched stretch
+    # of bands by stretch of bands, so x goes up in ranges with the chunks that need no more than what has landed behind it
+    nrow, ncol = 1_200_000, 50_000
+    rp = (np.arange(nrow + 1, dtype=np.int64) * 40).astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    vv = rng.uniform(-1, 1, nnz) if valued else None
+    capi.set_option("ldsx", 2)
+    capi.set_option("binning", 0)
+    capi.set_option("tiling", 0)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+        A.build_transpose(capi.current_stream())
+    finally:
+        capi.set_option("ldsx", 1)
+        capi.set_option("binning", 1)
+        capi.set_option("tiling", 1)
+    assert A.kernel_name(True) == "lds-staged"
+    rows = np.repeat(np.arange(nrow, dtype=np.int32), 40)
+    for u in (S.x_sin(nrow, 11.0, -0.2), S.x_int(5, nrow)):
+        z = np.full(ncol, -7.0)
+        A.spmv_host(z, u, transposed=True)
+        assert capi.lib().fs_debug_last_host_path() == 3
+        zref = O.coo_tmul(ncol, rows, cc, vv, u)
+        if not valued and np.all(u == np.round(u)):
+            assert np.array_equal(z, zref)
+        else:
+            zscale = O.coo_tmul(ncol, rows, cc, None if vv is None else np.abs(vv), np.abs(u))
+            assert np.all(np.abs(z - zref) <= TOL * np.maximum(zscale, 1e-300))
+    A.close()
     # a small matrix (chunk-streaming kernel) takes the plain path
     rp, cc, vv = (np.array([0, 2, 2, 3], np.int32), np.array([0, 2, 1], np.int32), np.array([1.5, -2.0, 4.0]))
     A = capi.Matrix.from_csr(3, 3, rp, cc, vv)
     y = np.full(3, -7.0)
     A.spmv_host(y, np.array([1.0, 2.0, 3.0]))
+    assert capi.lib().fs_debug_last_host_path() == 0
     assert np.array_equal(y, [1.5 - 6.0, 0.0, 8.0])

@@ -303,6 +303,33 @@ def main():
             report(out, f"c3_bcsr_forced_{label}:{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st)))
             del A
         capi.set_option("spmv_kernel", 0)
+    if "hostvec" in what:
+        # products with HOST vectors (fs_spmv_host): config 3's shape, A (y 80 MB down) and A' (x 80 MB up), wall time per call
+        import numpy as np
+        nrow, ncol = n, max(n // 10, 1)
+        rp, cc, _ = capi.synth_uniform(nrow, ncol, 64, 0x5EED0003, valued=False)
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+        A.build_transpose(st)
+        torch.cuda.synchronize()
+        xh = np.round(1000 * np.sin(np.arange(ncol) * 0.7))
+        uh = np.round(1000 * np.cos(np.arange(nrow) * 0.3))
+        yh, zh = np.empty(nrow), np.empty(ncol)
+        for tr, (o, i) in ((False, (yh, xh)), (True, (zh, uh))):
+            A.spmv_host(o, i, transposed=tr)
+            ts = []
+            for _ in range(10):
+                t0 = time.time()
+                A.spmv_host(o, i, transposed=tr)
+                ts.append((time.time() - t0) * 1e3)
+            ts.sort()
+            od = torch.empty(o.size, dtype=torch.float64, device="cuda")
+            A.spmv(od, torch.from_numpy(i).cuda(), st, transposed=tr)
+            rec = {"name": "c3_%s_host_vectors:%s" % ("At_mul_B" if tr else "A_mul_B", A.kernel_name(tr)), "ms_min": ts[0], "ms_med": ts[5],
+                   "path": capi.lib().fs_debug_last_host_path(), "host_chunks": os.environ.get("FS_HOST_CHUNKS", "8"),
+                   "equal_to_device_vector_product": bool(np.array_equal(od.cpu().numpy(), o))}
+            print(json.dumps(rec), flush=True)
+            out.write(json.dumps(rec) + "\n")
+        del A
     if "cols" in what:
         # how the product behaves as x shrinks (column count), rows and non-zeros as config 2
         capi.set_option("tiling", args.tiling)
