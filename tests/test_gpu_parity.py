@@ -755,6 +755,7 @@ def test_fuzz_every_forced_copy_small_shapes(hip):
     from libfastsparse_amd import capi
     rng = np.random.default_rng(int(os.environ.get("FS_FUZZ_SEED", "20261004")))
     opts = ("binning", "ldsx", "tiling", None)
+    host_paths = set()
     try:
         for trial in range(int(os.environ.get("FS_FUZZ_TRIALS", "48"))):
             scale = int(os.environ.get("FS_FUZZ_SCALE", "1"))        # one-off runs at larger sizes
@@ -792,8 +793,8 @@ def test_fuzz_every_forced_copy_small_shapes(hip):
             A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
             ref = O.csr_mul(nrow, rp, cc, vv, x)
             if valued:
-                sc = O.csr_abs_scale(nrow, rp, cc, vv, x)
-                assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(sc, 1e-300)), what
+                sc_y = O.csr_abs_scale(nrow, rp, cc, vv, x)
+                assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * np.maximum(sc_y, 1e-300)), what
             else:
                 assert np.array_equal(y.cpu().numpy(), ref), what
             u = S.x_sin(nrow, 11.0, -0.2) if valued else S.x_int(trial + 1, nrow)
@@ -813,10 +814,22 @@ def test_fuzz_every_forced_copy_small_shapes(hip):
             for j in range(2):
                 sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X[:, j]))
                 assert np.all(np.abs(Y.cpu().numpy()[:, j] - Yref[:, j]) <= TOL * np.maximum(sc, 1e-300)), (what, j)
+            # the same two products with HOST vectors (fs_spmv_host: ranges of bands / panels / workgroups where the copy allows)
+            yh, zh = np.full(nrow, -1.0), np.full(ncol, -1.0)
+            A.spmv_host(yh, x)
+            host_paths.add(capi.lib().fs_debug_last_host_path())
+            A.spmv_host(zh, u, transposed=True)
+            host_paths.add(capi.lib().fs_debug_last_host_path())
+            if valued:
+                assert np.all(np.abs(yh - ref) <= TOL * np.maximum(sc_y, 1e-300)), what
+                assert np.all(np.abs(zh - zref) <= TOL * np.maximum(zs, 1e-300)), what
+            else:
+                assert np.array_equal(yh, ref) and np.array_equal(zh, zref), what
             del A
     finally:
         for k_ in ("tile_rows", "tile_cols", "bin_rows", "tile_split"):
             capi.set_option(k_, 0)
+    assert {0, 1, 2} <= host_paths or int(os.environ.get("FS_FUZZ_TRIALS", "48")) < 48, host_paths
 
 
 @pytest.mark.parametrize("valued", [False, True])
