@@ -622,45 +622,160 @@ static int max_row_len(const DeviceCsr &A, hipStream_t s, int *out)
 }
 
 // LDS-staged kernel only: inside a work item the order of the entries is free (the kernel adds with LDS atomics), so
-// every item is rearranged round-robin over the residue classes of the local row mod 32 -- the 32 lanes of a
-// half-wave then add into 32 different bank pairs of the y slice.  Entry with class c and rank r inside its class goes
-// to position  sum_c' min(count[c'], r) + #{c' < c : count[c'] > r}.
-__global__ __launch_bounds__(256) void ldsx_reorder_kernel(const int4 *__restrict__ items, int lcol_bits,
-                                                          unsigned *__restrict__ pk, double *__restrict__ vals)
+// every item is rearranged for the LDS banks.  A half-wave (32 lanes) of the kernel takes 32 consecutive members of a
+// SEQUENCE built here; its ds_add_f64 into the y slice is conflict-free when the 32 local rows differ mod 32 (bank pairs),
+// its ds_read_b64 from the x slice when the 32 local columns differ mod 32.
+//   Rows: round-robin over the row classes (local row mod 32) -- round r holds one entry of every class that still has
+//     one, in class order, so lane l of a half-wave adds into bank pair l until the classes start to run out.
+//   Columns (ARRANGE; FS_LDSX_ARRANGE=0 turns it off): WHICH entry of its class goes into round r is free.  The classes
+//     of a round choose together so that their column banks differ: every class proposes a bank it still has entries for
+//     and that the round has not used (starting from the diagonal (class + round) mod 32), the lowest class wins a
+//     contested bank, the losers propose again; a class left without a free bank takes any.  Random columns cost 3.5
+//     cycles per half-wave gather in stored order and about 2 this way (simulated).  Measured on config 3 with a serial
+//     greedy of the same quality (which took 570 ms per matrix; this one works a round with 32 lanes at once):
+//     A 0.79 -> 0.745 ms, A' 0.866 -> 0.824 ms.
+// Sequence place s goes to stored position 2s (first half) or 2(s - half) + 1: the kernel's thread t takes the ADJACENT
+// entries 2t and 2t + 1 (one 8-byte load), so the lanes of a wave see, for their first entry, every other stored
+// position, and each of the two adds of a wave walks consecutive members of the sequence.
+__device__ __forceinline__ int rot_ffs(unsigned m, int rot)   // lowest set bit of m at or after bit `rot`, cyclically (m != 0)
+{
+  const unsigned rr = rot ? ((m >> rot) | (m << (32 - rot))) : m;
+  return (__ffs((int)rr) - 1 + rot) & 31;
+}
+
+// orders the LDS accesses of the lanes of ONE wave (the hardware runs a wave's LDS instructions in order; this keeps the
+// compiler from moving them across and waits for the ones in flight)
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kReorderThreads = 256;
+constexpr int kReorderSegs = kReorderThreads / 32;               // the item is counted in 8 segments at once
+constexpr int kReorderPer = kTiledItem / kReorderThreads;        // entries per thread when the item is copied out
+
+template <bool ARRANGE>
+__global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int4 *__restrict__ items, int lcol_bits,
+                                                                      unsigned *__restrict__ pk, double *__restrict__ vals)
 {
   __shared__ unsigned w[kTiledItem];
-  __shared__ double v[kTiledItem];
-  __shared__ unsigned short rk[kTiledItem];
-  __shared__ int cnt[32];
+  __shared__ unsigned short lst[kTiledItem];   // entries grouped by (row class, column bank), stored order inside a group
+  __shared__ unsigned short seq[kTiledItem];   // first: rank of an entry inside its (segment, class, bank); then the sequence
+  __shared__ unsigned short segcnt[kReorderSegs][32 * 32];   // entries of (class, bank) per segment, then their prefix
+  __shared__ unsigned short left[32 * 32];     // entries of (class, bank) not placed yet
+  __shared__ unsigned short size[32 * 32];     // entries of (class, bank)
+  __shared__ unsigned short off[32 * 32];      // first entry of (class, bank) in lst
+  __shared__ int owner[32];
   const int4 d = items[blockIdx.x];
   const int n = d.y, t = threadIdx.x;
-  if (t < 32) cnt[t] = 0;
-  for (int i = t; i < n; i += 256) {
-    w[i] = pk[(int64_t)d.x + i];
-    if (vals) v[i] = vals[(int64_t)d.x + i];
+  for (int i = t; i < n; i += kReorderThreads) w[i] = pk[(int64_t)d.x + i];
+  for (int i = t; i < kReorderSegs * 32 * 32; i += kReorderThreads) (&segcnt[0][0])[i] = 0;
+  __syncthreads();
+  // thread (segment, class) walks its segment of the item and ranks the entries of its class per column bank
+  {
+    const int sg = t >> 5, c = t & 31;
+    const int per = (n + kReorderSegs - 1) / kReorderSegs;
+    const int i0 = sg * per, i1 = (i0 + per < n) ? i0 + per : n;
+    for (int i = i0; i < i1; ++i)
+      if ((int)((w[i] >> lcol_bits) & 31u) == c) {
+        const int k = c * 32 + (ARRANGE ? (int)(w[i] & 31u) : 0);
+        seq[i] = segcnt[sg][k]++;
+      }
   }
   __syncthreads();
-  // ranks inside a class follow the stored order (one thread per class walks the item: 32 x 2048 steps, once per matrix)
-  if (t < 32) {
-    int c = 0;
-    for (int i = 0; i < n; ++i)
-      if ((int)((w[i] >> lcol_bits) & 31u) == t) rk[i] = (unsigned short)c++;
-    cnt[t] = c;
+  // per (class, bank): prefix over the segments, total
+  for (int k = t; k < 32 * 32; k += kReorderThreads) {
+    int a = 0;
+    for (int sg = 0; sg < kReorderSegs; ++sg) { const int m = segcnt[sg][k]; segcnt[sg][k] = (unsigned short)a; a += m; }
+    size[k] = (unsigned short)a;
+    left[k] = (unsigned short)a;
   }
   __syncthreads();
-  for (int i = t; i < n; i += 256) {
-    const int c = (int)((w[i] >> lcol_bits) & 31u), r = rk[i];
-    int pos = 0;
+  // lane c of wave 0 owns row class c: offsets of its banks in lst (class totals by a wave scan)
+  unsigned avail = 0;                           // banks this class still has entries for
+  int mine = 0;
+  if (t < 64) {
+    if (t < 32)
+      for (int b = 0; b < 32; ++b) mine += size[t * 32 + b];
+    int base = mine;
+    for (int m = 1; m < 32; m <<= 1) {
+      const int o = __shfl_up(base, m);
+      if (t >= m) base += o;
+    }
+    base -= mine;
+    if (t < 32) {
+      int a = base;
+      for (int b = 0; b < 32; ++b) {
+        off[t * 32 + b] = (unsigned short)a;
+        a += size[t * 32 + b];
+        if (size[t * 32 + b]) avail |= 1u << b;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int per = (n + kReorderSegs - 1) / kReorderSegs;
+    for (int i = t; i < n; i += kReorderThreads) {
+      const int k = (int)((w[i] >> lcol_bits) & 31u) * 32 + (ARRANGE ? (int)(w[i] & 31u) : 0);
+      lst[off[k] + segcnt[i / per][k] + seq[i]] = (unsigned short)i;
+    }
+  }
+  __syncthreads();
+  if (t < 64) {                                 // the rounds: wave 0, lanes 32-63 only take part in the ballots
+    int remaining = t < 32 ? mine : 0, placed = 0;
+    for (int r = 0;; ++r) {
+      const unsigned nonempty = (unsigned)__ballot(remaining > 0);
+      if (!nonempty) break;
+      unsigned used = 0;
+      int bank = -1;
+      bool pending = remaining > 0;
+      for (int iter = 0;; ++iter) {
+        int prop = -1;
+        if (pending) {
+          const unsigned free_banks = avail & ~used;
+          const int rot = (t + r + 7 * iter) & 31;
+          if (!ARRANGE || free_banks == 0u) { bank = rot_ffs(avail, rot); pending = false; }
+          else prop = rot_ffs(free_banks, rot);
+        }
+        if (!__ballot(prop >= 0)) break;        // everybody is settled
+        if (t < 32) owner[t] = 255;
+        wave_lds_fence();
+        if (prop >= 0) atomicMin(&owner[prop], t);
+        wave_lds_fence();
+        if (prop >= 0 && owner[prop] == t) { bank = prop; pending = false; }
+        used |= (unsigned)__ballot(t < 32 && owner[t & 31] != 255);    // lane index = bank index
+        wave_lds_fence();
+      }
+      if (bank >= 0) {
+        const int k = t * 32 + bank;
+        const int before = left[k];
+        left[k] = (unsigned short)(before - 1);
+        if (before == 1) avail &= ~(1u << bank);
+        --remaining;
+        seq[placed + __popc(nonempty & ((1u << t) - 1u))] = lst[off[k] + (size[k] - before)];
+      }
+      placed += __popc(nonempty);
+    }
+  }
+  __syncthreads();
+  // copy out: sources into registers first (the item is permuted in place)
+  const int half = (n + 1) >> 1;
+  double v[kReorderPer];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) pos += (cnt[k] < r ? cnt[k] : r) + ((k < c && cnt[k] > r) ? 1 : 0);
-    // `pos` is the place in the round-robin sequence.  The kernel's thread t takes the ADJACENT entries 2t and 2t+1 (one
-    // 8-byte load), so the lanes of a wave see, for their first entry, every other stored position: the first half of
-    // the sequence goes to the even positions, the second half to the odd ones, and each of the two adds of a wave
-    // still walks consecutive members of the sequence.
-    const int half = (n + 1) >> 1;
-    pos = pos < half ? 2 * pos : 2 * (pos - half) + 1;
-    pk[(int64_t)d.x + pos] = w[i];
-    if (vals) vals[(int64_t)d.x + pos] = v[i];
+  for (int j = 0; j < kReorderPer; ++j) {
+    const int q = t + j * kReorderThreads;
+    v[j] = (vals && q < n) ? vals[(int64_t)d.x + seq[q]] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kReorderPer; ++j) {
+    const int q = t + j * kReorderThreads;
+    if (q < n) {
+      const int pos = q < half ? 2 * q : 2 * (q - half) + 1;
+      pk[(int64_t)d.x + pos] = w[seq[q]];
+      if (vals) vals[(int64_t)d.x + pos] = v[j];
+    }
   }
 }
 
@@ -857,7 +972,11 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   if (!items.empty()) FS_HIP(hipMemcpy(T->items, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
   if (ldsx && T->nitems > 0) {
-    hipLaunchKernelGGL(ldsx_reorder_kernel, dim3(T->nitems), dim3(256), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
+    static const bool arrange = [] { const char *v = getenv("FS_LDSX_ARRANGE"); return !(v && *v == '0'); }();
+    if (arrange)
+      hipLaunchKernelGGL(ldsx_reorder_kernel<true>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
+    else
+      hipLaunchKernelGGL(ldsx_reorder_kernel<false>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
     FS_HIP(hipGetLastError());
     FS_HIP(hipStreamSynchronize(s));
   }
