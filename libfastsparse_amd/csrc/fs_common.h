@@ -196,7 +196,8 @@ struct Options {
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
   int tile_split = 0;    // rows longer than this are cut into virtual rows (0 = 256)
-  int tiled_flags = 0;   // tuning switches of the tiled kernel (see launch_spmv_tiled)
+  int tiled_flags = 0;   // tuning switches of the tiled kernels (launch_spmv_tiled): bit 0 cached entry loads, bit 1 the first
+                         // LDS-staged kernel, bit 2 no LDS DMA for the x slices (spmv_ldsx_pipe_kernel); FS_TILED_FLAGS presets it
   int reproducible = 0;  // 1: only kernels whose sums are bit-identical run to run (the two-pass kernels add with LDS
                          // atomics in arrival order); read when a matrix is created and at every product
   int bin_wgs = 0;       // override the number of persistent pass-1 workgroups (0 = one per CU)

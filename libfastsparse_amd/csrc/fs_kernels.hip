@@ -929,6 +929,153 @@ __global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int n
   if (r < nrow) y[r] = 0.0 + tot;
 }
 
+// The pipelined sweep with the x slices sent STRAIGHT from global memory into LDS (global_load_lds_dwordx4: 16 bytes per
+// lane land at M0 + 16 * lane, so a wave fills 1 KiB of a slice with one instruction): no pass through the registers, no
+// ds_write of the slice, four VGPRs fewer per register set.  The default of the LDS-staged copy when x has unit stride, is
+// 16-byte aligned and has an even number of columns (a pair load at the end of an odd vector would read past it);
+// spmv_ldsx_pipe_kernel otherwise and with tiled_flags bit 2.  Config 3: A 0.745 -> 0.70 ms, A' 0.826 -> 0.775 ms.
+//   phase IT:  gather item IT+1 (its slice landed a phase ago) | start the DMA of item IT+3's slice into the buffer item IT
+//   used (free since the barrier) | add item IT | request the entries of item IT+NSETS-1 | wait until this wave's DMA of
+//   item IT+2 has landed | barrier.
+// vmcnt retires in order: the wait lets the operations issued AFTER that DMA stay in flight (the entries requested behind
+// it a phase ago, this phase's DMA and entries), so the order "DMA, then entries" inside a phase is pinned.
+// The slice buffers are three separate LDS objects: the compiler tracks an LDS DMA per object and would otherwise make
+// every gather wait for the DMA still under way into another buffer.
+// Inside the loop every LDS access is written as inline assembly and the barrier is the bare s_barrier: the compiler makes
+// each LDS instruction it knows about wait for every LDS DMA under way (vmcnt(0) in front of every ds_add_f64, and again
+// before the barrier), which would end the prefetch of the entries as well -- vmcnt retires in order.  The waits are
+// placed by hand instead:
+//   before the barrier   vmcnt(n): this wave's DMA of item IT+2 has landed; the operations issued after it (the entries
+//                        requested behind it a phase ago, this phase's DMA and entries: n = 2 * loads per entry pair + 1)
+//                        stay in flight, so the order "DMA, then entries" inside a phase is pinned by scheduling barriers;
+//                        lgkmcnt(0): this wave's gathers have returned (their buffer is refilled next phase) .
+#ifndef FS_DMA_SETS
+#define FS_DMA_SETS 6
+#endif
+#ifndef FS_DMA_ADDS_LAST
+#define FS_DMA_ADDS_LAST 1
+#endif
+#ifndef FS_DMA_ABL
+#define FS_DMA_ABL 0   // ablation builds (timing only, results wrong): 1 no slice DMA, 3 no adds, 4 no gathers
+#endif
+constexpr int kLdsxDmaSets = FS_DMA_SETS;
+#define FS_WAIT_IMM(VM, LGKM) (((VM) & 0xF) | (0x7 << 4) | (((LGKM) & 0xF) << 8) | (((VM) >> 4) << 14))
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+template <bool VALUED, bool NT, int NSETS>
+__global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
+    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
+    const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
+    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int ys)
+{
+  static_assert(NSETS % 3 == 0, "the slice buffer of a phase is a compile-time constant");
+  static_assert(NSETS >= 4, "the sweep starts NSETS - 1 phases early and the DMA of an item is sent three phases before it");
+  __shared__ double ytile[kLdsxRows];
+  __shared__ __attribute__((aligned(16))) double xs0[kLdsxCols];
+  __shared__ __attribute__((aligned(16))) double xs1[kLdsxCols];
+  __shared__ __attribute__((aligned(16))) double xs2[kLdsxCols];
+  const int t = threadIdx.x;
+  const int cp = chunk_panel[blockIdx.x];
+  const int p = cp & 0x7fffffff;
+  const bool shared = cp < 0;
+  const int row0 = panel_row[p];
+  const int nr = panel_row[p + 1] - row0;
+  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
+  const unsigned cmask = (1u << lcol_bits) - 1u;
+  const int it0 = chunk_item[2 * blockIdx.x], it1 = chunk_item[2 * blockIdx.x + 1];
+  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
+  const int itf = it1 > it0 ? it0 : itl;
+  auto item = [&](int i) {
+    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
+    if (i < it0 || i >= it1) d.y = 0;
+    return d;
+  };
+  int4 dset[NSETS];
+  unsigned w[NSETS][2];
+  double v[NSETS][2];
+#pragma unroll
+  for (int k = 0; k < NSETS; ++k) {
+    dset[k] = item(it0 - 1);
+    w[k][0] = w[k][1] = 0;
+    v[k][0] = v[k][1] = 0.0;
+  }
+  double gcur[2] = {0.0, 0.0};
+  const int first = it0 - (NSETS - 1);
+  int4 dN = item(first + NSETS - 1);
+  int4 dS = item(first + 3);                      // descriptor of the item whose slice this phase sends for
+  const int wave_cols = 2 * (t & ~63);            // first column (inside the slice) of this wave's 1 KiB
+  const unsigned ybase = lds_addr(ytile);
+  const unsigned xbase[3] = {lds_addr(xs0), lds_addr(xs1), lds_addr(xs2)};
+  __syncthreads();
+  for (int it = first; it < it1; it += NSETS) {
+#pragma unroll
+    for (int ph = 0; ph < NSETS; ++ph) {
+      const int IT = it + ph;
+      const int s0 = ph, s1 = (ph + 1) % NSETS, sl = (ph + NSETS - 1) % NSETS;
+      dset[sl] = dN;
+      dN = item(IT + NSETS);
+      // buffers: item j lives in buffer (j - first) % 3; NSETS is a multiple of 3, so these are constants per unrolled phase
+      double *const bfree = ph % 3 == 0 ? xs0 : (ph % 3 == 1 ? xs1 : xs2);               // item IT's: refilled for IT+3
+      double gnew[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned a = xbase[(ph + 1) % 3] + ((w[s1][q] & cmask) << 3);                // item IT+1: gathered now
+        if (FS_DMA_ABL != 4) asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
+        else gnew[q] = 1.0;
+      }
+      {
+        const int c0 = dS.z * W + 2 * t;
+        const int cc = c0 + 1 < ncol ? c0 : ncol - 2;            // ncol is even and >= 2 here
+        if (FS_DMA_ABL != 1)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(x + cc),
+                                           (void __attribute__((address_space(3))) *)(bfree + wave_cols), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dS = item(IT + 4);
+#if FS_DMA_ADDS_LAST
+      // the gathers (and the descriptor loads) have returned: their buffer may be refilled once every wave is past the
+      // barrier.  The adds go out AFTER this wait and are not waited for: nothing but the end of the kernel reads the y slice,
+      // so they drain under the barrier and the next phase instead of holding it up
+      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(63, 0));
+      // the gathered values are written by the hardware some time after the ds_read was issued: tell the compiler they are
+      // live up to here, whatever uses them later, so that it can never hand their registers to something else in between
+      asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (2 * t + q < dset[s0].y) {
+          double pr = gcur[q];
+          if (VALUED) pr *= v[s0][q];
+          const unsigned a = ybase + ((w[s0][q] >> lcol_bits) << 3);
+          if (FS_DMA_ABL != 3) asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
+        }
+      }
+      // (the entries after the adds: requested right behind the DMA, 0.70 -> 0.74 ms -- memory instructions issued in a
+      // burst queue up in front of the address unit)
+      ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(VALUED ? 5 : 3, FS_DMA_ADDS_LAST ? 15 : 0));
+#if !FS_DMA_ADDS_LAST
+      asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));   // see above
+#endif
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      gcur[0] = gnew[0]; gcur[1] = gnew[1];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));
+  __syncthreads();
+  if (shared) {
+    for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
+  } else {
+    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // y = A x in two streaming passes (BinnedCsr in fs_common.h).  Same callers as the kernels above.
 //
@@ -1314,7 +1461,16 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
   hipLaunchKernelGGL((spmv_ldsx_pipe_kernel<V, N, X1, kLdsxPipeSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s,       \
                      T.panel_row, T.W, T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, \
                      out, xs, ost)
-      if (options().tiled_flags & 2) {             // bit 1: the first version (gather and add of an item in one phase)
+      // slices by LDS DMA: unit-stride x, 16-byte aligned, an even number of columns (bit 2 of tiled_flags turns it off)
+      if (!(options().tiled_flags & (2 | 4)) && xs == 1 && A.ncol >= 2 && (A.ncol & 1) == 0 &&
+          (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+#define FS_LDSXD(V, N)                                                                                              \
+  hipLaunchKernelGGL((spmv_ldsx_dma_kernel<V, N, kLdsxDmaSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
+                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, ost)
+        if (A.vals) { if (nt) FS_LDSXD(true, true); else FS_LDSXD(true, false); }
+        else        { if (nt) FS_LDSXD(false, true); else FS_LDSXD(false, false); }
+#undef FS_LDSXD
+      } else if (options().tiled_flags & 2) {      // bit 1: the first version (gather and add of an item in one phase)
         if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
         else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
       } else if (xs == 1 && A.ncol >= 2) {
