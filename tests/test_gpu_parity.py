@@ -729,6 +729,19 @@ def test_lds_staged_kernel_dense_tiles(hip, valued):
             capi.set_option("ldsx", 1)
         chosen.append(A.kernel_name())
         y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        # the three generations of the kernel on the same copy: slices by LDS DMA (default), through the registers
+        # (tiled_flags bit 2), the first version (bit 1); x 16-byte aligned (DMA) and 8 bytes off (falls back)
+        xpad = torch.zeros(ncol + 1, dtype=torch.float64, device="cuda")
+        xpad[1:] = torch.from_numpy(xs_).cuda()
+        for flags, xdev in ((0, torch.from_numpy(xs_).cuda()), (4, torch.from_numpy(xs_).cuda()), (2, torch.from_numpy(xs_).cuda()),
+                            (0, xpad[1:])):
+            capi.set_option("tiled_flags", flags)
+            try:
+                y.fill_(-1.0)
+                A.spmv(y, xdev, capi.current_stream())
+            finally:
+                capi.set_option("tiled_flags", 0)
+            assert np.all(np.abs(y.cpu().numpy() - ref_s) <= TOL * np.maximum(sc_s, 1e-300)), (chosen, flags)
         A.spmv(y, torch.from_numpy(xs_).cuda(), capi.current_stream())
         assert np.all(np.abs(y.cpu().numpy() - ref_s) <= TOL * np.maximum(sc_s, 1e-300)), chosen
         A.spmv(y, torch.from_numpy(xi_).cuda(), capi.current_stream())
