@@ -19,10 +19,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 
 Options &options()
 {
-  // FS_TILED_FLAGS: initial value of the option "tiled_flags" (A/B runs of bench.py, which sets no tuning switches)
+  // FS_TILED_FLAGS / FS_BIN_ROWS: initial values of the options "tiled_flags" / "bin_rows" (A/B runs of bench.py, which sets
+  // no tuning switches)
   static Options o = [] {
     Options q;
     if (const char *v = getenv("FS_TILED_FLAGS")) q.tiled_flags = atoi(v);
+    if (const char *v = getenv("FS_BIN_ROWS")) q.bin_rows = atoi(v);
     return q;
   }();
   return o;

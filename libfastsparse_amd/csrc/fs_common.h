@@ -105,6 +105,14 @@ constexpr int kBinBlock = 1024;        // threads per workgroup, both passes
 constexpr int kBinCols = 16384;        // columns per band: 128 KiB of x in LDS, one pass-1 workgroup per CU
 constexpr int kBinRowsMax = 16384;     // rows per panel: 128 KiB of y in LDS, one pass-2 workgroup per CU (measured equal to
                                        // 8192 rows x two workgroups; larger panels mean longer runs, less padding)
+// short runs (a power-law shard with a very wide x: config 5, 66 entries per run) pay 7.5 padding entries per run: such
+// matrices get bands and panels as large as LDS allows, 19 % fewer bands and panels, 29 % fewer runs (config-5 shard 2.84 ->
+// 2.72 ms; config 2, 344 entries per run, was measured 1 % slower with them and keeps the power-of-two sizes)
+constexpr int kBinColsBig = 19456, kBinRowsBig = 19456;   // 152 KiB of x / of y in LDS
+constexpr int kBinBigRunEntries = 192;                     // chosen below this many entries per run (single-vector copies)
+static_assert(kBinColsBig % 1024 == 0 && kBinColsBig < 65536, "band loads are 1024 threads wide; 16-bit local ids");
+static_assert(kBinCols % 1024 == 0 && kBinCols % 4 == 0 && kBinRowsMax % 4 == 0 && kBinCols < 65536 && kBinRowsMax <= 65536,
+              "band loads are 1024 threads wide; 16-bit local ids; k-column copies divide both by 2 and 4");
 constexpr int kBinGroupLog = 4;
 constexpr int kBinGroup = 1 << kBinGroupLog;  // entries per group = one 128-byte L2 line of products (runs that start on half
                                                // lines were measured 19 % slower in pass 1: 0.459 vs 0.386 ms)
@@ -115,6 +123,7 @@ struct BinnedCsr {
   int kw = 1;                  // right-hand sides one sweep serves: bands of kBinCols / kw columns (kw * 8 bytes of X per
                                // column in LDS), panels of at most kBinRowsMax / kw rows, groups of kBinGroup / kw entries
                                // (a group is always kBinGroup products = one 128-byte line)
+  int bcols = kBinCols;        // columns per band (kBinCols / kw, or kBinColsBig: see there)
   int B = 0, P = 0;            // bands, panels
   int64_t n = 0;               // padded entry count (multiple of kBinGroup)
   uint16_t *lcol = nullptr;    // n, pass-1 order: column - band*kBinCols; padding = kBinCols (a zero slot)

@@ -1161,7 +1161,12 @@ int build_binned_k(DeviceCsr &A, int kw, hipStream_t s)
 static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int kw)
 {
   const Options &o = options();
-  const int bcols = kBinCols / kw;     // columns per band: kw * 8 bytes of X per column, 128 KiB in LDS
+  // short runs: the large bands and panels (fs_common.h kBinColsBig).  FS_BIN_BIG=0 / 1 never / always (A/B runs)
+  static const int big_env = [] { const char *v = getenv("FS_BIN_BIG"); return v && *v ? atoi(v) : -1; }();
+  const double per_run = (double)A.nnz / ((double)((A.ncol + kBinCols - 1) / kBinCols) * (double)((A.nrow + kBinRowsMax - 1) / kBinRowsMax));
+  const bool big = kw == 1 && o.bin_rows == 0 && (big_env >= 0 ? big_env != 0 : per_run < kBinBigRunEntries);
+  const int bcols = big ? kBinColsBig : kBinCols / kw;   // columns per band: kw * 8 bytes of X per column in LDS
+  const int rmax = big ? kBinRowsBig : kBinRowsMax / kw; // rows per panel: kw * 8 bytes of Y per row in LDS
   const int ge = kBinGroup / kw;       // entries per group: a group of products is one 128-byte line
   if (o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz == 0) return FS_OK;
   // (measured on 10 M x 10 M x 16: 0.75 ms against 1.06 ms tiled and 2.99 ms streaming; the two passes move
@@ -1181,6 +1186,7 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   BinnedCsr *N = new BinnedCsr();
   slot = N;
   N->kw = kw;
+  N->bcols = bcols;
   N->split = virt ? split : 0;
   Scratch<int> vrow_ptr_own;
   const int *vrow_ptr = A.row_ptr;
@@ -1193,8 +1199,8 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
 
   // ---- panels of equal non-zero count, at most R rows: pass 2 runs one workgroup per panel and they all
   // have to finish together; the count is a whole number of generations of resident workgroups -----------
-  int R = o.bin_rows > 0 ? o.bin_rows : kBinRowsMax / kw;
-  if (R > kBinRowsMax / kw) R = kBinRowsMax / kw;   // kw * 8 bytes of Y per row in LDS
+  int R = o.bin_rows > 0 ? o.bin_rows : rmax;
+  if (R > rmax) R = rmax;
   std::vector<int> vp((size_t)nvrow + 1);
   FS_HIP(hipMemcpyAsync(vp.data(), vrow_ptr, sizeof(int) * vp.size(), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
@@ -1280,7 +1286,7 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   if (o.binning == 1 && kw == 1) {
     // two streaming passes (measured 4.6-5.0 TB/s) against what the other kernels reach on this shape
     const double x_bytes = (double)A.ncol * 8;
-    const double t_bin = ((double)N->n * (A.vals ? 28.5 : 20.5) + (double)(B + ncu) * kBinCols * 8 + (double)nvrow * 8) / 4.6e12;
+    const double t_bin = ((double)N->n * (A.vals ? 28.5 : 20.5) + (double)(B + ncu) * bcols * 8 + (double)nvrow * 8) / 4.6e12;
     const double t_stream = (double)A.nnz / (x_bytes <= (3 << 20) ? 172e9 : 53e9);
     if (t_bin > 0.95 * t_stream) return FS_OK;   // hopeless; between the survivors choose_copy measures
   }

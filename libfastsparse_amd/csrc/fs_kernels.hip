@@ -1095,13 +1095,13 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // pass 1: persistent workgroups, one per CU; workgroup w streams the w-th equal share of the (band, panel)-ordered
 // groups and reloads its x band when the share crosses into the next band (every band is loaded once, plus once
 // per share boundary: cutting bands into many small workgroups instead re-reads x several times over)
-template <bool VALUED, int U, bool NTLD, bool NTST>
+template <bool VALUED, int U, bool NTLD, bool NTST, int BC = kBinCols>
 __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
     int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
     const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
     double *__restrict__ prod, unsigned gbeg, unsigned gend)
 {
-  __shared__ double xband[kBinCols + 8];   // slot kBinCols is the zero the padding entries point at
+  __shared__ double xband[BC + 8];         // slot BC is the zero the padding entries point at
   const int t = threadIdx.x;
   // this launch covers the groups gbeg .. gend (everything, or the bands whose part of x has arrived: fs_spmv_host)
   const uint64_t groups = gend - gbeg;
@@ -1120,24 +1120,24 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
   for (unsigned g = g0; g < g1; ++b) {
     const unsigned gb = band_ptr[b + 1] < g1 ? band_ptr[b + 1] : g1;   // end of this band's part of the share
     if (gb <= g) continue;                                               // empty band
-    const int c0 = b * kBinCols;
-    const int w = (ncol - c0 < kBinCols) ? ncol - c0 : kBinCols;
+    const int c0 = b * BC;
+    const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
     __syncthreads();                                                     // everyone is done with the previous band
     {
       // 16 loads per thread in flight together (clamped addresses, masking afterwards: a select next to the load
-      // would make every one of them wait for itself); slots kBinCols .. kBinCols+7 are the zero padding points at
-      double r[kBinCols / kBinBlock];
+      // would make every one of them wait for itself); slots BC .. BC+7 are the zero padding points at
+      double r[BC / kBinBlock];
 #pragma unroll
-      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+      for (int j = 0; j < BC / kBinBlock; ++j) {
         const int i = j * kBinBlock + t;
         r[j] = __builtin_nontemporal_load(x + (int64_t)(c0 + (i < w ? i : w - 1)) * xs);
       }
 #pragma unroll
-      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+      for (int j = 0; j < BC / kBinBlock; ++j) {
         const int i = j * kBinBlock + t;
         xband[i] = (i < w) ? r[j] : 0.0;
       }
-      if (t < 8) xband[kBinCols + t] = 0.0;
+      if (t < 8) xband[BC + t] = 0.0;
     }
     __syncthreads();
     const int64_t e0 = (int64_t)g * kBinGroup, e1 = (int64_t)gb * kBinGroup;
@@ -1181,12 +1181,12 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
 }
 
 // pass 2: workgroup = one row panel; its products are contiguous
-template <bool NTLD>
+template <bool NTLD, int RM = kBinRowsMax>
 __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
     const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
     const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
 {
-  __shared__ double ytile[kBinRowsMax];
+  __shared__ double ytile[RM];
   const int t = threadIdx.x;
   const int panel = pbase + blockIdx.x;
   const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
@@ -1526,13 +1526,24 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
 #define FS_EXPAND(V, U, NL, NS)                                                                                    \
   hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
                      N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog))
+    if (N.bcols == kBinColsBig) {                // the large-band copy: default switches only
+      if (A.vals)
+        hipLaunchKernelGGL((spmv_expand_kernel<true, 4, false, true, kBinColsBig>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B,
+                           N.band_ptr, N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog));
+      else
+        hipLaunchKernelGGL((spmv_expand_kernel<false, 4, false, true, kBinColsBig>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B,
+                           N.band_ptr, N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog));
+    } else
     if (A.vals) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
     else        { if ((flags & 3) == 1) FS_EXPAND4(false, 8); else if ((flags & 3) == 2) FS_EXPAND4(false, 2); else FS_EXPAND4(false, 4); }
 #undef FS_EXPAND4
 #undef FS_EXPAND
     FS_HIP(hipGetLastError());
   }
-  if (options().bin_flags & 4)
+  if (N.bcols == kBinColsBig)
+    hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow,
+                       N.prod, out, os, 0);
+  else if (options().bin_flags & 4)
     hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, 0);
   else
     hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, 0);
@@ -1873,8 +1884,8 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
   const int c1 = want_chunks < N.B ? want_chunks : N.B;
   for (int j = 0; j < c1; ++j) {
     const int b0 = (int)((int64_t)N.B * j / c1), b1 = (int)((int64_t)N.B * (j + 1) / c1);
-    const int64_t x0 = (int64_t)b0 * kBinCols;
-    int64_t x1 = (int64_t)b1 * kBinCols;
+    const int64_t x0 = (int64_t)b0 * N.bcols;
+    int64_t x1 = (int64_t)b1 * N.bcols;
     if (x1 > A.ncol || j == c1 - 1) x1 = A.ncol;
     if (x1 > x0) FS_HIP(hipMemcpy(H.sx + x0, x_host + x0, sizeof(double) * (size_t)(x1 - x0), hipMemcpyHostToDevice));
     const unsigned g0 = N.h_band_ptr[b0], g1 = N.h_band_ptr[b1];
@@ -1883,20 +1894,24 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
     int wgs = nwg1;
     const int64_t cap = ((int64_t)(g1 - g0) * kBinGroup + kBinShareMin - 1) / kBinShareMin;
     if (cap < wgs) wgs = (int)(cap < 1 ? 1 : cap);
-    if (A.vals)
-      hipLaunchKernelGGL((spmv_expand_kernel<true, 4, false, true>), dim3(wgs), dim3(kBinBlock), 0, H.stream, A.ncol, N.B,
-                         N.band_ptr, N.lcol, N.vals, N.gdst, H.sx, 1, N.prod, g0, g1);
-    else
-      hipLaunchKernelGGL((spmv_expand_kernel<false, 4, false, true>), dim3(wgs), dim3(kBinBlock), 0, H.stream, A.ncol, N.B,
-                         N.band_ptr, N.lcol, N.vals, N.gdst, H.sx, 1, N.prod, g0, g1);
+#define FS_XH(V, BC)                                                                                                    \
+  hipLaunchKernelGGL((spmv_expand_kernel<V, 4, false, true, BC>), dim3(wgs), dim3(kBinBlock), 0, H.stream, A.ncol, N.B, \
+                     N.band_ptr, N.lcol, N.vals, N.gdst, H.sx, 1, N.prod, g0, g1)
+    if (N.bcols == kBinColsBig) { if (A.vals) FS_XH(true, kBinColsBig); else FS_XH(false, kBinColsBig); }
+    else                        { if (A.vals) FS_XH(true, kBinCols); else FS_XH(false, kBinCols); }
+#undef FS_XH
     FS_HIP(hipGetLastError());
   }
   // pass 2, panel range by panel range, an event behind each
   const int c2 = want_chunks < N.P ? want_chunks : N.P;
   for (int j = 0; j < c2; ++j) {
     const int p0 = (int)((int64_t)N.P * j / c2), p1 = (int)((int64_t)N.P * (j + 1) / c2);
-    hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, H.stream, N.bin_ptr, N.panel_row, N.lrow,
-                       N.prod, H.sy, 1, p0);
+    if (N.bcols == kBinColsBig)
+      hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, H.stream, N.bin_ptr,
+                         N.panel_row, N.lrow, N.prod, H.sy, 1, p0);
+    else
+      hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, H.stream, N.bin_ptr, N.panel_row, N.lrow,
+                         N.prod, H.sy, 1, p0);
     FS_HIP(hipGetLastError());
     FS_HIP(hipEventRecord(H.ev[j], H.stream));
   }
