@@ -179,6 +179,23 @@ class HipProvider:
         A.spmv(y, x, self.stream(), transposed=transposed)
 
 
+def in_turns(fn, prov, world, rank, nccl):
+    """fn() on every rank -- one rank after the other when the ranks SHARE one GPU (the gloo rehearsal): the radix sorts of the
+    format builders and of torch wait for other workgroups of their own grid (decoupled look-back), and several processes
+    time-sliced on one card were seen to starve each other there for ever (GPU 100 % busy, no memory traffic).  One process
+    per GPU, the real thing, has the card to itself."""
+    if nccl or world == 1 or getattr(prov, "name", "") != "hip":
+        return fn()
+    import torch.distributed as dist
+    out = None
+    for r in range(world):
+        if r == rank:
+            out = fn()
+            prov.synchronize()
+        dist.barrier()
+    return out
+
+
 def timed_steps(prov, step, drain, steps, warmup, world, backend_is_nccl):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks (seconds)"""
     import torch
@@ -427,8 +444,11 @@ def run_c2(args, prov, world, rank, nccl):
 
     # ---- this rank's shard: rows lo .. lo+n_local of the (N*10M) x 10M matrix ------------------------
     rp, cc, vv = capi.synth_uniform(n_local, ncol, per, SEED_C2, row_offset=lo)
-    A = capi.Matrix.from_csr(n_local, ncol, rp, cc, vv, borrow=True)
-    A.build_transpose(st)
+    def build():
+        M = capi.Matrix.from_csr(n_local, ncol, rp, cc, vv, borrow=True)
+        M.build_transpose(st)
+        return M
+    A = in_turns(build, prov, world, rank, nccl)
     bounds = fsd.even_row_partition(n_global, world)
     bytes_a = A.algorithmic_bytes()
     bytes_t = csr_bytes(n_local * per, ncol, n_local)   # same entries, nrow and ncol swap roles
@@ -810,7 +830,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     lo, hi = bounds[mine], bounds[mine + 1]
     rp, cc, vv, nnz = c5_shard(prov, lo, hi, ncol)
     n_local = hi - lo
-    A = prov.csr(n_local, ncol, rp, cc, vv)
+    A = in_turns(lambda: prov.csr(n_local, ncol, rp, cc, vv), prov, world, rank, nccl)
     bytes_local = csr_bytes(nnz, n_local, ncol)
 
     x = prov.sin_vector(ncol, 7.0, 0.3)
@@ -829,7 +849,8 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         try:
             cb = fsd.even_row_partition(ncol, world)
             tr, tc, tv = fsd.build_transposed_shard(rp, cc, vv, lo, cb)
-            At = prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), tv)
+            At = in_turns(lambda: prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), tv),
+                          prov, world, rank, nccl)
             del tr, tc, tv
             opt = fsd.TransposedGatherOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb)
             u = prov.sin_vector(n_global, 11.0, -0.2)
@@ -984,6 +1005,9 @@ def main():
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run "
                              "--nproc-per-node %d) or drop the launcher and let bench.py start them" % (args.gpus, world, args.gpus))
 
+    if os.environ.get("FS_BENCH_WATCHDOG"):     # seconds: every rank then dumps its Python stacks to stderr (a hung collective)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FS_BENCH_WATCHDOG"]), repeat=False)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():

@@ -249,9 +249,24 @@ def exchange_transpose_entries(rows_global, cols_global, vals, col_bounds, group
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     bounds_t = torch.tensor(col_bounds[1:-1], dtype=cols_global.dtype, device=cols_global.device)
-    dest = torch.bucketize(cols_global, bounds_t, right=True)
-    order = torch.sort(dest, stable=True).indices
-    send_counts = torch.bincount(dest, minlength=world).to(torch.int64)
+
+    def local_part():
+        d = torch.bucketize(cols_global, bounds_t, right=True)
+        # `world` distinct keys: one byte each sorts in a fraction of the time of int64 keys (a stable partition)
+        o = torch.sort(d.to(torch.uint8) if world <= 255 else d, stable=True).indices
+        return d, o, torch.bincount(d, minlength=world).to(torch.int64)
+
+    if world > 1 and _host_collective(cols_global, group):
+        # ranks sharing ONE GPU (gloo rehearsal): one after the other -- the device sorts of several processes time-sliced
+        # on one card were seen to starve each other for ever (see bench.py in_turns)
+        dest = order = send_counts = None
+        for r in range(world):
+            if r == rank:
+                dest, order, send_counts = local_part()
+                torch.cuda.synchronize()
+            dist.barrier(group)
+    else:
+        dest, order, send_counts = local_part()
     lo = col_bounds[rank]
     if world == 1:
         return (cols_global[order] - lo), rows_global[order], (None if vals is None else vals[order])
