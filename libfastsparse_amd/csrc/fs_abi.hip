@@ -19,12 +19,13 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 
 Options &options()
 {
-  // FS_TILED_FLAGS / FS_BIN_ROWS: initial values of the options "tiled_flags" / "bin_rows" (A/B runs of bench.py, which sets
+  // FS_TILED_FLAGS / FS_BIN_ROWS / FS_TILE_COLS: initial values of the options "tiled_flags" / "bin_rows" / "tile_cols" (A/B runs of bench.py, which sets
   // no tuning switches)
   static Options o = [] {
     Options q;
     if (const char *v = getenv("FS_TILED_FLAGS")) q.tiled_flags = atoi(v);
     if (const char *v = getenv("FS_BIN_ROWS")) q.bin_rows = atoi(v);
+    if (const char *v = getenv("FS_TILE_COLS")) q.tile_cols = atoi(v);
     return q;
   }();
   return o;

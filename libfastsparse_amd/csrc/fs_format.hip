@@ -881,7 +881,9 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   const int w_max = ldsx ? kLdsxCols : (1 << kTiledColBits);
   int W = o.tile_cols;
   if (W <= 0) {
-    double w = (ldsx ? 0.85 : 0.9) * kTiledItem * (double)A.ncol * P / (double)A.nnz;
+    // (LDS-staged: 0.95 -- a slice costs its 16 KiB whatever the tile holds; config 3 transposed 0.777 -> 0.752 ms with
+    // 2048-column slices instead of the 1904 that 0.85 gave, 1800 / 1600: 0.80 / 0.86)
+    double w = (ldsx ? 0.95 : 0.9) * kTiledItem * (double)A.ncol * P / (double)A.nnz;
     if (w < (ldsx ? 256 : 4096)) w = ldsx ? 256 : 4096;
     if (w > w_max) w = w_max;
     W = (int)w;
