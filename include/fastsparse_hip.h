@@ -69,8 +69,9 @@ int  fs_set_device(int device);
  * Threads and streams: every entry point may be called from several host threads; launches on one handle are serialised by
  * a lock.  A handle keeps scratch vectors for some kernels (rows that cross chunks in the streaming kernel, sums of cut rows in
  * the tiled kernel, the products of the two-pass kernels for k = 1 and for the k-column sweeps k = 2..4, the cell sums of a
- * column-blocked matrix), so products on ONE handle must not overlap in time on different streams: order them, or use one
- * handle per stream.  Only the row kernel (multi-column products with k >= 5, or option "spmm_kernel" = 1) and distinct handles
+ * column-blocked matrix, the column-major copies of X and Y of multi-column products on the LDS-staged copy, k = 2..12), so
+ * products on ONE handle must not overlap in time on different streams: order them, or use one handle per stream.  Only the
+ * row kernel (option "spmm_kernel" = 1; k >= 5 on matrices that keep the two-pass copy, k > 12 otherwise) and distinct handles
  * are unrestricted.
  * "spmm_kernel" (multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep for k = 2..4, 3 one single-vector sweep
  * per column, 4 the v_mfma_f64_16x16x4_f64 experiment), "ata_kernel" (fs_ata_mul: 0 two products, 2 the fused single kernel),

@@ -42,6 +42,9 @@ struct DeviceCsr {
   // built on the first multi-column product that can use them (launch_spmm); `tried` = the builder declined once
   BinnedCsr *binned2 = nullptr, *binned4 = nullptr;
   bool tried2 = false, tried4 = false;
+  // multi-column products of a matrix on the LDS-staged copy: X and Y column-major in here, one unit-stride sweep per column
+  double *spmm_scratch = nullptr;
+  size_t spmm_scratch_doubles = 0;
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};

@@ -165,6 +165,7 @@ void free_csr(DeviceCsr &A)
   free_binned(A);
   free_binned_slot(A.binned2);
   free_binned_slot(A.binned4);
+  if (A.spmm_scratch) { (void)traced_free(A.spmm_scratch); A.spmm_scratch = nullptr; A.spmm_scratch_doubles = 0; }
   A = DeviceCsr();
 }
 

@@ -1924,6 +1924,27 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
   return FS_OK;
 }
 
+// row-major n x k  <->  k columns of `ld` doubles each (column-major)
+__global__ __launch_bounds__(kBlock) void rows_to_columns_kernel(int64_t n, int k, int64_t ld, const double *__restrict__ rm,
+                                                                 double *__restrict__ cm)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int j = 0; j < k; ++j) cm[(int64_t)j * ld + i] = rm[i * k + j];
+}
+
+__global__ __launch_bounds__(kBlock) void columns_to_rows_kernel(int64_t n, int k, int64_t ld, const double *__restrict__ cm,
+                                                                 double *__restrict__ rm)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int j = 0; j < k; ++j) rm[i * k + j] = cm[(int64_t)j * ld + i];
+}
+
+// multi-column products on the LDS-staged copy: one sweep per column up to this k (config 3's shape: 0.77 ms per column
+// against a row kernel that takes 12.5 ms for any k from 4 to 16 -- it is bound by the rate of its X-row gathers -- and 22 at 32)
+constexpr int kLdsxSweepMaxK = 12;
+
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
@@ -1957,6 +1978,32 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
   if (want != 1 && (k <= 3 || want == 3) && A.binned && A.binned->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) {
     for (int j = 0; j < k; ++j)
       if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
+    return FS_OK;
+  }
+  // A matrix on the LDS-staged copy (dense tiles: config 3's class, bsbm_A_mul_B2 / _B4 / _Bn on a tall binary matrix): one
+  // sweep per column, but on COLUMN-major copies of X and Y so that every sweep is the unit-stride kernel with its slices by
+  // LDS DMA (config 3's shape, k = 2 / 4 / 8: 2.1 / 12.1 / 12.4 ms with strided sweeps and the row kernel; two transposes
+  // cost k * 16 bytes per row and column)
+  if (want != 1 && want != 4 && k >= 2 && k <= kLdsxSweepMaxK && A.tiledx && A.tiledx->built && !(A.binned && A.binned->built) &&
+      free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) {
+    const int64_t ldx = ((int64_t)A.ncol + 1) & ~(int64_t)1, ldy = ((int64_t)A.nrow + 1) & ~(int64_t)1;   // 16-byte aligned columns
+    const size_t need = (size_t)k * (size_t)(ldx + ldy);
+    if (A.spmm_scratch_doubles < need) {
+      if (A.spmm_scratch) FS_HIP(hipFree(A.spmm_scratch));
+      A.spmm_scratch = nullptr; A.spmm_scratch_doubles = 0;
+      FS_HIP(hipMalloc(&A.spmm_scratch, sizeof(double) * need));
+      A.spmm_scratch_doubles = need;
+    }
+    double *xt = A.spmm_scratch, *yt = A.spmm_scratch + (size_t)k * (size_t)ldx;
+    if (A.ncol > 0)
+      hipLaunchKernelGGL(rows_to_columns_kernel, dim3((unsigned)(((int64_t)A.ncol + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                         (int64_t)A.ncol, k, ldx, X, xt);
+    FS_HIP(hipGetLastError());
+    for (int j = 0; j < k; ++j)
+      if (int rc = launch_spmv_tiled(A, *A.tiledx, yt + (int64_t)j * ldy, xt + (int64_t)j * ldx, s, 1, 1)) return rc;
+    hipLaunchKernelGGL(columns_to_rows_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       (int64_t)A.nrow, k, ldy, yt, Y);
+    FS_HIP(hipGetLastError());
     return FS_OK;
   }
   if (want != 1 && k <= 2 && A.tiledx && A.tiledx->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) {

@@ -353,6 +353,21 @@ def main():
             report(out, f"c2_spmm_k{k}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
             del X, Y
         del A, rp, cc, vv
+    if "c3spmm" in what:
+        # multi-column products on config 3's shape (bsbm_A_mul_B2 / _B4 / _Bn on a tall binary matrix, bsbm_cg2's products)
+        nrow, ncol = n, max(n // 10, 1)
+        rp, cc, _ = capi.synth_uniform(nrow, ncol, 64, 0x5EED0003, valued=False)
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None, borrow=True)
+        for k in (1, 2, 4, 8, 16, 32):
+            X = torch.sin(torch.arange(ncol * k, device="cuda", dtype=torch.float64)).reshape(ncol, k)
+            Y = torch.empty(nrow, k, dtype=torch.float64, device="cuda")
+            report(out, f"c3_spmm_k{k}:{A.kernel_name()}", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
+            if k >= 8:
+                capi.set_option("spmm_kernel", 1)
+                report(out, f"c3_spmm_k{k}:row_kernel", A.algorithmic_bytes(k), timeit(lambda: A.spmm(Y, X, k, st), iters=3, warm=1))
+                capi.set_option("spmm_kernel", 0)
+            del X, Y
+        del A, rp, cc
     if "build" in what:
         # new_bcsr on config 3's 640 M COO entries, host loop against the device build (upload + stable
         # sort + download), host arrays in and out either way
