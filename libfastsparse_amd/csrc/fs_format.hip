@@ -897,8 +897,9 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   if (mode == 1 && ldsx) {
     // every tile costs one barrier phase and one slice of x from L2: worth it only when the tiles are reasonably
     // full (config 3, 10 M x 1 M x 64 per row: 1 700 entries per tile; config 2: 43).  Beyond that the choice is
-    // measured (choose_copy).
-    if ((double)A.nnz / ntiles < 600.0) return FS_OK;
+    // measured (choose_copy).  With the DMA kernel the crossover against the L2-tiled kernel lies near 500 entries per
+    // tile (10 M rows x 16: 786 K columns, 543 per tile: 0.64 against 0.71 ms; 1 M columns, 407: 0.79 against 0.74)
+    if ((double)A.nnz / ntiles < 450.0) return FS_OK;
   }
   if (mode == 1 && !ldsx) {
     // tiles must not be hopelessly thin, and re-reading x once per generation of resident workgroups must
