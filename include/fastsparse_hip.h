@@ -69,9 +69,9 @@ int  fs_set_device(int device);
  * Threads and streams: every entry point may be called from several host threads; launches on one handle are serialised by
  * a lock.  A handle keeps scratch vectors for some kernels (rows that cross chunks in the streaming kernel, sums of cut rows in
  * the tiled kernel, the products of the two-pass kernels for k = 1 and for the k-column sweeps k = 2..4, the cell sums of a
- * column-blocked matrix, the column-major copies of X and Y of multi-column products on the LDS-staged copy, k = 2..12), so
+ * column-blocked matrix, the column-major copies of X and Y of multi-column products on the LDS-staged copy, k = 2..16), so
  * products on ONE handle must not overlap in time on different streams: order them, or use one handle per stream.  Only the
- * row kernel (option "spmm_kernel" = 1; k >= 5 on matrices that keep the two-pass copy, k > 12 otherwise) and distinct handles
+ * row kernel (option "spmm_kernel" = 1; k >= 5 on matrices that keep the two-pass copy, k > 16 otherwise) and distinct handles
  * are unrestricted.
  * "spmm_kernel" (multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep for k = 2..4, 3 one single-vector sweep
  * per column, 4 the v_mfma_f64_16x16x4_f64 experiment), "ata_kernel" (fs_ata_mul: 0 two products, 2 the fused single kernel),
@@ -125,7 +125,9 @@ int  fs_matrix_download(fs_matrix_t A, int transposed, int *row_ptr, int *cols, 
 int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
 /* y[ncol] = A' x[nrow]          (At_mul_B / sdm_At_mul_B; CSR At_mul_B of BASELINE config 2) */
 int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
-/* Y[nrow,k] = A X[ncol,k], X and Y row-major  (csr_A_mul_Bn, bcsr_A_mul_B2..._B32n, bsbm_A_mul_B2/_B4/_Bn) */
+/* Y[nrow,k] = A X[ncol,k], X and Y row-major  (csr_A_mul_Bn, bcsr_A_mul_B2..._B32n, bsbm_A_mul_B2/_B4/_Bn).
+ * On a matrix that keeps the LDS-staged copy the FIRST product with a given k (3..16) runs twice -- one sweep per column and
+ * the row kernel -- and waits for both: the faster one serves that k from then on (FS_TRACE_BUILD prints the two times). */
 int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
 int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
 /* y[ncol] = A'A x[ncol]; tmp is caller scratch of nrow doubles in HBM   (bcsr_AA_mul_B, parallel_bcsr_AA_mul_B) */

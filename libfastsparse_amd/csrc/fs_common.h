@@ -45,6 +45,7 @@ struct DeviceCsr {
   // multi-column products of a matrix on the LDS-staged copy: X and Y column-major in here, one unit-stride sweep per column
   double *spmm_scratch = nullptr;
   size_t spmm_scratch_doubles = 0;
+  signed char spmm_choice[17] = {};   // per k: 0 not measured yet, 1 one sweep per column, 2 the row kernel (timed on first use)
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};

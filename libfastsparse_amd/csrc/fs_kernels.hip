@@ -1941,9 +1941,11 @@ __global__ __launch_bounds__(kBlock) void columns_to_rows_kernel(int64_t n, int 
   for (int j = 0; j < k; ++j) rm[i * k + j] = cm[(int64_t)j * ld + i];
 }
 
-// multi-column products on the LDS-staged copy: one sweep per column up to this k (config 3's shape: 0.77 ms per column
-// against a row kernel that takes 12.5 ms for any k from 4 to 16 -- it is bound by the rate of its X-row gathers -- and 22 at 32)
-constexpr int kLdsxSweepMaxK = 12;
+// multi-column products on the LDS-staged copy: one sweep per column OR the row kernel, whichever the first product with
+// that k measures faster on this matrix.  Neither wins everywhere: config 3's shape (64 per row, X of 1 M rows) 0.77 ms per
+// column against a row kernel that takes 12.5 ms for any k from 4 to 16 (bound by the rate of its X-row gathers, 51 G/s once
+// X is larger than L2); 10 M rows x 16 with X of 131 K rows, k = 8: 3.5 ms in sweeps, 2.05 ms on the row kernel (X in L2).
+constexpr int kLdsxSweepMaxK = 16;
 
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
@@ -1984,8 +1986,16 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
   // sweep per column, but on COLUMN-major copies of X and Y so that every sweep is the unit-stride kernel with its slices by
   // LDS DMA (config 3's shape, k = 2 / 4 / 8: 2.1 / 12.1 / 12.4 ms with strided sweeps and the row kernel; two transposes
   // cost k * 16 bytes per row and column)
+  bool time_both = false;
+  if (want == 0 && k >= 3 && k <= kLdsxSweepMaxK && A.tiledx && A.tiledx->built && !(A.binned && A.binned->built) && free_order &&
+      (o.spmv_kernel == 0 || o.spmv_kernel == 8) && A.spmm_choice[k] == 0)
+    time_both = true;                             // k = 2: the sweeps won every measurement
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  if (time_both)
+    for (hipEvent_t &e : ev) FS_HIP(hipEventCreate(&e));
+  if (time_both) FS_HIP(hipEventRecord(ev[0], s));
   if (want != 1 && want != 4 && k >= 2 && k <= kLdsxSweepMaxK && A.tiledx && A.tiledx->built && !(A.binned && A.binned->built) &&
-      free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) {
+      free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8) && (want != 0 || k == 2 || A.spmm_choice[k] != 2)) {
     const int64_t ldx = ((int64_t)A.ncol + 1) & ~(int64_t)1, ldy = ((int64_t)A.nrow + 1) & ~(int64_t)1;   // 16-byte aligned columns
     const size_t need = (size_t)k * (size_t)(ldx + ldy);
     if (A.spmm_scratch_doubles < need) {
@@ -2004,7 +2014,8 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
     hipLaunchKernelGGL(columns_to_rows_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                        (int64_t)A.nrow, k, ldy, yt, Y);
     FS_HIP(hipGetLastError());
-    return FS_OK;
+    if (!time_both) return FS_OK;
+    FS_HIP(hipEventRecord(ev[1], s));             // ... and the row kernel below writes the same Y once more
   }
   if (want != 1 && k <= 2 && A.tiledx && A.tiledx->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) {
     for (int j = 0; j < k; ++j)
@@ -2038,6 +2049,19 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 #undef FS_SPMM_LG
 #undef FS_SPMM
   FS_HIP(hipGetLastError());
+  if (time_both) {
+    FS_HIP(hipEventRecord(ev[2], s));
+    FS_HIP(hipEventSynchronize(ev[2]));
+    float t_sweeps = 0.f, t_row = 0.f;
+    FS_HIP(hipEventElapsedTime(&t_sweeps, ev[0], ev[1]));
+    FS_HIP(hipEventElapsedTime(&t_row, ev[1], ev[2]));
+    A.spmm_choice[k] = t_sweeps <= t_row ? 1 : 2;
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
+    if (trace)
+      fprintf(stderr, "[fastsparse] %d x %d, k = %d: one sweep per column %.2f ms, row kernel %.2f ms\n", A.nrow, A.ncol, k,
+              t_sweeps, t_row);
+  }
   return FS_OK;
 }
 

@@ -344,6 +344,21 @@ def main():
                 report(out, f"c2rows_ncol{ncol}_{label}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st), iters=10))
             capi.set_option("spmv_kernel", 0)
             del A, rp, cc, vv
+    if "colsspmm" in what:
+        # multi-column products as x shrinks: one sweep per column (LDS-staged copy) against the row kernel
+        for ncol in (args.ncols or (131072, 262144, 524288, 786432)):
+            rp, cc, vv = capi.synth_uniform(n, ncol, 16, 0x5EED0002)
+            A = capi.Matrix.from_csr(n, ncol, rp, cc, vv, borrow=True)
+            for k in (2, 4, 8):
+                X = torch.sin(torch.arange(ncol * k, device="cuda", dtype=torch.float64)).reshape(ncol, k)
+                Y = torch.empty(n, k, dtype=torch.float64, device="cuda")
+                for sk, label in ((0, "auto"), (1, "row_kernel")):
+                    capi.set_option("spmm_kernel", sk)
+                    report(out, f"c2rows_ncol{ncol}_{A.kernel_name()}_spmm_k{k}_{label}", A.algorithmic_bytes(k),
+                           timeit(lambda: A.spmm(Y, X, k, st), iters=5, warm=1))
+                capi.set_option("spmm_kernel", 0)
+                del X, Y
+            del A, rp, cc, vv
     if "spmm" in what:
         rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
         A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
