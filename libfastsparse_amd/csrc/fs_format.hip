@@ -780,6 +780,31 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
   }
 }
 
+// how many column bands of W columns do the entries of panel (blockIdx.x * stride) touch?  out[2b] = bands, out[2b + 1] = entries
+constexpr int kPanelBandWords = 8192;    // 262 144 bands: 32 KiB of LDS
+__global__ __launch_bounds__(256) void panel_bands_kernel(int stride, int W, int words, const int *__restrict__ panel_row,
+                                                          const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                          int *__restrict__ out)
+{
+  __shared__ unsigned bits[kPanelBandWords];
+  __shared__ int total;
+  const int p = blockIdx.x * stride, t = threadIdx.x;
+  for (int i = t; i < words; i += 256) bits[i] = 0u;
+  if (t == 0) total = 0;
+  __syncthreads();
+  const int64_t e0 = row_ptr[panel_row[p]], e1 = row_ptr[panel_row[p + 1]];
+  for (int64_t e = e0 + t; e < e1; e += 256) {
+    const int b = cols[e] / W;
+    atomicOr(&bits[b >> 5], 1u << (b & 31));
+  }
+  __syncthreads();
+  int c = 0;
+  for (int i = t; i < words; i += 256) c += __popc(bits[i]);
+  atomicAdd(&total, c);
+  __syncthreads();
+  if (t == 0) { out[2 * blockIdx.x] = total; out[2 * blockIdx.x + 1] = (int)(e1 - e0); }
+}
+
 static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool ldsx);
 
 // The tiled copies are optimisations: if building one fails (typically: not enough HBM for another copy) the
@@ -899,7 +924,26 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     // full (config 3, 10 M x 1 M x 64 per row: 1 700 entries per tile; config 2: 43).  Beyond that the choice is
     // measured (choose_copy).  With the DMA kernel the crossover against the L2-tiled kernel lies near 500 entries per
     // tile (10 M rows x 16: 786 K columns, 543 per tile: 0.64 against 0.71 ms; 1 M columns, 407: 0.79 against 0.74)
-    if ((double)A.nnz / ntiles < 450.0) return FS_OK;
+    // Structured matrices (banded, block-diagonal: x close to the diagonal) fill few of a panel's tiles, and those densely:
+    // count the bands a sample of panels really touches before giving up on the average over ALL tiles
+    if ((double)A.nnz / ntiles < 450.0) {
+      constexpr int kSample = 64;
+      const int words = (J + 31) / 32;
+      if (words > kPanelBandWords || P < 1) return FS_OK;
+      const int ns = P < kSample ? P : kSample, stride = P / ns;
+      Scratch<int> prow, cnt;
+      FS_HIP(prow.alloc(panel_row.size()));
+      FS_HIP(cnt.alloc(2 * (size_t)ns));
+      FS_HIP(hipMemcpyAsync(prow.p, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(panel_bands_kernel, dim3(ns), dim3(256), 0, s, stride, W, words, prow.p, vrow_ptr, A.cols, cnt.p);
+      FS_HIP(hipGetLastError());
+      std::vector<int> hc(2 * (size_t)ns);
+      FS_HIP(hipMemcpyAsync(hc.data(), cnt.p, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, s));
+      FS_HIP(hipStreamSynchronize(s));
+      double tiles = 0, entries = 0;
+      for (int i = 0; i < ns; ++i) { tiles += hc[2 * i]; entries += hc[2 * i + 1]; }
+      if (tiles < 1 || entries / tiles < 450.0) return FS_OK;
+    }
   }
   if (mode == 1 && !ldsx) {
     // tiles must not be hopelessly thin, and re-reading x once per generation of resident workgroups must

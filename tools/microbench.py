@@ -359,6 +359,21 @@ def main():
                 capi.set_option("spmm_kernel", 0)
                 del X, Y
             del A, rp, cc, vv
+    if "banded" in what:
+        # structured columns (FEM / stencil like): 16 per row within +-w of the diagonal; which kernel does the builder keep, how fast
+        for w in (1000, 100000):
+            rows = torch.arange(n, device="cuda", dtype=torch.int64).repeat_interleave(16)
+            cc = (rows + torch.randint(-w, w + 1, (n * 16,), device="cuda")).clamp_(0, n - 1)
+            cc = cc.view(n, 16).sort(dim=1).values.reshape(-1).to(torch.int32)
+            rp = (torch.arange(n + 1, device="cuda", dtype=torch.int64) * 16).to(torch.int32)
+            vv = torch.rand(n * 16, device="cuda", dtype=torch.float64)
+            del rows
+            A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
+            x = torch.sin(7.0 * torch.arange(n, device="cuda", dtype=torch.float64) + 0.3)
+            y = torch.empty(n, dtype=torch.float64, device="cuda")
+            print("banded", w, "builder timed", A.candidate_ms(), flush=True)
+            report(out, f"banded_w{w}_auto:{A.kernel_name()}", A.algorithmic_bytes(), timeit(lambda: A.spmv(y, x, st), iters=10))
+            del A, rp, cc, vv
     if "spmm" in what:
         rp, cc, vv = capi.synth_uniform(n, n, 16, 0x5EED0002)
         A = capi.Matrix.from_csr(n, n, rp, cc, vv, borrow=True)
