@@ -344,23 +344,29 @@ EntryP coo_entry(const void *host, int variant, int nrow, int ncol, long nnz, co
 EntryP blocked_entry(const void *host, int nrow, int ncol, int nblocks, const int *blk_nnz, int **brows,
                      int **bcols, double **bvals, const char *who)
 {
+  // per call: nothing here may cost O(nblocks) once the blocks run into the millions (block size 8 on 10 M rows)
+  const bool few = nblocks <= (1 << 14);
   int64_t nnz = 0;
-  for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
-  const bool full = hash_in_full(nnz * (bvals ? 16 : 8));
+  if (few)
+    for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
+  const bool full = few && hash_in_full(nnz * (bvals ? 16 : 8));
   uint64_t h = mix(mix(mix(3, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nblocks);
-  h = print_ints(h, blk_nnz, nblocks, true);
+  h = print_ints(h, blk_nnz, nblocks, few);
   // sampled mode: the same budget as an unblocked matrix -- about 2048 samples per array in ALL, spread over at most 64
   // blocks (2048 per array in EACH of 64 blocks cost 0.85 ms of host time per call on a 2 M x 200 K matrix of 1954 blocks,
   // five times the product itself; the reference's bench loops over bsbm_A_mul_B)
   const int stride = nblocks / 64 + 1, per_block = 2048 / ((nblocks + stride - 1) / stride) + 1;
-  for (int b = 0; b < nblocks; b++) {
-    h = mix(mix(h, (uint64_t)(uintptr_t)brows[b]), (uint64_t)(uintptr_t)bcols[b]);
-    if (full || b % stride == 0) {
-      h = print_ints(print_ints(h, brows[b], blk_nnz[b], full, per_block), bcols[b], blk_nnz[b], full, per_block);
-      if (bvals) h = print_doubles(h, bvals[b], blk_nnz[b], full, per_block);
-    }
+  const int pstride = full ? 1 : nblocks / 4096 + 1;              // array pointers: all of them up to 4096 blocks
+  for (int b = 0; b < nblocks; b += pstride) h = mix(mix(h, (uint64_t)(uintptr_t)brows[b]), (uint64_t)(uintptr_t)bcols[b]);
+  for (int b = 0; b < nblocks; b += full ? 1 : stride) {
+    h = print_ints(print_ints(h, brows[b], blk_nnz[b], full, per_block), bcols[b], blk_nnz[b], full, per_block);
+    if (bvals) h = print_doubles(h, bvals[b], blk_nnz[b], full, per_block);
   }
   return lookup(host, kDirect, h, [&](Entry &n) {
+    if (!few) {
+      nnz = 0;
+      for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
+    }
     std::vector<int> r((size_t)nnz), c((size_t)nnz);
     std::vector<double> v(bvals ? (size_t)nnz : 0);
     size_t o = 0;
