@@ -935,20 +935,22 @@ __global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int n
 // 16-byte aligned and has an even number of columns (a pair load at the end of an odd vector would read past it);
 // spmv_ldsx_pipe_kernel otherwise and with tiled_flags bit 2.  Config 3: A 0.745 -> 0.70 ms, A' 0.826 -> 0.775 ms.
 //   phase IT:  gather item IT+1 (its slice landed a phase ago) | start the DMA of item IT+3's slice into the buffer item IT
-//   used (free since the barrier) | add item IT | request the entries of item IT+NSETS-1 | wait until this wave's DMA of
-//   item IT+2 has landed | barrier.
-// vmcnt retires in order: the wait lets the operations issued AFTER that DMA stay in flight (the entries requested behind
-// it a phase ago, this phase's DMA and entries), so the order "DMA, then entries" inside a phase is pinned.
+//   used (free since the barrier) | wait for the gathers | add item IT | request the entries of item IT+NSETS-1 | wait until
+//   this wave's DMA of item IT+2 has landed | barrier.
 // The slice buffers are three separate LDS objects: the compiler tracks an LDS DMA per object and would otherwise make
-// every gather wait for the DMA still under way into another buffer.
-// Inside the loop every LDS access is written as inline assembly and the barrier is the bare s_barrier: the compiler makes
-// each LDS instruction it knows about wait for every LDS DMA under way (vmcnt(0) in front of every ds_add_f64, and again
-// before the barrier), which would end the prefetch of the entries as well -- vmcnt retires in order.  The waits are
-// placed by hand instead:
-//   before the barrier   vmcnt(n): this wave's DMA of item IT+2 has landed; the operations issued after it (the entries
-//                        requested behind it a phase ago, this phase's DMA and entries: n = 2 * loads per entry pair + 1)
-//                        stay in flight, so the order "DMA, then entries" inside a phase is pinned by scheduling barriers;
-//                        lgkmcnt(0): this wave's gathers have returned (their buffer is refilled next phase) .
+// every gather wait for the DMA still under way into another buffer.  Even so it makes each LDS instruction it knows about
+// wait for every LDS DMA under way (vmcnt(0) in front of every ds_add_f64, and again before the barrier), which would end
+// the prefetch of the entries as well -- vmcnt retires in order.  So inside the loop every LDS access is inline assembly,
+// the barrier is the bare s_barrier, and the waits are placed by hand:
+//   after the gathers and the DMA   lgkmcnt(0): the gathered values are in their registers (an empty asm that takes them
+//                        as in/out operands keeps the compiler from giving those registers to anything else before this
+//                        point -- the hardware writes them some time after the ds_read was issued) and their buffer may
+//                        be refilled once every wave is past the barrier.  The adds go out AFTER this wait and are not
+//                        waited for: nothing but the end of the kernel reads the y slice.
+//   before the barrier   vmcnt(n): this wave's DMA of item IT+2 has landed; the n operations issued after it stay in
+//                        flight (the entries requested behind it a phase ago, this phase's DMA and entries: n = 2 * loads
+//                        per entry pair + 1), so the order "DMA, then entries" inside a phase is pinned by scheduling
+//                        barriers.  tests/test_isa_guards.py checks n against the compiled code.
 #ifndef FS_DMA_SETS
 #define FS_DMA_SETS 6
 #endif
