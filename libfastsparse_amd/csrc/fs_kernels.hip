@@ -646,10 +646,13 @@ __device__ __forceinline__ void ldsx_load2_entries(const int4 d, int t, const un
   // entries 2t, 2t+1 of the item; threads wholly past its end re-read its first pair (masked at the add), the thread
   // on an odd end reads one entry of the next item (or of the slack behind the array), masked too
   const int64_t e = (int64_t)d.x + (2 * t < d.y ? 2 * t : 0);
-  const v2u_a4 pw = stream_load<NT>(reinterpret_cast<const v2u_a4 *>(pk + e));
+  // (the pair types carry the alignment of ONE element: spelled out here, a template would deduce the plain vector type)
+  const v2u_a4 *pp = reinterpret_cast<const v2u_a4 *>(pk + e);
+  const v2u_a4 pw = NT ? __builtin_nontemporal_load(pp) : *pp;
   w[0] = pw.x; w[1] = pw.y;
   if (VALUED) {
-    const v2d_a8 pv = stream_load<NT>(reinterpret_cast<const v2d_a8 *>(vals + e));
+    const v2d_a8 *vp = reinterpret_cast<const v2d_a8 *>(vals + e);
+    const v2d_a8 pv = NT ? __builtin_nontemporal_load(vp) : *vp;
     v[0] = pv.x; v[1] = pv.y;
   }
 }
