@@ -72,7 +72,8 @@ int  fs_set_device(int device);
  * column-blocked matrix, the column-major copies of X and Y of multi-column products on the LDS-staged copy, k = 2..16), so
  * products on ONE handle must not overlap in time on different streams: order them, or use one handle per stream.  Only the
  * row kernel (option "spmm_kernel" = 1; k >= 5 on matrices that keep the two-pass copy, k > 16 otherwise) and distinct handles
- * are unrestricted.
+ * are unrestricted.  (fs_spmv_host / fs_spmv_t_host order themselves behind the handle's last device-vector product.)
+ * Options are read at the call, on the calling thread, without a lock: set them before other threads create or multiply.
  * "spmm_kernel" (multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep for k = 2..4, 3 one single-vector sweep
  * per column, 4 the v_mfma_f64_16x16x4_f64 experiment), "ata_kernel" (fs_ata_mul: 0 two products, 2 the fused single kernel),
  * "device_build" (format constructors: 0 host loops, 1 on the device from 4 M entries, 2 on the device always).
@@ -126,10 +127,26 @@ int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
 /* y[ncol] = A' x[nrow]          (At_mul_B / sdm_At_mul_B; CSR At_mul_B of BASELINE config 2) */
 int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
 /* Y[nrow,k] = A X[ncol,k], X and Y row-major  (csr_A_mul_Bn, bcsr_A_mul_B2..._B32n, bsbm_A_mul_B2/_B4/_Bn).
- * On a matrix that keeps the LDS-staged copy the FIRST product with a given k (3..16) runs twice -- one sweep per column and
- * the row kernel -- and waits for both: the faster one serves that k from then on (FS_TRACE_BUILD prints the two times). */
+ * Stream-ordered like fs_spmv: a product never builds a copy and never waits for the device.  What a given k can use
+ * beyond the copies made at creation -- the k-column two-pass copy (k = 2..4), the measured choice between one sweep per
+ * column and the row kernel (LDS-staged copy, k = 3..16) -- is made by fs_matrix_prepare; without it the product runs on
+ * what the handle already holds (fs_matrix_spmm_plan tells which kernel that is). */
 int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
 int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
+/* One-time work for products with k columns on A (transposed != 0: on A', after fs_matrix_build_transpose): builds the
+ * k-column two-pass copy (k = 2, 3, 4 on matrices that keep the two-pass copy: +(4 + 16k [+ 8]) bytes per entry of HBM,
+ * 30-40 ms at 160 M entries), allocates the column-major scratch and times column sweeps against the row kernel (k = 3..16
+ * on matrices that keep the LDS-staged copy).  Synchronous; idempotent; k = 1 and k > 16 need nothing.  The drop-in
+ * layer calls it on the first product with a new k, and for every k listed in the environment variable FS_PREPARE_K
+ * (e.g. "2,4") when it makes the device copy of a matrix, so that no later product call carries the work. */
+int fs_matrix_prepare(fs_matrix_t A, int k, int transposed, fs_stream_t stream);
+/* which kernel fs_spmm / fs_spmm_t runs for this k right now: 1 row kernel, 2 k-column two-pass sweep, 3 one
+ * single-vector two-pass sweep per column, 4 MFMA experiment, 5 column-major sweeps of the LDS-staged kernel, 6 / 7 strided
+ * sweeps of the LDS-staged / L2-tiled kernel */
+int fs_matrix_spmm_plan(fs_matrix_t A, int k, int transposed);
+/* HBM the handle holds (A and, once built, A'), in bytes: [0] the CSR arrays it owns + chunk schedule, [1] the kept
+ * single-vector copy (two-pass incl. its product stream / L2-tiled / LDS-staged), [2] k-column copies and multi-column scratch */
+int fs_matrix_device_bytes(fs_matrix_t A, int64_t *bytes3);
 /* y[ncol] = A'A x[ncol]; tmp is caller scratch of nrow doubles in HBM   (bcsr_AA_mul_B, parallel_bcsr_AA_mul_B) */
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream);
 

@@ -19,6 +19,7 @@ DEVICE_API = [
     "fs_version", "fs_last_error", "fs_device_count", "fs_set_device", "fs_set_option", "fs_get_option",
     "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
     "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel", "fs_matrix_candidate_ms",
+    "fs_matrix_prepare", "fs_matrix_spmm_plan", "fs_matrix_device_bytes",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
     "fs_spmv", "fs_spmv_t", "fs_spmv_host", "fs_spmv_t_host", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all", "fs_cache_entries",
@@ -88,6 +89,9 @@ def lib():
     L.fs_matrix_has_transpose.argtypes = [vp]
     L.fs_matrix_spmv_kernel.argtypes = [vp, C.c_int]
     L.fs_matrix_candidate_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.fs_matrix_prepare.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.fs_matrix_spmm_plan.argtypes = [vp, C.c_int, C.c_int]
+    L.fs_matrix_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fs_matrix_nrow.argtypes = [vp]
     L.fs_matrix_ncol.argtypes = [vp]
     L.fs_matrix_nnz.argtypes = [vp]
@@ -200,6 +204,24 @@ class Matrix:
         out = (C.c_float * 4)()
         check(lib().fs_matrix_candidate_ms(self.h, int(transposed), out), "fs_matrix_candidate_ms")
         return dict(zip(("stream", "tiled", "lds-staged", "two-pass"), (round(float(v), 4) for v in out)))
+
+    SPMM_PLANS = {0: "spmv", 1: "row", 2: "k-column two-pass", 3: "two-pass per column", 4: "mfma", 5: "lds-staged per column",
+                  6: "lds-staged strided", 7: "tiled strided"}
+
+    def prepare(self, k, stream=None, transposed=False):
+        """one-time work for k-column products (fs_matrix_prepare): fs_spmm itself never builds or waits"""
+        check(lib().fs_matrix_prepare(self.h, int(k), int(transposed), stream), "fs_matrix_prepare")
+
+    def spmm_plan(self, k, transposed=False):
+        """name of the kernel fs_spmm runs for this k right now"""
+        code = lib().fs_matrix_spmm_plan(self.h, int(k), int(transposed))
+        return self.SPMM_PLANS.get(code, str(code))
+
+    def device_bytes(self):
+        """HBM held by the handle: (CSR + schedule, kept single-vector copy, k-column copies + scratch)"""
+        out = (C.c_int64 * 3)()
+        check(lib().fs_matrix_device_bytes(self.h, out), "fs_matrix_device_bytes")
+        return tuple(int(v) for v in out)
 
     def build_transpose(self, stream=None):
         check(lib().fs_matrix_build_transpose(self.h, stream), "fs_matrix_build_transpose")

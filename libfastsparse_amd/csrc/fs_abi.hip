@@ -1,4 +1,5 @@
 // fs_abi.hip -- the device-resident layer of the C-ABI (include/fastsparse_hip.h, part 2).
+#include <dlfcn.h>
 #include <string.h>
 
 #include "fs_common.h"
@@ -30,6 +31,40 @@ Options &options()
   }();
   return o;
 }
+
+// ---- roctx (see fs_common.h) ---------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+};
+Roctx &roctx()
+{
+  static Roctx r = [] {
+    Roctx q;
+    const char *force = getenv("FS_ROCTX");
+    const char *pre = getenv("LD_PRELOAD");
+    const bool under_profiler = (pre && strstr(pre, "rocprofiler-sdk")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") ||
+                                getenv("ROCPROF_OUTPUT_PATH") || getenv("ROCP_TOOL_LIBRARIES");
+    if (force ? *force == '0' : !under_profiler) return q;
+    void *lib = nullptr;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) return q;
+    q.push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+    q.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    q.on = q.push && q.pop;
+    return q;
+  }();
+  return r;
+}
+}  // namespace
+bool roctx_enabled() { return roctx().on; }
+void roctx_push(const char *name) { (void)roctx().push(name); }
+void roctx_pop() { (void)roctx().pop(); }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -133,6 +168,7 @@ int fs_get_option(const char *name)
 fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols, const double *vals,
                           int space, int borrow)
 {
+  FS_RANGE("fs_csr_create");
   if (nrow < 0 || ncol < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !cols)) {
     set_error("fs_csr_create: bad argument");
     return nullptr;
@@ -163,6 +199,7 @@ fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, c
 fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, const int *cols, const double *vals,
                           int space)
 {
+  FS_RANGE("fs_coo_create");
   if (nrow < 0 || ncol < 0 || nnz < 0 || (nnz > 0 && (!rows || !cols))) {
     set_error("fs_coo_create: bad argument");
     return nullptr;
@@ -202,6 +239,7 @@ void fs_matrix_destroy(fs_matrix_t A)
 
 int fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream)
 {
+  FS_RANGE("fs_matrix_build_transpose");
   if (!A) { set_error("fs_matrix_build_transpose: NULL handle"); return FS_ERR_ARG; }
   std::lock_guard<std::mutex> g(A->lock);
   if (A->has_t) return FS_OK;
@@ -263,8 +301,10 @@ static int check_mul(fs_matrix_t A, const void *y, const void *x, const char *wh
 
 int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
 {
+  FS_RANGE("fs_spmv");
   if (int rc = check_mul(A, y, x, "fs_spmv")) return rc;
   std::lock_guard<std::mutex> g(A->lock);
+  A->last_stream = (hipStream_t)stream; A->last_async = true;
   return fs::launch_spmv(A->a, y, x, (hipStream_t)stream);
 }
 
@@ -301,27 +341,47 @@ int fs_debug_tiled_trace(fs_matrix_t A, double *y, const double *x, long long *t
   return FS_OK;
 }
 
+// The host-vector path launches on the handle's own non-blocking stream but shares the handle's scratch (product stream of
+// the two-pass copy, sums of cut rows) with the device-vector products, which return right after an asynchronous launch:
+// wait for the stream the last of those went to (a non-blocking stream is not ordered against it, not even the null stream).
+static int order_behind_last(fs_matrix_t A)
+{
+  if (!A->last_async) return FS_OK;
+  A->last_async = false;
+  if (hipStreamSynchronize(A->last_stream) != hipSuccess) {   // e.g. the caller has destroyed that stream since
+    (void)hipGetLastError();
+    FS_HIP(hipDeviceSynchronize());
+  }
+  return FS_OK;
+}
+
 // products with HOST vectors: synchronous; the copies of x and y overlap the kernels where the kept copy allows it
 int fs_spmv_host(fs_matrix_t A, double *y_host, const double *x_host)
 {
+  FS_RANGE("fs_spmv_host");
   if (int rc = check_mul(A, y_host, x_host, "fs_spmv_host")) return rc;
   std::lock_guard<std::mutex> g(A->lock);
+  if (int rc = order_behind_last(A)) return rc;
   return fs::spmv_host_vectors(A->a, A->pipe, y_host, x_host);
 }
 
 int fs_spmv_t_host(fs_matrix_t A, double *y_host, const double *x_host)
 {
   if (int rc = check_mul(A, y_host, x_host, "fs_spmv_t_host")) return rc;
+  FS_RANGE("fs_spmv_t_host");
   if (!A->has_t) { set_error("fs_spmv_t_host: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(A->lock);
+  if (int rc = order_behind_last(A)) return rc;
   return fs::spmv_host_vectors(A->at, A->pipe, y_host, x_host);
 }
 
 int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
 {
   if (int rc = check_mul(A, y, x, "fs_spmv_t")) return rc;
+  FS_RANGE("fs_spmv_t");
   if (!A->has_t) { set_error("fs_spmv_t: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(A->lock);
+  A->last_stream = (hipStream_t)stream; A->last_async = true;
   return fs::launch_spmv(A->at, y, x, (hipStream_t)stream);
 }
 
@@ -330,7 +390,9 @@ int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream
   if (int rc = check_mul(A, Y, X, "fs_spmm")) return rc;
   if (k < 1) { set_error("fs_spmm: k < 1"); return FS_ERR_ARG; }
   if (k == 1) return fs_spmv(A, Y, X, stream);
-  std::lock_guard<std::mutex> g(A->lock);   // k <= 4 may build a copy and uses the handle's product scratch
+  FS_RANGE("fs_spmm");
+  std::lock_guard<std::mutex> g(A->lock);   // the k-column sweeps use the handle's product scratch
+  A->last_stream = (hipStream_t)stream; A->last_async = true;
   return fs::launch_spmm(A->a, Y, X, k, (hipStream_t)stream);
 }
 
@@ -340,12 +402,48 @@ int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stre
   if (k < 1) { set_error("fs_spmm_t: k < 1"); return FS_ERR_ARG; }
   if (!A->has_t) { set_error("fs_spmm_t: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   if (k == 1) return fs_spmv_t(A, Y, X, stream);
+  FS_RANGE("fs_spmm_t");
   std::lock_guard<std::mutex> g(A->lock);
+  A->last_stream = (hipStream_t)stream; A->last_async = true;
   return fs::launch_spmm(A->at, Y, X, k, (hipStream_t)stream);
+}
+
+// Everything a k-column product on this handle needs beyond a launch -- the k-column two-pass copy (k = 2..4), the
+// column-major scratch and the measured sweeps-or-row-kernel choice (LDS-staged copy, k = 3..16) -- done now, so that
+// fs_spmm / fs_spmm_t never build, allocate a copy or wait inside a product.  Synchronous, idempotent.
+int fs_matrix_prepare(fs_matrix_t A, int k, int transposed, fs_stream_t stream)
+{
+  FS_RANGE("fs_matrix_prepare");
+  if (!A || k < 1) { set_error("fs_matrix_prepare: bad argument"); return FS_ERR_ARG; }
+  if (transposed && !A->has_t) { set_error("fs_matrix_prepare: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  const int rc = fs::prepare_spmm(transposed ? A->at : A->a, k, (hipStream_t)stream);
+  fs::pool_trim();
+  return rc;
+}
+
+int fs_matrix_spmm_plan(fs_matrix_t A, int k, int transposed)
+{
+  if (!A || k < 1 || (transposed && !A->has_t)) return FS_ERR_ARG;
+  if (k == 1) return 0;
+  std::lock_guard<std::mutex> g(A->lock);
+  return fs::spmm_plan(transposed ? A->at : A->a, k, nullptr);
+}
+
+int fs_matrix_device_bytes(fs_matrix_t A, int64_t *bytes3)
+{
+  if (!A || !bytes3) return FS_ERR_ARG;
+  std::lock_guard<std::mutex> g(A->lock);
+  int64_t a[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+  fs::device_bytes(A->a, a);
+  if (A->has_t) fs::device_bytes(A->at, t);
+  for (int i = 0; i < 3; ++i) bytes3[i] = a[i] + t[i];
+  return FS_OK;
 }
 
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream)
 {
+  FS_RANGE("fs_ata_mul");
   if (int rc = check_mul(A, y, x, "fs_ata_mul")) return rc;
   if (fs::options().ata_kernel == 2 && !fs::options().strict_order && !fs::options().reproducible) {
     // the fused form (bcsr_AA_mul_B's own loop nest): one pass over A per phase, no copy of A'.  Measured slower than
@@ -413,6 +511,7 @@ void fs_cbcsr_destroy(fs_cbcsr_t A)
 
 int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream)
 {
+  FS_RANGE("fs_cbcsr_spmv");
   if (!A || !y || !x) { set_error("fs_cbcsr_spmv: NULL argument"); return FS_ERR_ARG; }
   std::lock_guard<std::mutex> g(A->lock);
   return fs::launch_cbcsr(*A, y, x, (hipStream_t)stream);

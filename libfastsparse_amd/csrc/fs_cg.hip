@@ -241,6 +241,7 @@ int fs_axpy(int n, double a, const double *x, double *y, fs_stream_t stream)
 int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lambda, double tol, int *out_iter,
           fs_stream_t stream)
 {
+  FS_RANGE("fs_cg");
   if (!A || !At || !x || !b) { set_error("fs_cg: NULL argument"); return FS_ERR_ARG; }
   const int N = A->a.nrow, F = A->a.ncol;
   if (At->a.nrow != F || At->a.ncol != N) { set_error("fs_cg: At is not the transpose shape of A"); return FS_ERR_ARG; }
@@ -277,9 +278,13 @@ int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lamb
 int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lambda, double tol, int *out_iter,
            fs_stream_t stream)
 {
+  FS_RANGE("fs_cg2");
   if (!A || !At || !X || !B) { set_error("fs_cg2: NULL argument"); return FS_ERR_ARG; }
   const int N = A->a.nrow, F = A->a.ncol;
   if (At->a.nrow != F || At->a.ncol != N) { set_error("fs_cg2: At is not the transpose shape of A"); return FS_ERR_ARG; }
+  // the two-column copies of both matrices, before the first iteration (fs_spmm itself never builds)
+  if (int rc = fs_matrix_prepare(A, 2, 0, stream)) return rc;
+  if (int rc = fs_matrix_prepare(At, 2, 0, stream)) return rc;
   hipStream_t s = (hipStream_t)stream;
   Workspace ws;
   double *R = ws.get(2 * (size_t)F), *P = ws.get(2 * (size_t)F), *Q = ws.get(2 * (size_t)F), *tmp = ws.get(2 * (size_t)N);

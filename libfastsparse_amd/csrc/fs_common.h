@@ -45,7 +45,7 @@ struct DeviceCsr {
   // multi-column products of a matrix on the LDS-staged copy: X and Y column-major in here, one unit-stride sweep per column
   double *spmm_scratch = nullptr;
   size_t spmm_scratch_doubles = 0;
-  signed char spmm_choice[17] = {};   // per k: 0 not measured yet, 1 one sweep per column, 2 the row kernel (timed on first use)
+  signed char spmm_choice[17] = {};   // per k: 0 not measured (column sweeps run), 1 one sweep per column, 2 the row kernel (prepare_spmm measures)
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
@@ -167,6 +167,8 @@ struct fs_matrix_s {
   bool has_t = false;
   int device = 0;
   std::mutex lock;             // serialises products that share head/tail scratch
+  hipStream_t last_stream = nullptr;   // stream of the handle's last asynchronous product (fs_spmv_host orders itself behind it)
+  bool last_async = false;
   fs::HostPipe pipe;           // fs_spmv_host / fs_spmv_t_host
 };
 
@@ -201,6 +203,21 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     if (e_ != hipSuccess) return ::fs::hip_fail(e_, #call, __FILE__, __LINE__); \
   } while (0)
 
+// ---- roctx ranges around the C-ABI entry points ("roctx ranges around each C-ABI entry") -----------------
+// librocprofiler-sdk-roctx.so.1 is dlopen'ed on first use when FS_ROCTX=1 or the process runs under rocprofv3 (its tool
+// library is preloaded); otherwise a range costs one predictable branch.  `rocprofv3 --marker-trace -- <program>` shows them.
+bool roctx_enabled();
+void roctx_push(const char *name);
+void roctx_pop();
+struct Range {
+  bool on;
+  explicit Range(const char *name) : on(roctx_enabled()) { if (on) roctx_push(name); }
+  ~Range() { if (on) roctx_pop(); }
+  Range(const Range &) = delete;
+  Range &operator=(const Range &) = delete;
+};
+#define FS_RANGE(name) ::fs::Range fs_range_(name)
+
 struct Options {
   int strict_order = 0;
   int spmv_kernel = 0;   // 0 auto, 1 stream (nt loads), 2 lanes-per-row, 3 stream (cached loads), 6 tiled, 7 two-pass,
@@ -228,7 +245,9 @@ Options &options();
 
 // ---- launchers implemented in fs_kernels.hip --------------------------------------------
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
-int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // may build a k-column copy
+int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // never builds, never waits: see prepare_spmm
+int prepare_spmm(DeviceCsr &A, int k, hipStream_t s);   // k-column copy, scratch, measured choice: synchronous, idempotent
+int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare);   // which kernel launch_spmm runs for this k (kPlan* in fs_kernels.hip)
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
 int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
 // y_host = A x_host: copies and kernels overlapped where the kept copy allows it (two-pass copy without cut rows)
@@ -257,5 +276,6 @@ int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, co
                      hipStream_t s);   // FS_ERR_ARG (with a message) when an index is out of range
 void pool_trim(bool everything = false);   // frees the format builders' idle scratch beyond FS_SCRATCH_POOL_MB (or all of it)
 void free_csr(DeviceCsr &A);
+void device_bytes(const DeviceCsr &A, int64_t out[3]);   // HBM held: CSR + schedule, kept single-vector copy, k-column copies + scratch
 
 }  // namespace fs

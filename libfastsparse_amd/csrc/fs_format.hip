@@ -169,6 +169,31 @@ void free_csr(DeviceCsr &A)
   A = DeviceCsr();
 }
 
+// HBM held by a handle's CSR and every copy / scratch made for it so far, in bytes: [0] the CSR itself (0 when the arrays
+// are borrowed) + chunk schedule, [1] the kept single-vector copy (two-pass incl. its product stream, L2-tiled or LDS-staged),
+// [2] the k-column two-pass copies (k = 2, 4) and the column-major scratch of multi-column products
+void device_bytes(const DeviceCsr &A, int64_t out[3])
+{
+  auto tiled_bytes = [&](const TiledCsr *T) -> int64_t {
+    if (!T) return 0;
+    int64_t b = 4 * A.nnz + (T->vals ? 8 * A.nnz : 0) + 16ll * T->nitems + 4ll * (T->P + 1) * 2;
+    if (T->vfirst) b += 4ll * (A.nrow + 1);
+    if (T->yv) b += 8ll * (T->split ? T->nvrow : A.nrow);
+    b += 12ll * T->nchunks;
+    return b;
+  };
+  auto binned_bytes = [&](const BinnedCsr *N) -> int64_t {
+    if (!N) return 0;
+    int64_t b = N->n * (2 + 2 + 8ll * N->kw + (N->vals ? 8 : 0)) + 4 * (N->n / (kBinGroup / N->kw)) + 4ll * (N->B + 1) + 8ll * (N->P + 1);
+    if (N->vfirst) b += 4ll * (A.nrow + 1);
+    if (N->yv) b += 8ll * N->nvrow * N->kw;
+    return b;
+  };
+  out[0] = (A.owns ? 4ll * (A.nrow + 1) + 4 * A.nnz + (A.vals ? 8 * A.nnz : 0) : 0) + 4ll * (A.nchunks + 1) + 16ll * A.nchunks;
+  out[1] = tiled_bytes(A.tiled) + tiled_bytes(A.tiledx) + binned_bytes(A.binned);
+  out[2] = binned_bytes(A.binned2) + binned_bytes(A.binned4) + 8ll * (int64_t)A.spmm_scratch_doubles;
+}
+
 // first index r in [0, n] with a[r] >= key (a non-decreasing)
 __device__ __forceinline__ int lower_bound_dev(const int *__restrict__ a, int n, int64_t key)
 {

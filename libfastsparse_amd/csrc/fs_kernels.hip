@@ -1946,99 +1946,78 @@ __global__ __launch_bounds__(kBlock) void columns_to_rows_kernel(int64_t n, int 
   for (int j = 0; j < k; ++j) rm[i * k + j] = cm[(int64_t)j * ld + i];
 }
 
-// multi-column products on the LDS-staged copy: one sweep per column OR the row kernel, whichever the first product with
-// that k measures faster on this matrix.  Neither wins everywhere: config 3's shape (64 per row, X of 1 M rows) 0.77 ms per
-// column against a row kernel that takes 12.5 ms for any k from 4 to 16 (bound by the rate of its X-row gathers, 51 G/s once
-// X is larger than L2); 10 M rows x 16 with X of 131 K rows, k = 8: 3.5 ms in sweeps, 2.05 ms on the row kernel (X in L2).
+// ------------------------------------------------------------------------------------------
+// Multi-column products Y = A X (X, Y row-major, k columns).  Which kernel serves a given (matrix, k) is ONE decision
+// (spmm_plan) over the copies the handle holds and the options; fs_spmm never builds a copy, never allocates a k-column
+// copy and never waits for the device: everything that costs more than a launch happens in prepare_spmm (C-ABI:
+// fs_matrix_prepare; the drop-in layer calls it on the first product with a new k, or for the ks listed in
+// FS_PREPARE_K when the device copy of a matrix is made).
+//
+//   plan 2  k = 2..4 on a matrix that keeps the two-pass copy: ONE sweep with a k-column band of X in LDS (k = 3: a
+//           2-column sweep and a single-vector sweep) -- needs the k-column copy, which prepare builds
+//   plan 3  one single-vector two-pass sweep per column (strided gathers and stores): k <= 3 without a k-column copy
+//   plan 5  a matrix on the LDS-staged copy (dense tiles: config 3's class): one unit-stride sweep per column on
+//           COLUMN-major copies of X and Y (two transposes; the handle's scratch, allocated by prepare or on first use);
+//           for k >= 3 prepare times this against the row kernel on the matrix and keeps the faster (neither wins
+//           everywhere: config 3's shape 0.77 ms per column against a row kernel bound by its X-row gathers at 51 G/s,
+//           12.5 ms for any k from 4 to 16; 10 M rows x 16 with X of 131 K rows, k = 8: 3.5 ms in sweeps, 2.05 ms on
+//           the row kernel, X in L2).  Unprepared: the sweeps (the kernel the builder kept this copy for)
+//   plan 6 / 7  k <= 2 strided sweeps of the LDS-staged / L2-tiled kernel
+//   plan 4  the v_mfma_f64_16x16x4_f64 experiment (option spmm_kernel = 4)
+//   plan 1  the row kernel: k >= 5 on two-pass matrices, k > 16, strict_order / reproducible, small matrices
+// ------------------------------------------------------------------------------------------
 constexpr int kLdsxSweepMaxK = 16;
+enum { kPlanRow = 1, kPlanBinnedK = 2, kPlanBinnedCols = 3, kPlanMfma = 4, kPlanLdsxColumns = 5, kPlanLdsxStrided = 6,
+       kPlanTiledStrided = 7 };
 
-int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
+// *needs_prepare: what prepare_spmm would still do for this k -- bit 0 build the k-column two-pass copy, bit 1 measure
+// column sweeps against the row kernel (0: the plan is final)
+int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
 {
-  if (A.nrow == 0) return FS_OK;
   const Options &o = options();
-  const bool free_order = !o.strict_order && !o.reproducible;   // the two-pass kernels add in arrival order
-  // k = 2, 3, 4 on a matrix large enough for the two-pass kernels: ONE sweep with a k-column band of X in LDS
-  // (k = 3: a 2-column sweep and a single-vector sweep).  The copy is built on the first such product.
-  // spmm_kernel: 0 auto, 1 row kernel, 2 k-column two-pass sweep (fails over to the row kernel when the builder
-  // declines), 3 one single-vector sweep per column
+  if (needs_prepare) *needs_prepare = 0;
+  const bool free_order = !o.strict_order && !o.reproducible;   // the two-pass and LDS-staged kernels add in arrival order
   const int want = o.spmm_kernel;
-  // (only where the format builder kept the two-pass copy for the single-vector product: that is the class of
-  // matrices -- large x, thin tiles -- on which streaming products beats gathering; config 3's dense tiles stay on
-  // the LDS-staged kernel, two sweeps of 0.9 ms against 36 bytes per entry here)
-  if (free_order && k >= 2 && k <= 4 && (want == 0 || want == 2) && o.binning != 0 && (o.spmv_kernel == 0 || o.spmv_kernel == 7) &&
-      ((A.binned && A.binned->built) || o.binning == 2 || want == 2)) {
-    const int kw = k == 4 ? 4 : 2;
-    BinnedCsr *&slot = kw == 2 ? A.binned2 : A.binned4;
-    if (!slot && !(kw == 2 ? A.tried2 : A.tried4)) {
-      if (int rc = build_binned_k(A, kw, s)) return rc;
-    }
-    const bool tail_ok = k != 3 || (A.binned && A.binned->built);
-    if (slot && slot->built && tail_ok) {
-      if (int rc = launch_spmm_binned(A, *slot, Y, X, s, k, k)) return rc;
-      if (k == 3) return launch_spmv_binned(A, Y + 2, X + 2, s, k, k);
-      return FS_OK;
-    }
+  const bool hb = A.binned && A.binned->built, hx = A.tiledx && A.tiledx->built, ht = A.tiled && A.tiled->built;
+  const bool bin_ok = o.spmv_kernel == 0 || o.spmv_kernel == 7, ldsx_ok = o.spmv_kernel == 0 || o.spmv_kernel == 8;
+  // (the k-column copy only where the format builder kept the two-pass copy for the single-vector product: that is the
+  // class of matrices -- large x, thin tiles -- on which streaming products beats gathering; config 3's dense tiles stay
+  // on the LDS-staged kernel, two sweeps of 0.9 ms against 36 bytes per entry here)
+  if (free_order && k >= 2 && k <= 4 && (want == 0 || want == 2) && o.binning != 0 && bin_ok && (hb || o.binning == 2 || want == 2)) {
+    const BinnedCsr *slot = k == 4 ? A.binned4 : A.binned2;
+    const bool tried = k == 4 ? A.tried4 : A.tried2;
+    if (slot && slot->built && (k != 3 || hb)) return kPlanBinnedK;
+    if (!slot && !tried && needs_prepare) *needs_prepare |= 1;
   }
-  // column by column on the single-vector kernels (strided gathers and stores) where that beats the row kernel, whose
-  // every X-row gather misses L2 (three sweeps of the two-pass pair: 3.0 ms on config 2 against 3.8 ms for the row
-  // kernel; four: 4.0 against 3.5)
-  if (want != 1 && (k <= 3 || want == 3) && A.binned && A.binned->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) {
-    for (int j = 0; j < k; ++j)
-      if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
-    return FS_OK;
+  // column by column on the single-vector pair where that beats the row kernel, whose every X-row gather misses L2 (three
+  // sweeps: 3.0 ms on config 2 against 3.8 ms for the row kernel; four: 4.0 against 3.5)
+  if (want != 1 && (k <= 3 || want == 3) && hb && free_order && bin_ok) return kPlanBinnedCols;
+  if (want != 1 && want != 4 && k >= 2 && k <= kLdsxSweepMaxK && hx && !hb && free_order && ldsx_ok) {
+    if (want != 0 || k == 2) return kPlanLdsxColumns;          // k = 2: the sweeps won every measurement
+    if (A.spmm_choice[k] == 0 && needs_prepare) *needs_prepare |= 2;
+    return A.spmm_choice[k] == 2 ? kPlanRow : kPlanLdsxColumns;
   }
-  // A matrix on the LDS-staged copy (dense tiles: config 3's class, bsbm_A_mul_B2 / _B4 / _Bn on a tall binary matrix): one
-  // sweep per column, but on COLUMN-major copies of X and Y so that every sweep is the unit-stride kernel with its slices by
-  // LDS DMA (config 3's shape, k = 2 / 4 / 8: 2.1 / 12.1 / 12.4 ms with strided sweeps and the row kernel; two transposes
-  // cost k * 16 bytes per row and column)
-  bool time_both = false;
-  if (want == 0 && k >= 3 && k <= kLdsxSweepMaxK && A.tiledx && A.tiledx->built && !(A.binned && A.binned->built) && free_order &&
-      (o.spmv_kernel == 0 || o.spmv_kernel == 8) && A.spmm_choice[k] == 0)
-    time_both = true;                             // k = 2: the sweeps won every measurement
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  if (time_both)
-    for (hipEvent_t &e : ev) FS_HIP(hipEventCreate(&e));
-  if (time_both) FS_HIP(hipEventRecord(ev[0], s));
-  if (want != 1 && want != 4 && k >= 2 && k <= kLdsxSweepMaxK && A.tiledx && A.tiledx->built && !(A.binned && A.binned->built) &&
-      free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8) && (want != 0 || k == 2 || A.spmm_choice[k] != 2)) {
-    const int64_t ldx = ((int64_t)A.ncol + 1) & ~(int64_t)1, ldy = ((int64_t)A.nrow + 1) & ~(int64_t)1;   // 16-byte aligned columns
-    const size_t need = (size_t)k * (size_t)(ldx + ldy);
-    if (A.spmm_scratch_doubles < need) {
-      if (A.spmm_scratch) FS_HIP(hipFree(A.spmm_scratch));
-      A.spmm_scratch = nullptr; A.spmm_scratch_doubles = 0;
-      FS_HIP(hipMalloc(&A.spmm_scratch, sizeof(double) * need));
-      A.spmm_scratch_doubles = need;
-    }
-    double *xt = A.spmm_scratch, *yt = A.spmm_scratch + (size_t)k * (size_t)ldx;
-    if (A.ncol > 0)
-      hipLaunchKernelGGL(rows_to_columns_kernel, dim3((unsigned)(((int64_t)A.ncol + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                         (int64_t)A.ncol, k, ldx, X, xt);
-    FS_HIP(hipGetLastError());
-    for (int j = 0; j < k; ++j)
-      if (int rc = launch_spmv_tiled(A, *A.tiledx, yt + (int64_t)j * ldy, xt + (int64_t)j * ldx, s, 1, 1)) return rc;
-    hipLaunchKernelGGL(columns_to_rows_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       (int64_t)A.nrow, k, ldy, yt, Y);
-    FS_HIP(hipGetLastError());
-    if (!time_both) return FS_OK;
-    FS_HIP(hipEventRecord(ev[1], s));             // ... and the row kernel below writes the same Y once more
+  if (want != 1 && k <= 2 && hx && free_order && ldsx_ok) return kPlanLdsxStrided;
+  if (want != 1 && k <= 2 && ht && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return kPlanTiledStrided;
+  return want == 4 ? kPlanMfma : kPlanRow;
+}
+
+static int spmm_scratch_ready(DeviceCsr &A, int k, int64_t *ldx_out, int64_t *ldy_out)
+{
+  const int64_t ldx = ((int64_t)A.ncol + 1) & ~(int64_t)1, ldy = ((int64_t)A.nrow + 1) & ~(int64_t)1;   // 16-byte aligned columns
+  const size_t need = (size_t)k * (size_t)(ldx + ldy);
+  if (A.spmm_scratch_doubles < need) {
+    if (A.spmm_scratch) FS_HIP(hipFree(A.spmm_scratch));
+    A.spmm_scratch = nullptr; A.spmm_scratch_doubles = 0;
+    FS_HIP(hipMalloc(&A.spmm_scratch, sizeof(double) * need));
+    A.spmm_scratch_doubles = need;
   }
-  if (want != 1 && k <= 2 && A.tiledx && A.tiledx->built && free_order && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) {
-    for (int j = 0; j < k; ++j)
-      if (int rc = launch_spmv_tiled(A, *A.tiledx, Y + j, X + j, s, k, k)) return rc;
-    return FS_OK;
-  }
-  if (want != 1 && k <= 2 && A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) {
-    for (int j = 0; j < k; ++j)
-      if (int rc = launch_spmv_tiled(A, *A.tiled, Y + j, X + j, s, k, k)) return rc;
-    return FS_OK;
-  }
-  if (want == 4) {   // the matrix-core experiment (see spmm_mfma_kernel)
-    const unsigned g4 = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
-    if (A.vals) hipLaunchKernelGGL(spmm_mfma_kernel<true>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
-    else        hipLaunchKernelGGL(spmm_mfma_kernel<false>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
-    FS_HIP(hipGetLastError());
-    return FS_OK;
-  }
+  *ldx_out = ldx; *ldy_out = ldy;
+  return FS_OK;
+}
+
+static int launch_spmm_row(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
+{
   const int lg = ceil_log2(k > 64 ? 64 : k);
   const int gpb = kBlock >> lg;
   const unsigned grid = (unsigned)(((int64_t)A.nrow + gpb - 1) / gpb);
@@ -2054,19 +2033,129 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 #undef FS_SPMM_LG
 #undef FS_SPMM
   FS_HIP(hipGetLastError());
-  if (time_both) {
-    FS_HIP(hipEventRecord(ev[2], s));
-    FS_HIP(hipEventSynchronize(ev[2]));
-    float t_sweeps = 0.f, t_row = 0.f;
-    FS_HIP(hipEventElapsedTime(&t_sweeps, ev[0], ev[1]));
-    FS_HIP(hipEventElapsedTime(&t_row, ev[1], ev[2]));
-    A.spmm_choice[k] = t_sweeps <= t_row ? 1 : 2;
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
-    if (trace)
-      fprintf(stderr, "[fastsparse] %d x %d, k = %d: one sweep per column %.2f ms, row kernel %.2f ms\n", A.nrow, A.ncol, k,
-              t_sweeps, t_row);
+  return FS_OK;
+}
+
+// one unit-stride sweep of the LDS-staged kernel per column, on column-major copies of X and Y in the handle's scratch
+static int launch_spmm_ldsx_columns(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
+{
+  int64_t ldx = 0, ldy = 0;
+  if (int rc = spmm_scratch_ready(A, k, &ldx, &ldy)) return rc;
+  double *xt = A.spmm_scratch, *yt = A.spmm_scratch + (size_t)k * (size_t)ldx;
+  if (A.ncol > 0)
+    hipLaunchKernelGGL(rows_to_columns_kernel, dim3((unsigned)(((int64_t)A.ncol + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       (int64_t)A.ncol, k, ldx, X, xt);
+  FS_HIP(hipGetLastError());
+  for (int j = 0; j < k; ++j)
+    if (int rc = launch_spmv_tiled(A, *A.tiledx, yt + (int64_t)j * ldy, xt + (int64_t)j * ldx, s, 1, 1)) return rc;
+  hipLaunchKernelGGL(columns_to_rows_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                     (int64_t)A.nrow, k, ldy, yt, Y);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+static int launch_spmm_plan(DeviceCsr &A, int plan, double *Y, const double *X, int k, hipStream_t s)
+{
+  switch (plan) {
+    case kPlanBinnedK: {
+      const BinnedCsr &N = k == 4 ? *A.binned4 : *A.binned2;
+      if (int rc = launch_spmm_binned(A, N, Y, X, s, k, k)) return rc;
+      if (k == 3) return launch_spmv_binned(A, Y + 2, X + 2, s, k, k);
+      return FS_OK;
+    }
+    case kPlanBinnedCols:
+      for (int j = 0; j < k; ++j)
+        if (int rc = launch_spmv_binned(A, Y + j, X + j, s, k, k)) return rc;
+      return FS_OK;
+    case kPlanLdsxColumns:
+      return launch_spmm_ldsx_columns(A, Y, X, k, s);
+    case kPlanLdsxStrided:
+    case kPlanTiledStrided: {
+      const TiledCsr &T = plan == kPlanLdsxStrided ? *A.tiledx : *A.tiled;
+      for (int j = 0; j < k; ++j)
+        if (int rc = launch_spmv_tiled(A, T, Y + j, X + j, s, k, k)) return rc;
+      return FS_OK;
+    }
+    case kPlanMfma: {   // the matrix-core experiment (see spmm_mfma_kernel)
+      const unsigned g4 = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
+      if (A.vals) hipLaunchKernelGGL(spmm_mfma_kernel<true>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
+      else        hipLaunchKernelGGL(spmm_mfma_kernel<false>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
+      FS_HIP(hipGetLastError());
+      return FS_OK;
+    }
+    default:
+      return launch_spmm_row(A, Y, X, k, s);
   }
+}
+
+int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
+{
+  if (A.nrow == 0) return FS_OK;
+  return launch_spmm_plan(A, spmm_plan(A, k, nullptr), Y, X, k, s);
+}
+
+namespace {
+struct EventPair {   // destroyed however the function leaves
+  hipEvent_t a = nullptr, b = nullptr;
+  int create() { FS_HIP(hipEventCreate(&a)); FS_HIP(hipEventCreate(&b)); return FS_OK; }
+  ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+struct Scratch2 {    // zero operands of a timed run
+  double *x = nullptr, *y = nullptr;
+  int alloc(size_t nx, size_t ny)
+  {
+    FS_HIP(hipMalloc(&x, sizeof(double) * (nx ? nx : 1)));
+    FS_HIP(hipMalloc(&y, sizeof(double) * (ny ? ny : 1)));
+    return FS_OK;
+  }
+  ~Scratch2() { if (x) (void)hipFree(x); if (y) (void)hipFree(y); }
+};
+}  // namespace
+
+// Everything a product with k columns on this matrix may need beyond a launch: the k-column two-pass copy (k = 2..4),
+// the column-major scratch and the measured choice between column sweeps and the row kernel (LDS-staged copy, k = 3..16).
+// Synchronous (builds and timed runs wait for the device); idempotent and cheap once done.
+int prepare_spmm(DeviceCsr &A, int k, hipStream_t s)
+{
+  if (A.nrow == 0 || A.nnz == 0 || k < 2) return FS_OK;
+  int needs = 0;
+  int plan = spmm_plan(A, k, &needs);
+  if (needs & 1) {
+    if (int rc = build_binned_k(A, k == 4 ? 4 : 2, s)) return rc;     // declines (and says so in tried2 / tried4) where it would not pay
+    plan = spmm_plan(A, k, &needs);
+  }
+  if (plan == kPlanLdsxColumns) {                 // scratch first: its hipMalloc may stall and must not be inside a timed run
+    int64_t ldx, ldy;
+    if (spmm_scratch_ready(A, k, &ldx, &ldy) != FS_OK) {
+      (void)hipGetLastError();                     // no room for the column-major copies: this k runs on the row kernel
+      if (k <= kLdsxSweepMaxK) A.spmm_choice[k] = 2;
+      return FS_OK;
+    }
+  }
+  if (!(needs & 2)) return FS_OK;
+  // LDS-staged copy, k = 3..16: time one run of each candidate on zero operands (same addresses and traffic as any X)
+  // after an untimed run of each (code objects loaded, TLB warm)
+  Scratch2 xy;
+  if (xy.alloc((size_t)A.ncol * k, (size_t)A.nrow * k) != FS_OK) { (void)hipGetLastError(); return FS_OK; }
+  FS_HIP(hipMemsetAsync(xy.x, 0, sizeof(double) * (size_t)A.ncol * k, s));
+  EventPair e0, e1;
+  if (e0.create() != FS_OK || e1.create() != FS_OK) { (void)hipGetLastError(); return FS_OK; }
+  float t_sweeps = 0.f, t_row = 0.f;
+  for (int cand = 0; cand < 2; ++cand) {
+    const int pl = cand == 0 ? kPlanLdsxColumns : kPlanRow;
+    if (int rc = launch_spmm_plan(A, pl, xy.y, xy.x, k, s)) return rc;            // warm-up
+    FS_HIP(hipEventRecord(cand == 0 ? e0.a : e1.a, s));
+    if (int rc = launch_spmm_plan(A, pl, xy.y, xy.x, k, s)) return rc;
+    FS_HIP(hipEventRecord(cand == 0 ? e0.b : e1.b, s));
+  }
+  FS_HIP(hipEventSynchronize(e1.b));
+  FS_HIP(hipEventElapsedTime(&t_sweeps, e0.a, e0.b));
+  FS_HIP(hipEventElapsedTime(&t_row, e1.a, e1.b));
+  A.spmm_choice[k] = t_sweeps <= t_row ? 1 : 2;
+  static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
+  if (trace)
+    fprintf(stderr, "[fastsparse] %d x %d, k = %d: one sweep per column %.2f ms, row kernel %.2f ms\n", A.nrow, A.ncol, k,
+            t_sweeps, t_row);
   return FS_OK;
 }
 

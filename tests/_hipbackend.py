@@ -49,6 +49,7 @@ class HipDeviceBackend:
     def csr_mul_n(self, nrow, ncol, rows, cols, vals, X, k, name):
         m = self._coo(nrow, ncol, rows, cols, vals)
         Y = self._out(nrow * k)
+        m.prepare(k, capi.current_stream())
         m.spmm(Y, self._d(np.ascontiguousarray(X).reshape(-1)), k, capi.current_stream())
         return Y.cpu().numpy().reshape(nrow, k)
 
@@ -64,6 +65,7 @@ class HipDeviceBackend:
         order = np.argsort(rows // bs, kind="stable")
         m = self._coo(nrow, ncol, rows[order], cols[order], None if vals is None else vals[order])
         Y = self._out(nrow * k)
+        m.prepare(k, capi.current_stream())
         m.spmm(Y, self._d(np.ascontiguousarray(X).reshape(-1)), k, capi.current_stream())
         Y = Y.cpu().numpy()
         return Y.reshape(nrow, k) if k > 1 else Y

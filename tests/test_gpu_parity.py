@@ -871,7 +871,26 @@ def test_spmm_k_columns_in_one_two_pass_sweep(hip, k, valued):
     try:
         A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
         assert A.kernel_name() == "two-pass"
-        Xs = [S.X_sin(ncol, k)]
+        # a product never builds: before fs_matrix_prepare the k columns run on what the handle holds (and are right) ...
+        before = A.spmm_plan(k)
+        assert before == ("two-pass per column" if k <= 3 else "row"), before
+        X0 = S.X_sin(ncol, k)
+        Y0 = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+        A.spmm(Y0, torch.from_numpy(X0).cuda(), k, st)
+        ref0 = O.csr_mul_n(nrow, rp, cc, vv, X0, k)
+        for j in range(k):
+            sc = O.csr_abs_scale(nrow, rp, cc, vv, np.ascontiguousarray(X0[:, j]))
+            assert np.all(np.abs(Y0.cpu().numpy()[:, j] - ref0[:, j]) <= TOL * np.maximum(sc, 1e-300)), j
+        held = A.device_bytes()
+        assert held[2] == 0, held
+        # ... prepare builds the k-column copy (idempotent), and from then on the one sweep serves this k
+        A.prepare(k, st)
+        A.prepare(k, st)
+        assert A.spmm_plan(k) == "k-column two-pass", A.spmm_plan(k)
+        held2 = A.device_bytes()
+        per_entry = held2[2] / nnz
+        assert held2[:2] == held[:2] and (4 + 16 * (4 if k == 4 else 2)) <= per_entry <= 1.6 * (12 + 16 * (4 if k == 4 else 2)), per_entry
+        Xs = [X0]
         if not valued:
             Xs.append(np.ascontiguousarray(np.stack([S.x_int(31 + j, ncol) for j in range(k)], 1)))
         for X in Xs:
@@ -972,6 +991,115 @@ def test_dropin_cache_sees_one_edited_entry(hip):
             L.csr_A_mul_B(hip._dp(y), C.byref(A), hip._dp(x))
             assert abs(y[777] - ref1[777]) <= 1e-9
         L.fs_invalidate(C.byref(A))
+
+
+@pytest.mark.parametrize("nnz", [3, 7, 45, 8 * 1000 + 5])
+def test_dropin_cache_sees_edits_in_short_and_ragged_arrays(hip, nnz):
+    """the full fingerprint must cover EVERY byte.  Arrays shorter than 32 bytes (3 ints, 3 doubles) are all
+    "tail" for a 32-byte-block hash, and 8k + 5 entries leave 20 / 40 trailing bytes: an edit of the FIRST value or the
+    FIRST column at unchanged pointers must be seen (it used to survive: only the last 8 bytes of the tail were hashed)"""
+    import ctypes as C
+    L = hip.HipDropinBackend().L
+    L.csr_A_mul_B.restype = None
+    rng = np.random.default_rng(nnz)
+    nrow, ncol = 4, 11
+    rp = np.array([0, nnz // 3, nnz // 3, nnz - 1, nnz], np.int32)
+    cc = rng.integers(0, ncol - 1, nnz).astype(np.int32)
+    vv = rng.uniform(-1, 1, nnz)
+    A = _csr_struct(hip, nrow, ncol, rp, cc, vv)
+    x = np.arange(ncol, dtype=np.float64) + 1.0
+    y = np.full(nrow, -1.0)
+    L.csr_A_mul_B(hip._dp(y), C.byref(A), hip._dp(x))
+    assert np.array_equal(y, O.csr_mul(nrow, rp, cc, vv, x))
+    for edit in ("vals", "cols", "vals_tail", "cols_tail"):
+        i = 0 if not edit.endswith("tail") else max(nnz - 3, 0)        # inside the trailing bytes, not the last word
+        if edit.startswith("vals"):
+            vv[i] += 3.0
+        else:
+            cc[i] = cc[i] + 1
+        L.csr_A_mul_B(hip._dp(y), C.byref(A), hip._dp(x))
+        assert np.array_equal(y, O.csr_mul(nrow, rp, cc, vv, x)), (nnz, edit)
+    L.fs_invalidate(C.byref(A))
+
+
+def test_dropin_blocked_matrix_without_rows(hip):
+    """new_bsbm of a matrix with nrow == 0 has no blocks; bsbm_A_mul_B on it does nothing in the reference
+    (sparse.h:259-273: the block loop runs zero times) and used to divide by zero in the side table's fingerprint"""
+    import ctypes as C
+    be = hip.HipDropinBackend()
+    L = be.L
+    s = be.sbm(0, 7, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    B = L.new_bsbm(C.byref(s), 8)
+    assert B.contents.nblocks == 0
+    y = np.full(1, -1.0)
+    for f in (L.bsbm_A_mul_B, L.bsbm_A_mul_B2):
+        f.restype = None
+        f(hip._dp(y), B, hip._dp(np.ones(14)))
+    assert y[0] == -1.0                      # nothing to write: y has no elements
+    L.fs_invalidate(B)
+
+
+@pytest.mark.parametrize("k", [2, 5])
+def test_spmm_never_waits_prepare_decides(hip, k):
+    """a matrix on the LDS-staged copy.  fs_spmm before fs_matrix_prepare runs one sweep per column (no
+    timing of candidates inside the product any more); fs_matrix_prepare measures sweeps against the row kernel once and
+    pins the plan; both give the oracle's result (row-scaled bar; pattern-only + integer X bit for bit)"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(k)
+    nrow, ncol, per = 60_000, 4_096, 40
+    rp = (np.arange(nrow + 1, dtype=np.int64) * per).astype(np.int32)
+    cc = rng.integers(0, ncol, nrow * per).astype(np.int32)
+    st = capi.current_stream()
+    capi.set_option("ldsx", 2)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None)
+        assert A.kernel_name() == "lds-staged"
+        X = np.ascontiguousarray(np.stack([S.x_int(11 + j, ncol) for j in range(k)], 1))
+        ref = O.csr_mul_n(nrow, rp, cc, None, X, k)
+        Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+        assert A.spmm_plan(k) == "lds-staged per column"
+        A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
+        assert np.array_equal(Y.cpu().numpy(), ref)
+        A.prepare(k, st)
+        plan = A.spmm_plan(k)
+        assert plan in ("lds-staged per column", "row") and (k != 2 or plan == "lds-staged per column"), plan
+        Y.fill_(-1.0)
+        A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
+        assert np.array_equal(Y.cpu().numpy(), ref)
+        assert A.device_bytes()[2] >= 8 * k * (nrow + ncol)          # the column-major scratch is accounted for
+    finally:
+        capi.set_option("ldsx", 1)
+
+
+def test_host_vector_product_waits_for_device_vector_products(hip):
+    """fs_spmv returns right after an asynchronous launch on the caller's stream; fs_spmv_host runs on the
+    handle's own non-blocking stream and shares the handle's scratch (the two-pass product stream).  It has to order itself
+    behind the earlier launches: a burst of device-vector products on a side stream, then the host-vector product"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(77)
+    nrow, ncol, per = 300_000, 2_000_003, 16
+    rp = (np.arange(nrow + 1, dtype=np.int64) * per).astype(np.int32)
+    cc = rng.integers(0, ncol, nrow * per).astype(np.int32)
+    capi.set_option("binning", 2)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None)
+        assert A.kernel_name() == "two-pass"
+        side = torch.cuda.Stream()
+        x1, x2 = S.x_int(1, ncol), S.x_int(2, ncol)
+        xd = torch.from_numpy(x1).cuda()
+        yd = torch.empty(nrow, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(30):
+            A.spmv(yd, xd, side.cuda_stream)
+        yh = np.full(nrow, -1.0)
+        A.spmv_host(yh, x2)                                  # must not overlap the 30 products still in flight
+        assert np.array_equal(yh, O.csr_mul(nrow, rp, cc, None, x2))
+        side.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), O.csr_mul(nrow, rp, cc, None, x1))
+    finally:
+        capi.set_option("binning", 1)
 
 
 def test_dropin_strict_cache_and_bounded_table_in_a_fresh_process(hip):

@@ -1,6 +1,8 @@
-"""Every reference-named product on ONE matrix (host structs, vectors in HBM, steady state): ms per call and the ratio to the
-plain product of the same matrix times the number of columns -- an entry point that costs far more than k plain products is a
-cliff in the drop-in layer or in the kernel choice, not in the kernels.   python tools/entrypoint_sweep.py [nrow ncol per_row]"""
+"""Every reference-named product on ONE matrix (host structs, vectors in HBM): the FIRST call (upload + format work, and for a
+new k the one-time fs_matrix_prepare the drop-in layer runs) reported apart from the steady state: ms per call and the ratio
+to the plain product of the same matrix times the number of columns -- an entry point that costs far more than k plain products
+is a cliff in the drop-in layer or in the kernel choice, not in the kernels.  FS_PREPARE_K=2,4,... moves the k-column work of
+the listed ks into the first call on the matrix.   python tools/entrypoint_sweep.py [nrow ncol per_row]"""
 import ctypes as C
 import os
 import sys
@@ -35,14 +37,18 @@ def timed(name, out_n, A, x_n, k=1, extra=(), reps=10):
     f.restype = None
     x, y = dev(x_n * k), torch.empty(out_n * k, device="cuda", dtype=torch.float64)
     a = A if isinstance(A, C._Pointer) else C.byref(A)
-    for _ in range(2):
-        f(ptr(y), a, ptr(x), *extra)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    f(ptr(y), a, ptr(x), *extra)
+    torch.cuda.synchronize()
+    first = (time.time() - t0) * 1e3
+    f(ptr(y), a, ptr(x), *extra)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(reps):
         f(ptr(y), a, ptr(x), *extra)
     torch.cuda.synchronize()
-    return (time.time() - t0) / reps * 1e3
+    return (time.time() - t0) / reps * 1e3, first
 
 
 base = {}
@@ -61,9 +67,10 @@ for name, out_n, A, x_n, k, extra, ref in [
         ("bcsr_A_mul_B32n", nrow, bcsr, ncol, 32, (C.c_int(32),), "A_mul_B"),
         ("csr_A_mul_Bn", nrow, csr, ncol, 2, (C.c_int(2),), "sdm_A_mul_B"), ("csr_A_mul_Bn", nrow, csr, ncol, 8, (C.c_int(8),), "sdm_A_mul_B"),
         ("bcsr_AA_mul_B", ncol, bcsr, ncol, 1, (), None)]:
-    ms = timed(name, out_n, A, x_n, k, extra)
+    ms, first = timed(name, out_n, A, x_n, k, extra)
     if ref is None:
         base[name] = ms
     ratio = ms / (base[ref] * k) if ref else 1.0
-    print("%-22s k=%-2d %8.3f ms   x%.2f of k plain products%s" % (name, k, ms, ratio, "   <-- look at this" if ratio > 2.5 else ""), flush=True)
+    print("%-22s k=%-2d %8.3f ms   x%.2f of k plain products   first call %9.2f ms%s"
+          % (name, k, ms, ratio, first, "   <-- look at this" if ratio > 2.5 else ""), flush=True)
 L.fs_release_all()
