@@ -134,7 +134,8 @@ int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
 int fs_spmm(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
 int fs_spmm_t(fs_matrix_t A, double *Y, const double *X, int k, fs_stream_t stream);
 /* One-time work for products with k columns on A (transposed != 0: on A', after fs_matrix_build_transpose): builds the
- * k-column two-pass copy (k = 2, 3, 4 on matrices that keep the two-pass copy: +(4 + 16k [+ 8]) bytes per entry of HBM,
+ * k-column two-pass copy (k = 2, 3, 4 on matrices that keep the two-pass copy: +(4.25 + 8 kw [+ 8]) bytes per padded entry
+ * of HBM with kw = 2 for k = 2, 3 and 4 for k = 4, fs_matrix_device_bytes reports it;
  * 30-40 ms at 160 M entries), allocates the column-major scratch and times column sweeps against the row kernel (k = 3..16
  * on matrices that keep the LDS-staged copy).  Synchronous; idempotent; k = 1 and k > 16 need nothing.  The drop-in
  * layer calls it on the first product with a new k, and for every k listed in the environment variable FS_PREPARE_K

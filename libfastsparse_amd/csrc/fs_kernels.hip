@@ -1100,17 +1100,14 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // pass 1: persistent workgroups, one per CU; workgroup w streams the w-th equal share of the (band, panel)-ordered
 // groups and reloads its x band when the share crosses into the next band (every band is loaded once, plus once
 // per share boundary: cutting bands into many small workgroups instead re-reads x several times over)
-template <bool VALUED, int U, bool NTLD, bool NTST, int BC = kBinCols>
-__global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
-    int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
-    const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
-    double *__restrict__ prod, unsigned gbeg, unsigned gend)
+// xband: BC + 8 doubles of LDS; slot BC is the zero the padding entries point at.  The share is groups [g0, g1).
+template <bool VALUED, int U, bool NTLD, bool NTST, int BC>
+__device__ __forceinline__ void expand_share(double *__restrict__ xband, int ncol, int B, const unsigned *__restrict__ band_ptr,
+                                             const uint16_t *__restrict__ lcol, const double *__restrict__ vals,
+                                             const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
+                                             double *__restrict__ prod, unsigned g0, unsigned g1)
 {
-  __shared__ double xband[BC + 8];         // slot BC is the zero the padding entries point at
   const int t = threadIdx.x;
-  // this launch covers the groups gbeg .. gend (everything, or the bands whose part of x has arrived: fs_spmv_host)
-  const uint64_t groups = gend - gbeg;
-  const unsigned g0 = gbeg + (unsigned)(groups * blockIdx.x / gridDim.x), g1 = gbeg + (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
   if (g0 >= g1) return;
   // band of the first group: last b with band_ptr[b] <= g0
   int b;
@@ -1185,21 +1182,32 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
   }
 }
 
-// pass 2: workgroup = one row panel; its products are contiguous
-template <bool NTLD, int RM = kBinRowsMax>
-__global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
-    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
+template <bool VALUED, int U, bool NTLD, bool NTST, int BC = kBinCols>
+__global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
+    int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
+    const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
+    double *__restrict__ prod, unsigned gbeg, unsigned gend)
 {
-  __shared__ double ytile[RM];
+  __shared__ double xband[BC + 8];
+  // this launch covers the groups gbeg .. gend (everything, or the bands whose part of x has arrived: fs_spmv_host)
+  const uint64_t groups = gend - gbeg;
+  const unsigned g0 = gbeg + (unsigned)(groups * blockIdx.x / gridDim.x), g1 = gbeg + (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
+  expand_share<VALUED, U, NTLD, NTST, BC>(xband, ncol, B, band_ptr, lcol, vals, gdst, x, xs, prod, g0, g1);
+}
+
+// pass 2: workgroup = one row panel; its products are contiguous.  ytile: the panel's slice of y in LDS.
+template <bool NTLD>
+__device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int panel, const unsigned *__restrict__ bin_ptr,
+                                             const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
+                                             const double *__restrict__ prod, double *__restrict__ y, int ys)
+{
   const int t = threadIdx.x;
-  const int panel = pbase + blockIdx.x;
   const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
   for (int i = t; i < nr; i += kBinBlock) ytile[i] = 0.0;
   __syncthreads();
   const int64_t e0 = (int64_t)bin_ptr[panel] * kBinGroup, e1 = (int64_t)bin_ptr[panel + 1] * kBinGroup;
   // 8 entries (64 bytes of products) per lane and step, two steps in flight in whole rounds (straight-line code:
-  // see spmv_expand_kernel); the last, partial round is guarded
+  // see expand_share); the last, partial round is guarded
 #define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define FS_ADD8(A, P)                                                  \
   FS_ADD(A.x & 0xffffu, P[0].x); FS_ADD(A.x >> 16, P[0].y);            \
@@ -1235,6 +1243,19 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
   for (int i = t; i < nr; i += kBinBlock) y[(int64_t)(r0 + i) * ys] = ytile[i];
 }
 
+template <bool NTLD, int RM = kBinRowsMax>
+__global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
+    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
+    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
+{
+  __shared__ double ytile[RM];
+  reduce_panel<NTLD>(ytile, pbase + blockIdx.x, bin_ptr, panel_row, lrow, prod, y, ys);
+}
+
+// (Both passes in ONE persistent launch behind a device-wide arrival counter were built and measured in round 3 and withdrawn:
+// on config 2 the single launch took 1.13 ms against 0.857 ms for the pair -- every wave's agent-scope release is a
+// buffer_wbl2 over the XCD's whole L2 -- and the kernel trace shows there is nothing to win: pass 2 starts 0.0 us after pass 1
+// ends, the next product 9 us after that (profiles/r03_gap_probe.jsonl, r03_kernel_gaps.txt).)
 
 // ------------------------------------------------------------------------------------------
 // Y = A X for K = 2 or 4 row-major right-hand sides in ONE sweep of a two-pass copy built with bands of
