@@ -126,6 +126,19 @@ int  fs_matrix_download(fs_matrix_t A, int transposed, int *row_ptr, int *cols, 
 int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
 /* y[ncol] = A' x[nrow]          (At_mul_B / sdm_At_mul_B; CSR At_mul_B of BASELINE config 2) */
 int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
+/* The same product in nparts parts (1..64), for callers that ship finished rows while the rest still computes -- the
+ * all-gather of the y shards of a row-sharded product overlapped with the product (csr.h:429: the row loop that shards).
+ * Call with part = 0 .. nparts-1 in order on ONE stream; once the stream has passed part p, rows [rows[p], rows[p+1]) of y
+ * are final, where rows[0 .. nparts] comes from fs_spmv_part_rows (fixed for a handle, nparts and the current options:
+ * the product is cut where its kernel finishes rows anyway -- panels of pass 2 of the two-pass pair, generations of
+ * workgroups of the tiled kernels; a kernel that cannot be cut does everything with part 0 and reports rows = {0, nrow,
+ * nrow, ...}).  All parts together are exactly fs_spmv / fs_spmv_t. */
+int fs_spmv_part_rows(fs_matrix_t A, int transposed, int nparts, int *rows /* nparts + 1 */);
+int fs_spmv_part(fs_matrix_t A, int transposed, double *y, const double *x, int part, int nparts, fs_stream_t stream);
+/* dst[dst_off[i] + j] = src[src_off[i] + j] for j < count[i], i < nseg, in one launch; table_dev = int64[3 * nseg] in HBM:
+ * dst_off[nseg], src_off[nseg], count[nseg]; max_count = the largest count (sizes the grid).  Unpacks the padded receive
+ * buffer of an all-gather of unequal y shards. */
+int fs_copy_segments(int nseg, const int64_t *table_dev, int64_t max_count, const double *src, double *dst, fs_stream_t stream);
 /* Y[nrow,k] = A X[ncol,k], X and Y row-major  (csr_A_mul_Bn, bcsr_A_mul_B2..._B32n, bsbm_A_mul_B2/_B4/_Bn).
  * Stream-ordered like fs_spmv: a product never builds a copy and never waits for the device.  What a given k can use
  * beyond the copies made at creation -- the k-column two-pass copy (k = 2..4), the measured choice between one sweep per

@@ -255,12 +255,7 @@ int fs_matrix_has_transpose(fs_matrix_t A) { return A && A->has_t; }
 int fs_matrix_spmv_kernel(fs_matrix_t A, int transposed)
 {
   if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
-  const fs::DeviceCsr &a = transposed ? A->at : A->a;
-  const fs::Options &o = fs::options();
-  if (!o.strict_order && !o.reproducible && a.binned && a.binned->built && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
-  if (!o.strict_order && !o.reproducible && a.tiledx && a.tiledx->built && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
-  if (!o.strict_order && a.tiled && a.tiled->built && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
-  return o.spmv_kernel == 2 ? 2 : 1;
+  return fs::spmv_choice(transposed ? A->at : A->a, fs::options());
 }
 
 int fs_matrix_candidate_ms(fs_matrix_t A, int transposed, float *ms4)
@@ -306,6 +301,35 @@ int fs_spmv(fs_matrix_t A, double *y, const double *x, fs_stream_t stream)
   std::lock_guard<std::mutex> g(A->lock);
   A->last_stream = (hipStream_t)stream; A->last_async = true;
   return fs::launch_spmv(A->a, y, x, (hipStream_t)stream);
+}
+
+// y = A x (transposed != 0: A' x) in nparts parts: see include/fastsparse_hip.h and launch_spmv_part
+int fs_spmv_part_rows(fs_matrix_t A, int transposed, int nparts, int *rows)
+{
+  if (!A || !rows || nparts < 1 || nparts > 64) { set_error("fs_spmv_part_rows: bad argument (1 <= nparts <= 64)"); return FS_ERR_ARG; }
+  if (transposed && !A->has_t) { set_error("fs_spmv_part_rows: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  const int *r = nullptr;
+  if (int rc = fs::spmv_part_bounds(transposed ? A->at : A->a, nparts, &r, nullptr)) return rc;
+  for (int p = 0; p <= nparts; ++p) rows[p] = r[p];
+  return FS_OK;
+}
+
+int fs_spmv_part(fs_matrix_t A, int transposed, double *y, const double *x, int part, int nparts, fs_stream_t stream)
+{
+  FS_RANGE("fs_spmv_part");
+  if (int rc = check_mul(A, y, x, "fs_spmv_part")) return rc;
+  if (nparts < 1 || nparts > 64 || part < 0 || part >= nparts) { set_error("fs_spmv_part: bad part"); return FS_ERR_ARG; }
+  if (transposed && !A->has_t) { set_error("fs_spmv_part: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  A->last_stream = (hipStream_t)stream; A->last_async = true;
+  return fs::launch_spmv_part(transposed ? A->at : A->a, y, x, part, nparts, (hipStream_t)stream);
+}
+
+int fs_copy_segments(int nseg, const int64_t *table_dev, int64_t max_count, const double *src, double *dst, fs_stream_t stream)
+{
+  if (nseg < 0 || (nseg > 0 && (!table_dev || !src || !dst))) { set_error("fs_copy_segments: bad argument"); return FS_ERR_ARG; }
+  return fs::launch_copy_segments(nseg, table_dev, max_count, src, dst, (hipStream_t)stream);
 }
 
 // ---- diagnostics (not part of include/fastsparse_hip.h; used by tools/trace_tiled.py and the tests) --------

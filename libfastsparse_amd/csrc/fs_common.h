@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "fastsparse_hip.h"
 
@@ -49,6 +50,10 @@ struct DeviceCsr {
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
+  // products in parts (spmv_part_bounds): the cuts computed last, for part_n parts of the kernel part_kind
+  int part_n = 0, part_kind = 0;
+  bool part_cut = false;
+  std::vector<int> part_rows, part_units;
 };
 
 // L2-tiled copy of a CSR for the column-band kernel (see DESIGN.md "spmv_tiled_kernel").
@@ -249,6 +254,10 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);
 int prepare_spmm(DeviceCsr &A, int k, hipStream_t s);   // k-column copy, scratch, measured choice: synchronous, idempotent
 int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare);   // which kernel launch_spmm runs for this k (kPlan* in fs_kernels.hip)
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
+int spmv_choice(const DeviceCsr &A, const Options &o);   // 7 two-pass, 8 LDS-staged, 6 L2-tiled, 2 lanes per row, 1 chunk-streaming
+int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out);
+int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int nparts, hipStream_t s);
+int launch_copy_segments(int nseg, const int64_t *tab_dev, int64_t max_count, const double *src, double *dst, hipStream_t s);
 int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
 // y_host = A x_host: copies and kernels overlapped where the kept copy allows it (two-pass copy without cut rows)
 int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const double *x_host);
@@ -264,7 +273,8 @@ int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heur
 int build_binned_k(DeviceCsr &A, int kw, hipStream_t s);   // the k-column copy (kw = 2 or 4) into A.binned2 / A.binned4
 int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys);
 int choose_copy(DeviceCsr &A, hipStream_t s);       // times the candidates and keeps the fastest copy
-int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1);
+int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1, int p0 = 0,
+                       int p1 = -1, int row0 = 0, int row1 = 0);   // p1 >= 0: pass 2 for panels p0 .. p1 only (pass 1 with p0 == 0)
 int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
                             hipStream_t s);
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,

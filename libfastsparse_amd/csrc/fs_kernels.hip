@@ -29,6 +29,7 @@
 //   cbcsr_kernel         column-blocked binary CSR, x tile staged in LDS per column block
 #include <stdlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -1435,9 +1436,10 @@ static int ceil_log2(int v)
 // walking 3 900 dependent loads made this pass 0.49 ms of a 2.9 ms product on a config-5 shard
 // (profiles/r02_c5_pmc_summary.csv).
 __global__ __launch_bounds__(kBlock) void tiled_combine_kernel(int nrow, const int *__restrict__ vfirst,
-                                                              const double *__restrict__ yv, double *__restrict__ y, int ys)
+                                                              const double *__restrict__ yv, double *__restrict__ y, int ys,
+                                                              int row0 = 0)
 {
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t r = (int64_t)row0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;   // rows row0 .. nrow of this launch
   const int lane = threadIdx.x & 63;
   int a = 0, b = 0;
   if (r < nrow) { a = vfirst[r]; b = vfirst[r + 1]; }
@@ -1532,13 +1534,18 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
   return FS_OK;
 }
 
-int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys)
+// p0 .. p1: the panels pass 2 covers in this launch (p1 < 0: all of them); pass 1 runs when p0 == 0.  With cut rows the
+// combine pass covers rows row0 .. row1 (the rows whose last piece lies in a panel below p1: see spmv_part_bounds).
+int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys, int p0, int p1, int row0,
+                       int row1)
 {
   const BinnedCsr &N = *A.binned;
   double *out = N.split ? N.yv : y;              // cut rows: virtual sums first, combined below
   const int os = N.split ? 1 : ys;
+  const bool part = p1 >= 0;
+  if (!part) { p0 = 0; p1 = N.P; row0 = 0; row1 = A.nrow; }
   const int nwg1 = (options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1;
-  if (nwg1 > 0) {
+  if (nwg1 > 0 && p0 == 0) {
     // tuning switches (A/B runs): bits 0-1 pass-1 unroll (1: 8, 2: 2 steps; default 4), bit 2 pass-2 loads
     // non-temporal, bit 3 pass-1 stores plain, bit 4 pass-1 loads non-temporal.  Defaults, measured on config 2
     // (valued / pattern-only, ms per product): plain loads in both passes and non-temporal stores 0.95 / 0.69;
@@ -1566,20 +1573,116 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
 #undef FS_EXPAND
     FS_HIP(hipGetLastError());
   }
-  if (N.bcols == kBinColsBig)
-    hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow,
-                       N.prod, out, os, 0);
-  else if (options().bin_flags & 4)
-    hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, 0);
-  else
-    hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, 0);
-  FS_HIP(hipGetLastError());
-  if (N.split) {
-    hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       A.nrow, N.vfirst, N.yv, y, ys);
+  if (p1 > p0) {
+    if (N.bcols == kBinColsBig)
+      hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row,
+                         N.lrow, N.prod, out, os, p0);
+    else if (options().bin_flags & 4)
+      hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
+                         out, os, p0);
+    else
+      hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
+                         out, os, p0);
+    FS_HIP(hipGetLastError());
+  }
+  if (N.split && row1 > row0) {
+    hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)(row1 - row0) + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       row1, N.vfirst, N.yv, y, ys, row0);
     FS_HIP(hipGetLastError());
   }
   return FS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// y = A x in parts, for callers that ship finished rows while the rest still computes: the all-gather of the y shards of
+// a row-sharded product overlapped with the product itself ("chunk rows, launch all-gather of finished
+// chunks while later chunks compute").  The product is cut where its kernel finishes rows anyway:
+//   two-pass copy      pass 1 as a whole with part 0, pass 2 (one workgroup per row panel) in ranges of panels; with cut
+//                      rows the combine pass follows in ranges of rows (a row is final once its last piece's panel is done)
+//   L2-tiled / LDS-staged copy whose workgroups own their rows: ranges of whole generations of resident workgroups
+//   anything else      (chunk-streaming kernel, chunks sharing panels, strict_order): everything with part 0
+// spmv_part_bounds gives the row cuts rows[0 .. nparts] (rows [rows[p], rows[p+1]) are final after part p) and the unit
+// cuts (panels / workgroups) for a given nparts; cached per handle.
+// ------------------------------------------------------------------------------------------
+int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out)
+{
+  const Options &o = options();
+  const int kind = spmv_choice(A, o);
+  if (A.part_n == nparts && A.part_kind == kind && !A.part_rows.empty()) {
+    *rows_out = A.part_rows.data(); if (units_out) *units_out = A.part_units.data();
+    return FS_OK;
+  }
+  std::vector<int> rows((size_t)nparts + 1, A.nrow), units((size_t)nparts + 1, 0);
+  rows[0] = 0;
+  bool cut = false;
+  if (kind == 7 && A.binned->nwg1 > 0 && nparts > 1 && A.binned->P >= nparts) {
+    BinnedCsr &N = *A.binned;
+    if (!N.h_panel_row) {
+      int *hp = (int *)malloc(sizeof(int) * ((size_t)N.P + 1));
+      if (!hp) { set_error("out of host memory"); return FS_ERR_HIP; }
+      const hipError_t e = hipMemcpy(hp, N.panel_row, sizeof(int) * ((size_t)N.P + 1), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { free(hp); return hip_fail(e, "hipMemcpy(panel_row)", __FILE__, __LINE__); }
+      N.h_panel_row = hp;
+    }
+    std::vector<int> vfirst;
+    if (N.split) {
+      vfirst.resize((size_t)A.nrow + 1);
+      FS_HIP(hipMemcpy(vfirst.data(), N.vfirst, sizeof(int) * vfirst.size(), hipMemcpyDeviceToHost));
+    }
+    for (int p = 0; p <= nparts; ++p) {
+      units[(size_t)p] = (int)((int64_t)N.P * p / nparts);
+      const int vcut = N.h_panel_row[units[(size_t)p]];
+      // cut rows: the rows whose every piece lies below the virtual row vcut
+      rows[(size_t)p] = !N.split ? vcut : p == nparts ? A.nrow :
+                        (int)(std::upper_bound(vfirst.begin(), vfirst.end(), vcut) - vfirst.begin()) - 1;
+    }
+    cut = true;
+  } else if ((kind == 8 || kind == 6) && nparts > 1) {
+    TiledCsr &M = kind == 8 ? *A.tiledx : *A.tiled;
+    if (!M.split && !(M.ldsx && M.shared)) {
+      if (!M.h_panel_row) {
+        int *hp = (int *)malloc(sizeof(int) * ((size_t)M.P + 1));
+        int *hc = (int *)malloc(sizeof(int) * (size_t)(M.nchunks > 0 ? M.nchunks : 1));
+        if (!hp || !hc) { free(hp); free(hc); set_error("out of host memory"); return FS_ERR_HIP; }
+        hipError_t e = hipMemcpy(hp, M.panel_row, sizeof(int) * ((size_t)M.P + 1), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && M.ldsx && M.nchunks > 0)
+          e = hipMemcpy(hc, M.chunk_panel, sizeof(int) * (size_t)M.nchunks, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(hp); free(hc); return hip_fail(e, "hipMemcpy(panel tables)", __FILE__, __LINE__); }
+        M.h_panel_row = hp; M.h_chunk_panel = hc;
+      }
+      const int nwg = M.P;
+      bool own = !M.ldsx || M.nchunks == M.P;      // workgroup w owns panel w
+      for (int w = 0; own && M.ldsx && w < nwg; ++w) own = M.h_chunk_panel[w] == w;
+      const int slots = M.slots > 0 ? M.slots : 256;
+      const int gens = (nwg + slots - 1) / slots;
+      if (own && gens >= 2) {
+        // one workgroup per CU and launches of one stream run one after the other: a part is a whole number of generations
+        const int c = nparts < gens ? nparts : gens;
+        for (int p = 0; p <= nparts; ++p) {
+          const int64_t w = p >= c ? nwg : (int64_t)slots * ((int64_t)gens * p / c);
+          units[(size_t)p] = (int)(w < nwg ? w : nwg);
+          rows[(size_t)p] = M.h_panel_row[units[(size_t)p]];
+        }
+        cut = true;
+      }
+    }
+  }
+  if (!cut) units.assign((size_t)nparts + 1, 0);    // everything with part 0: rows = {0, nrow, nrow, ...}
+  A.part_n = nparts; A.part_kind = kind; A.part_cut = cut;
+  A.part_rows.swap(rows); A.part_units.swap(units);
+  *rows_out = A.part_rows.data(); if (units_out) *units_out = A.part_units.data();
+  return FS_OK;
+}
+
+int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int nparts, hipStream_t s)
+{
+  if (A.nrow == 0) return FS_OK;
+  const int *rows = nullptr, *units = nullptr;
+  if (int rc = spmv_part_bounds(A, nparts, &rows, &units)) return rc;
+  if (!A.part_cut) return part == 0 ? launch_spmv(A, y, x, s) : FS_OK;
+  if (A.part_kind == 7) return launch_spmv_binned(A, y, x, s, 1, 1, units[part], units[part + 1], rows[part], rows[part + 1]);
+  if (units[part + 1] <= units[part]) return FS_OK;
+  return launch_spmv_tiled(A, A.part_kind == 8 ? *A.tiledx : *A.tiled, y, x, s, 1, 1, units[part], units[part + 1]);
 }
 
 // one sweep of a k-column two-pass copy: Y[:, 0:kw] = A X[:, 0:kw]; X / Y rows are xs / ys doubles apart
@@ -1654,20 +1757,29 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
   return FS_OK;
 }
 
+// which kernel a single-vector product on A runs under the options o: 7 two-pass, 8 LDS-staged, 6 L2-tiled, 2 lanes per
+// row, 1 chunk-streaming.  The copy the format builder kept unless the caller asked for storage-order (strict_order) or
+// run-to-run identical (reproducible) sums, which the kernels that add in arrival order cannot give.
+int spmv_choice(const DeviceCsr &A, const Options &o)
+{
+  if (A.binned && A.binned->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
+  if (A.tiledx && A.tiledx->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
+  if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
+  return o.spmv_kernel == 2 ? 2 : 1;
+}
+
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream)
 {
   if (A.nrow == 0) return FS_OK;
   Options o = options();
   if (force_stream) o.spmv_kernel = 1;
   const bool valued = A.vals != nullptr;
-  // auto: the L2-tiled copy when it was built (format builder decided it pays) and the caller did not
-  // ask for storage-order sums
-  if (A.binned && A.binned->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7))
-    return launch_spmv_binned(A, y, x, s);
-  if (A.tiledx && A.tiledx->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8))
-    return launch_spmv_tiled(A, *A.tiledx, y, x, s);
-  if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6))
-    return launch_spmv_tiled(A, *A.tiled, y, x, s);
+  switch (spmv_choice(A, o)) {
+    case 7: return launch_spmv_binned(A, y, x, s);
+    case 8: return launch_spmv_tiled(A, *A.tiledx, y, x, s);
+    case 6: return launch_spmv_tiled(A, *A.tiled, y, x, s);
+    default: break;
+  }
   // "reproducible" / "strict_order" set AFTER the matrix was created leave its kept copy unusable: the product then runs on
   // the chunk-streaming kernel (correct, but slow on large matrices).  Said once under FS_TRACE_BUILD.
   if ((o.reproducible || o.strict_order) && o.spmv_kernel == 0 && ((A.binned && A.binned->built) || (A.tiledx && A.tiledx->built))) {
@@ -1903,6 +2015,7 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
     hipError_t e = hipMemcpy(hb, N.band_ptr, sizeof(unsigned) * ((size_t)N.B + 1), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(hp, N.panel_row, sizeof(int) * ((size_t)N.P + 1), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { free(hb); free(hp); return hip_fail(e, "hipMemcpy(two-pass tables)", __FILE__, __LINE__); }
+    free(N.h_panel_row);                         // products in parts may have fetched it already
     N.h_band_ptr = hb; N.h_panel_row = hp;
   }
   const int nwg1 = (o.bin_wgs > 0 && o.bin_wgs < N.nwg1) ? o.bin_wgs : N.nwg1;
@@ -1947,6 +2060,26 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
     FS_HIP(hipEventSynchronize(H.ev[j]));
     if (r1 > r0) FS_HIP(hipMemcpy(y_host + r0, H.sy + r0, sizeof(double) * (size_t)(r1 - r0), hipMemcpyDeviceToHost));
   }
+  return FS_OK;
+}
+
+// dst[dst_off[i] + j] = src[src_off[i] + j], j < count[i], for nseg segments: blockIdx.y = segment.  Unpacks the padded
+// receive buffer of an all-gather of unequal shards (or parts of shards) into y with ONE launch.
+__global__ __launch_bounds__(kBlock) void copy_segments_kernel(int nseg, const int64_t *__restrict__ tab, const double *__restrict__ src,
+                                                               double *__restrict__ dst)
+{
+  const int sgm = blockIdx.y;
+  const int64_t d0 = tab[sgm], s0 = tab[nseg + sgm], n = tab[2 * nseg + sgm];
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) dst[d0 + j] = src[s0 + j];
+}
+
+int launch_copy_segments(int nseg, const int64_t *tab_dev, int64_t max_count, const double *src, double *dst, hipStream_t s)
+{
+  if (nseg <= 0 || max_count <= 0) return FS_OK;
+  int64_t gx = (max_count + kBlock - 1) / kBlock;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)gx, (unsigned)nseg), dim3(kBlock), 0, s, nseg, tab_dev, src, dst);
+  FS_HIP(hipGetLastError());
   return FS_OK;
 }
 

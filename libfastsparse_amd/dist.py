@@ -28,14 +28,16 @@ class _Done:
 
 
 class _Then:
-    """handle of an asynchronous collective followed by device work (e.g. unpacking a padded gather buffer):
-    wait() orders the current stream after the collective, then enqueues `after()` on it"""
+    """handle of one or several asynchronous collectives followed by device work (e.g. unpacking a padded gather
+    buffer): wait() orders the current stream after the collectives, then enqueues `after()` on it"""
 
     def __init__(self, work, after):
-        self.work, self.after = work, after
+        self.works = list(work) if isinstance(work, (list, tuple)) else [work]
+        self.after = after
 
     def wait(self):
-        self.work.wait()
+        for w in self.works:
+            w.wait()
         self.after()
         return True
 
@@ -97,17 +99,66 @@ def nnz_balanced_partition(row_ptr, world):
     return bounds
 
 
+def copy_segments_torch(dst, src, dst_off, src_off, counts):
+    """dst[dst_off[i] : +counts[i]] = src[src_off[i] : +counts[i]] -- the portable unpack (CPU tests; the HIP provider
+    injects fs_copy_segments: one launch for all segments)"""
+    for d, s_, c in zip(dst_off, src_off, counts):
+        if c:
+            dst[d:d + c] = src[s_:s_ + c]
+
+
+class EvenParts:
+    """local product in parts for backends that cannot cut a product (the oracle in the CPU tests): everything is
+    computed with part 0, and the rows are reported final in `nparts` even ranges only as their part comes up -- the
+    exchange logic above it sees the same protocol as with a kernel that really finishes rows range by range"""
+
+    def __init__(self, local_spmv, nrow_local):
+        self.local_spmv, self.n = local_spmv, nrow_local
+
+    def rows(self, nparts):
+        return [self.n * p // nparts for p in range(nparts + 1)]
+
+    def run(self, y_local, x_full, part, nparts):
+        if part == 0:
+            self.local_spmv(y_local, x_full)
+
+
+class HipParts:
+    """local product in parts on the HIP C-ABI (fs_spmv_part: pass 2 of the two-pass pair in ranges of panels, the
+    tiled kernels in generations of workgroups); `matrix` is a capi.Matrix"""
+
+    def __init__(self, matrix, transposed=False, stream_fn=None):
+        from . import capi
+        self.m, self.t, self.capi, self.stream_fn = matrix, transposed, capi, stream_fn
+
+    def rows(self, nparts):
+        return self.m.part_rows(nparts, transposed=self.t)
+
+    def run(self, y_local, x_full, part, nparts):
+        st = self.stream_fn() if self.stream_fn else self.capi.current_stream()
+        self.m.spmv_part(y_local, x_full, part, nparts, st, transposed=self.t)
+
+
 class ShardedOperator:
     """y = A x with rows [bounds[rank], bounds[rank+1]) of A on this rank.
 
     apply(y_full, x_full): local product into this rank's slice, then all-gather of the slices.
     Unequal shards are gathered through a padded buffer (RCCL's all-gather wants equal counts).
+    apply_overlapped(y_full, x_full, nparts): the exchange INSIDE the product -- the local product runs in parts
+    (`parts`: HipParts / EvenParts) and the all-gather of the rows part p has finished is started while part p + 1
+    computes ("communication ~ compute and must be overlapped (chunk rows ...)"); what the iterating
+    consumer needs, whose next product cannot start before y is complete (cg.h:15-16: y of A x is the x of A').
+    `k`: doubles per row (k right-hand sides, row-major).
     """
 
-    def __init__(self, local_spmv, bounds, group=None):
+    def __init__(self, local_spmv, bounds, group=None, parts=None, k=1, copy_segments=None):
         self.local_spmv = local_spmv
         self.bounds = list(bounds)
         self.group = group
+        self.parts = parts
+        self.k = k
+        self.copy_segments = copy_segments or copy_segments_torch
+        self._plan = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         assert len(self.bounds) == self.world + 1
@@ -125,9 +176,10 @@ class ShardedOperator:
 
     def _buffers(self, like):
         if self._y_local is None or self._y_local.device != like.device:
-            self._y_local = torch.empty(self.max_rows, dtype=like.dtype, device=like.device)
+            # twice the largest shard: the send window of a part may run past the end of the shard (padded counts)
+            self._y_local = torch.empty(2 * self.max_rows * self.k, dtype=like.dtype, device=like.device)
             if not self.equal:
-                self._pad = torch.empty(self.max_rows * self.world, dtype=like.dtype, device=like.device)
+                self._pad = torch.empty(self.max_rows * self.world * self.k, dtype=like.dtype, device=like.device)
         return self._y_local
 
     def apply_local(self, y_local, x_full):
@@ -140,7 +192,7 @@ class ShardedOperator:
             self.local_spmv(y_full, x_full)
             return y_full
         y_local = self._buffers(y_full)
-        self.local_spmv(y_local[:n_local], x_full)
+        self.local_spmv(y_local[:n_local * self.k], x_full)
         return y_local
 
     def gather(self, y_full, y_local):
@@ -149,16 +201,16 @@ class ShardedOperator:
             return y_full
         n_local = self.hi - self.lo
         if self.equal:
-            all_gather_into(y_full, y_local[:n_local], self.group)
+            all_gather_into(y_full, y_local[:n_local * self.k], self.group)
         else:
-            all_gather_into(self._pad, y_local, self.group)
+            all_gather_into(self._pad, y_local[:self.max_rows * self.k], self.group)
             self._unpack(y_full)
         return y_full
 
     def _unpack(self, y_full):
-        for r in range(self.world):
-            y_full[self.bounds[r]:self.bounds[r + 1]] = \
-                self._pad[r * self.max_rows: r * self.max_rows + self.sizes[r]]
+        k, m = self.k, self.max_rows
+        self.copy_segments(y_full, self._pad, [self.bounds[r] * k for r in range(self.world)],
+                           [r * m * k for r in range(self.world)], [self.sizes[r] * k for r in range(self.world)])
 
     def gather_async(self, y_full, y_local):
         """start the exchange step and return a handle whose wait() leaves y_full complete on the current stream.
@@ -168,12 +220,60 @@ class ShardedOperator:
         if self.world == 1:
             return _Done()
         if self.equal:
-            return all_gather_into_async(y_full, y_local[:self.hi - self.lo], self.group)
-        work = all_gather_into_async(self._pad, y_local, self.group)
+            return all_gather_into_async(y_full, y_local[:(self.hi - self.lo) * self.k], self.group)
+        work = all_gather_into_async(self._pad, y_local[:self.max_rows * self.k], self.group)
         return _Then(work, lambda: self._unpack(y_full))
 
     def apply(self, y_full, x_full):
         return self.gather(y_full, self.local(y_full, x_full))
+
+    # ---- the exchange inside the product ---------------------------------------------------------------------
+    def _part_plan(self, nparts, like):
+        """once per nparts: every rank's row cuts (exchanged), the padded count of every part, the unpack table"""
+        key = (nparts, like.device)
+        if key in self._plan:
+            return self._plan[key]
+        mine = [int(v) for v in self.parts.rows(nparts)]
+        cuts = [None] * self.world
+        dist.all_gather_object(cuts, mine, group=self.group)
+        k = self.k
+        maxc = [max(cuts[r][p + 1] - cuts[r][p] for r in range(self.world)) for p in range(nparts)]
+        off = [0]
+        for p in range(nparts):
+            off.append(off[-1] + self.world * maxc[p] * k)
+        dst, src, cnt = [], [], []
+        for p in range(nparts):
+            for r in range(self.world):
+                c = cuts[r][p + 1] - cuts[r][p]
+                if c:
+                    dst.append((self.bounds[r] + cuts[r][p]) * k)
+                    src.append(off[p] + r * maxc[p] * k)
+                    cnt.append(c * k)
+        plan = {"mine": mine, "maxc": maxc, "off": off, "dst": dst, "src": src, "cnt": cnt,
+                "pad": torch.empty(max(off[-1], 1), dtype=like.dtype, device=like.device)}
+        self._plan[key] = plan
+        return plan
+
+    def apply_overlapped_async(self, y_full, x_full, nparts=4):
+        """local product in `nparts` parts; the all-gather of part p's rows is started as soon as part p is enqueued and
+        runs under parts p + 1 ...; returns a handle whose wait() leaves y_full complete on the current stream"""
+        if self.world == 1 or self.parts is None or nparts <= 1:
+            return self.gather_async(y_full, self.local(y_full, x_full))
+        y_local = self._buffers(y_full)
+        plan = self._part_plan(nparts, y_full)
+        k, n_local = self.k, self.hi - self.lo
+        works = []
+        for p in range(nparts):
+            self.parts.run(y_local[:n_local * k], x_full, p, nparts)
+            c = plan["maxc"][p]
+            if c:
+                a = plan["mine"][p] * k
+                works.append(all_gather_into_async(plan["pad"][plan["off"][p]:plan["off"][p + 1]], y_local[a:a + c * k], self.group))
+        return _Then(works, lambda: self.copy_segments(y_full, plan["pad"], plan["dst"], plan["src"], plan["cnt"]))
+
+    def apply_overlapped(self, y_full, x_full, nparts=4):
+        self.apply_overlapped_async(y_full, x_full, nparts).wait()
+        return y_full
 
 
 def all_reduce_sum(t, group=None):
@@ -285,6 +385,132 @@ def exchange_transpose_entries(rows_global, cols_global, vals, col_bounds, group
     at_cols = xchg(rows_global)
     at_vals = None if vals is None else xchg(vals)
     return at_rows, at_cols, at_vals
+
+
+class ShardedCG:
+    """(A'A + lambda I) x = b on a row-sharded A: bsbm_cg (cg.h:25-82) and, for two right-hand sides, bsbm_cg2
+    (cg.h:85-187), the consumers that ITERATE on the path (y of A x is the x of A', cg.h:15-16, 134-135).
+
+    scheme "gather" (both directions are "rows + all-gather"): op_a = ShardedOperator on the rows of A, op_t =
+        ShardedOperator on the rows of A' this rank owns (= its slice of the F unknowns).  Every rank keeps its SLICE of
+        x, r, p, q; per iteration: y = A p (local rows, all-gather inside the product: apply_overlapped), q_r = A'_r y +
+        lambda p_r (no exchange), the dots as all-reduces of 1 (k = 1) or 3 (k = 2) doubles, the updates on the slices,
+        and the all-gather of the new p.  Moves N + F doubles per right-hand side and iteration.
+    scheme "reduce": op_t = TransposedShardedOperator (every rank multiplies the transpose of its own rows; an
+        all-reduce sums the full-length partials).  x, r, p, q are replicated, so the dots need no exchange and equal
+        the one-GPU solver's.  Moves 2 F doubles per right-hand side and iteration, nothing of length N: the scheme for
+        tall matrices (config 3's shape).
+    Vector algebra is torch (device-agnostic: RCCL ranks and the gloo CPU tests run the same code); products are the
+    injected local kernels."""
+
+    def __init__(self, op_a, op_t, scheme="gather", nparts=4, group=None):
+        assert scheme in ("gather", "reduce")
+        self.op_a, self.op_t, self.scheme, self.nparts, self.group = op_a, op_t, scheme, nparts, group
+        self.k = op_a.k
+        self.world = op_a.world
+
+    def _sum(self, t):
+        """sum over the ranks of a few partial dots"""
+        if self.world > 1:
+            all_reduce_sum(t, self.group)
+        return t
+
+    def _dots(self, X, Y, n):
+        """k = 1: [x.y]; k = 2: [a.a', b.b', a.b'] of the row-major two-column X with Y (linalg.h:61-73)"""
+        if self.k == 1:
+            return torch.stack([torch.dot(X, Y)])
+        X2, Y2 = X.view(n, 2), Y.view(n, 2)
+        return torch.stack([torch.dot(X2[:, 0], Y2[:, 0]), torch.dot(X2[:, 1], Y2[:, 1]), torch.dot(X2[:, 0], Y2[:, 1])])
+
+    @staticmethod
+    def _solve2sym(A, rhs):
+        """linalg.h:77-88 on host floats: A = [a00, a11, a01] symmetric, rhs row-major 2 x 2"""
+        dinv = 1.0 / (A[0] * A[1] - A[2] * A[2])
+        i0, i1, i2 = dinv * A[1], dinv * A[0], -dinv * A[2]
+        return [i0 * rhs[0] + i2 * rhs[1], i2 * rhs[0] + i1 * rhs[1], i0 * rhs[2] + i2 * rhs[3], i2 * rhs[2] + i1 * rhs[3]]
+
+    def solve(self, b_full, lam, tol, max_iter=None):
+        """b_full: the whole right-hand side (F, or F x 2 row-major, flat) on every rank.  Returns (x_full, iterations);
+        x_full is complete on every rank."""
+        k, op_a, op_t = self.k, self.op_a, self.op_t
+        F = b_full.numel() // k
+        N = op_a.nrow
+        gather = self.scheme == "gather"
+        lo, hi = (op_t.lo, op_t.hi) if gather else (0, F)
+        n = hi - lo
+        dev, dt = b_full.device, b_full.dtype
+        bl = b_full[lo * k:hi * k]
+        y_full = torch.empty(N * k, dtype=dt, device=dev)
+        p_full = torch.empty(F * k, dtype=dt, device=dev)
+        x = torch.zeros(n * k, dtype=dt, device=dev)
+        if k == 1:
+            r = bl.clone()
+            norms = None
+        else:
+            nb = [float(v) for v in self._sum(self._dots(bl, bl, n)[:2].clone()).sqrt().cpu()] if gather else \
+                 [float(v) for v in self._dots(bl, bl, n)[:2].sqrt().cpu()]
+            norms = torch.tensor(nb, dtype=dt, device=dev)
+            r = (bl.view(n, 2) / norms).reshape(-1)
+        p = r.clone()
+
+        def red(t):
+            return [float(v) for v in (self._sum(t) if gather else t).cpu()]
+
+        rr = red(self._dots(r, r, n))
+        stop = tol * (rr[0] ** 0.5) if k == 1 else tol * tol
+        q = torch.empty(n * k, dtype=dt, device=dev)
+        q_gather_buf = None
+        it = 0
+        max_iter = F if max_iter is None else max_iter
+        while it < max_iter:
+            # p on every rank (gather: the slices are all-gathered; reduce: it is replicated already)
+            if gather and self.world > 1:
+                pl = op_t._buffers(p_full)
+                pl[:n * k] = p
+                op_t.gather(p_full, pl)
+            else:
+                p_full[:] = p
+            if gather:
+                op_a.apply_overlapped(y_full, p_full, self.nparts)      # y = A p, exchange inside the product
+                op_t.local_spmv(q, y_full)                               # q_r = A'_r y
+            else:
+                t_local = op_a.local(y_full, p_full)                     # rows of this rank only: nothing of length N moves
+                nl = op_a.hi - op_a.lo
+                op_t.local_tspmv(q, t_local[:nl * k] if op_a.world > 1 else y_full)
+                op_t.reduce(q)
+            q.add_(p, alpha=lam)
+            if k == 1:
+                alpha = rr[0] / red(self._dots(p, q, n))[0]
+                x.add_(p, alpha=alpha)
+                r.add_(q, alpha=-alpha)
+                rr2 = red(self._dots(r, r, n))
+                if rr2[0] ** 0.5 <= stop:
+                    break
+                p.mul_(rr2[0] / rr[0]).add_(r)
+            else:
+                ptkp = red(self._dots(p, q, n))
+                al = self._solve2sym(ptkp, [rr[0], rr[2], rr[2], rr[1]])
+                P2, Q2, X2, R2 = p.view(n, 2), q.view(n, 2), x.view(n, 2), r.view(n, 2)
+                M = torch.tensor([[al[0], al[2]], [al[1], al[3]]], dtype=dt, device=dev)   # X += P M: row i gets [a0 p0 + a1 p1, a2 p0 + a3 p1]
+                X2.add_(P2 @ M)
+                R2.sub_(Q2 @ M)
+                rr2 = red(self._dots(r, r, n))
+                if rr2[0] <= stop and rr2[1] <= stop:
+                    break
+                ps = self._solve2sym(rr, [rr2[0], rr2[2], rr2[2], rr2[1]])
+                Mp = torch.tensor([[ps[0], ps[2]], [ps[1], ps[3]]], dtype=dt, device=dev)
+                P2.copy_(R2 + P2 @ Mp)
+            rr = rr2
+            it += 1
+        if k == 2:
+            x = (x.view(n, 2) * norms).reshape(-1)
+        if gather and self.world > 1:
+            x_full = torch.empty(F * k, dtype=dt, device=dev)
+            xl = op_t._buffers(x_full)
+            xl[:n * k] = x
+            op_t.gather(x_full, xl)
+            return x_full, it
+        return x, it
 
 
 def hip_local_spmv(matrix, stream_fn=None):

@@ -115,6 +115,94 @@ def test_two_rank_sharded_product_and_transpose(mode):
     assert dict(ret) == {0: True, 1: True}
 
 
+def _cg_worker(rank, world, port, ret):
+    """overlapped exchange + the iterating consumers: ShardedOperator.apply_overlapped (parts of unequal size on every rank,
+    empty parts included) and ShardedCG, both schemes, one and two right-hand sides, against the oracle's bsbm_cg / bsbm_cg2
+    restatement (oracle/fs_oracle_cg.c; the reference's own KAT size is 100 x 50, test_sparse.c:560-608) on the fixture
+    matrix and on a larger power-law one"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _synth as S
+        from libfastsparse_amd import dist as fsd
+        from oracle import pyoracle as O
+        from oracle import pysynth
+        ok = True
+        why = []
+        cases = []
+        _, _, rows, cols, _ = S.fixture_sbm()
+        cases.append(("sbm-100-50", 100, 50, rows, cols))
+        rp, cc, _ = pysynth.powerlaw(2500, 700, 2.3, 400, 7, valued=False)
+        cases.append(("powerlaw", 2500, 700, np.repeat(np.arange(2500, dtype=np.int32), np.diff(rp)), cc))
+        for name, N, F, rows, cols in cases:
+            a_rp, a_cc, _ = O.coo_to_csr(N, rows, cols, None)
+            t_rp, t_cc, _ = O.coo_to_csr(F, cols, rows, None)
+            rb = fsd.nnz_balanced_partition(a_rp, world)          # unequal row shards (some may be empty at 8 ranks)
+            cb = fsd.even_row_partition(F, world)
+            lo, hi = rb[rank], rb[rank + 1]
+            tlo, thi = cb[rank], cb[rank + 1]
+            l_rp = (a_rp[lo:hi + 1] - a_rp[lo]).astype(np.int32)
+            l_cc = a_cc[a_rp[lo]:a_rp[hi]].copy()
+            lt_rp = (t_rp[tlo:thi + 1] - t_rp[tlo]).astype(np.int32)
+            lt_cc = t_cc[t_rp[tlo]:t_rp[thi]].copy()
+            l_rows = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(l_rp))
+            for k in (1, 2):
+                def mul(nr, rp_, cc_, out, xin):
+                    X = xin.numpy().reshape(-1, k)
+                    Y = O.csr_mul_n(nr, rp_, cc_, None, np.ascontiguousarray(X), k) if k > 1 else O.csr_mul(nr, rp_, cc_, None, X[:, 0])
+                    out.copy_(torch.from_numpy(np.ascontiguousarray(Y).reshape(-1)))
+
+                def a_local(y_local, x_full):
+                    mul(hi - lo, l_rp, l_cc, y_local, x_full)
+
+                def t_local(z_local, u_full):
+                    mul(thi - tlo, lt_rp, lt_cc, z_local, u_full)
+
+                def t_partial(z_full, u_local):            # A_r' u_r: the transpose of this rank's rows, full length
+                    U = u_local.numpy().reshape(-1, k)
+                    Z = np.stack([O.coo_tmul(F, l_rows, l_cc, None, np.ascontiguousarray(U[:, j])) for j in range(k)], 1)
+                    z_full.copy_(torch.from_numpy(np.ascontiguousarray(Z).reshape(-1)))
+
+                op_a = fsd.ShardedOperator(a_local, rb, parts=fsd.EvenParts(a_local, hi - lo), k=k)
+                # (1) the exchange inside the product: 1, 3 and 5 parts give the product with the whole matrix, bit for bit
+                X = np.ascontiguousarray(np.stack([S.x_int(5 + j, F) for j in range(k)], 1)).reshape(-1)
+                ref = (O.csr_mul_n(N, a_rp, a_cc, None, X.reshape(F, k), k) if k > 1 else O.csr_mul(N, a_rp, a_cc, None, X)).reshape(-1)
+                for nparts in (1, 3, 5):
+                    y = torch.full((N * k,), -1.0, dtype=torch.float64)
+                    op_a.apply_overlapped(y, torch.from_numpy(X), nparts)
+                    if not np.array_equal(y.numpy(), ref):
+                        ok = False
+                        why.append((name, k, "overlapped", nparts))
+                # (2) the solvers
+                B = np.ascontiguousarray(np.stack([np.sin(0.37 * np.arange(F) + 1.0 + j) for j in range(k)], 1)).reshape(-1)
+                xref, itref = O.cg_normal(N, F, rows, cols, B.reshape(F, k) if k > 1 else B, 0.5, 1e-8, two=(k == 2))
+                for scheme in ("gather", "reduce"):
+                    op_t = fsd.ShardedOperator(t_local, cb, k=k) if scheme == "gather" else \
+                        fsd.TransposedShardedOperator(t_partial, rb)
+                    cg = fsd.ShardedCG(op_a, op_t, scheme=scheme, nparts=3)
+                    xs, it = cg.solve(torch.from_numpy(B), 0.5, 1e-8)
+                    err = float(np.max(np.abs(xs.numpy() - np.asarray(xref).reshape(-1))))
+                    # both stop at ||r|| <= 1e-8 ||b||; the dots are summed in another order (slices, then ranks), so a long
+                    # solve may stop a couple of iterations apart (the reference's own KAT bar is 1e-4, test_sparse.c:598)
+                    if not (abs(it - itref) <= max(2, itref // 20) and err <= 1e-7 * max(1.0, float(np.max(np.abs(xref))))):
+                        ok = False
+                        why.append((name, k, scheme, it, itref, err))
+        ret[rank] = (bool(ok), why)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_overlapped_exchange_and_row_sharded_cg(world):
+    """the all-gather overlapped INSIDE one product and the iterating consumer on top of it"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cg_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(v[0] for v in dict(ret).values()) and len(ret) == world, dict(ret)
+
+
 def test_partitions():
     sys.path.insert(0, ROOT)
     from libfastsparse_amd import dist as fsd

@@ -1040,6 +1040,70 @@ def test_dropin_blocked_matrix_without_rows(hip):
     L.fs_invalidate(B)
 
 
+@pytest.mark.parametrize("kind", ["two-pass", "two-pass cut rows", "lds-staged", "tiled", "stream"])
+def test_product_in_parts_finishes_rows_range_by_range(hip, kind):
+    """fs_spmv_part / fs_spmv_part_rows (the all-gather overlapped inside one product needs the product
+    to finish its rows range by range): for every kernel the row cuts are monotone from 0 to nrow, after parts 0 .. p the rows
+    below rows[p + 1] are final (the others still hold the poison), and all parts together are fs_spmv bit for bit
+    (pattern-only, integer x).  A kernel that cannot be cut does everything with part 0."""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(len(kind))
+    opt, nrow, ncol, per = {"two-pass": ("binning", 1_200_000, 700_001, 8), "two-pass cut rows": ("binning", 600_000, 700_001, 8),
+                            "lds-staged": ("ldsx", 1_000_000, 4_096, 12), "tiled": ("tiling", 1_000_000, 300_000, 10),
+                            "stream": (None, 50_000, 20_000, 10)}[kind]
+    lens = rng.integers(0, 2 * per, nrow)
+    if kind == "two-pass cut rows":
+        lens[[5, nrow // 2, nrow - 3]] = [70_000, 3_000, 900]        # cut into virtual rows; one spans several panels
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    cc = rng.integers(0, ncol, int(rp[-1])).astype(np.int32)
+    st = capi.current_stream()
+    if opt:
+        capi.set_option(opt, 2)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None)
+        assert A.kernel_name() == kind.split(" cut")[0], A.kernel_name()
+        x = S.x_int(9, ncol)
+        xd = torch.from_numpy(x).cuda()
+        ref = O.csr_mul(nrow, rp, cc, None, x)
+        for nparts in (1, 2, 4, 7):
+            rows = A.part_rows(nparts)
+            assert rows[0] == 0 and rows[-1] == nrow and all(a <= b for a, b in zip(rows, rows[1:])), rows
+            if kind != "stream" and nparts > 1:
+                assert sum(b > a for a, b in zip(rows, rows[1:])) >= 2, (kind, rows)     # it really is cut
+            y = torch.full((nrow,), -7.0, dtype=torch.float64, device="cuda")
+            for p in range(nparts):
+                A.spmv_part(y, xd, p, nparts, st)
+                got = y.cpu().numpy()
+                assert np.array_equal(got[:rows[p + 1]], ref[:rows[p + 1]]), (kind, nparts, p)
+            assert np.array_equal(y.cpu().numpy(), ref)
+    finally:
+        if opt:
+            capi.set_option(opt, 1)
+
+
+def test_copy_segments_unpacks_a_padded_gather(hip):
+    """fs_copy_segments: the one-launch unpack of the padded receive buffer of an all-gather of unequal shards"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(3)
+    counts = [0, 1, 1000, 123_457, 5, 0, 70_001]
+    src_off = np.cumsum([0] + [c + 17 for c in counts[:-1]])
+    dst_off = np.cumsum([3] + [c + 2 for c in counts[:-1]])
+    src = rng.uniform(size=int(src_off[-1] + counts[-1] + 17))
+    dst = np.full(int(dst_off[-1] + counts[-1] + 9), -1.0)
+    want = dst.copy()
+    for d, s_, c in zip(dst_off, src_off, counts):
+        want[d:d + c] = src[s_:s_ + c]
+    tab = torch.tensor(list(dst_off) + list(src_off) + counts, dtype=torch.int64, device="cuda")
+    sd, dd = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    capi.check(capi.lib().fs_copy_segments(len(counts), tab.data_ptr(), max(counts), sd.data_ptr(), dd.data_ptr(),
+                                           capi.current_stream()), "fs_copy_segments")
+    assert np.array_equal(dd.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("k", [2, 5])
 def test_spmm_never_waits_prepare_decides(hip, k):
     """a matrix on the LDS-staged copy.  fs_spmm before fs_matrix_prepare runs one sweep per column (no
