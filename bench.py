@@ -1,35 +1,50 @@
 #!/usr/bin/env python3
 """bench.py -- the A_mul_B / At_mul_B path on MI355X, one rank per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no launcher starts the N ranks ITSELF (fresh child processes, before this
 process touches the GPU) and fails loudly if the world it finds is not N.
 
+ONE JSON line on rank 0.  The line itself is BASELINE config 2 (`metric`, `value`, `roofline`, `cpu_baseline` exactly as
+before); with the default `--workload all` its key "also" holds one sub-record per other BASELINE config, each with its own
+`value`, `roofline` (+ `traffic`), `self_check` and, at N = 1, `cpu_baseline`:
+    N = 1:  c3, c4 (k = 32, with k = 2 / 4 / 8 beside it), c5 as ONE real shard
+    N > 1:  c2 strong scaling (the one 10 M-row matrix cut over the ranks), c5 across the N ranks (with and without the
+            all-gather, and with A'u)
+so that one driver command reaches every config (`--workload c2` prints the headline alone; c3 / c4 / c5 print that
+workload's record as the line).
+
 Workloads (all data synthetic, generated on the device by the counter-based generators whose CPU twins
 live in oracle/fs_synth.c):
 
-  c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on)
+  c2 (BASELINE.json configs[1], the configuration the metric is quoted on)
       fp64 CSR 10 M x 10 M, 16 nnz/row uniform.  Step = y = A x then z = A' u (two products).  N > 1: weak scaling by
-      rows, the global matrix is (N*10M) x 10M, every rank owns a config-2 shard, x replicated, y = local SpMV + RCCL
-      all-gather of the y shards, z = local A_r' u_r + RCCL all-reduce; exchanges overlap the next local product.
+      rows, the global matrix is (N*10M) x 10M, every rank owns a config-2 shard, x replicated.  The step is the ITERATING
+      consumer's (cg.h:15-16: y of A x is the x of A'): y = local product in parts with the RCCL all-gather of the finished
+      rows running under the later parts (ShardedOperator.apply_overlapped), y complete before A' starts; z = A' u as "row
+      shards of A' + all-gather" (built once by an all-to-all of the entries; --z-scheme reduce: local A_r' u_r + all-reduce).
   c3  SparseBinaryMatrix 10 M x 1 M, 64 nnz/row, supplied as COO to the A_mul_B / At_mul_B handles (fs_coo_create),
       integer-valued x.  Step = A_mul_B + At_mul_B.  One GPU.
   c4  CSR x dense SpMM: the config-2 matrix times X (10 M x 32, row-major).  Step = one csr_A_mul_Bn (k = 32);
       k = 2, 4, 8 are timed beside it.  One GPU.
   c5  CSR 100 M x 100 M, power-law row lengths (mean 32, clipped at 1e6), rows cut by non-zeros over the N ranks, x
-      (800 MB) replicated, y = local SpMV + RCCL all-gather of the (unequal) y shards; with --transpose also
-      z = A' u as "row shards of A' + all-gather".  The matrix does not fit one struct CSR (3.2 G non-zeros > 2^31-1),
-      so N = 1 runs ONE real shard: the rows rank 3 of 8 owns under the nnz-balanced cut.
+      (800 MB) replicated, y = local SpMV in parts + RCCL all-gather of the (unequal) y shards inside the product; with
+      --transpose (always inside "also") a second timed loop adds z = A' u as "row shards of A' + all-gather".  The matrix
+      does not fit one struct CSR (3.2 G non-zeros > 2^31-1), so N = 1 runs ONE real shard: the rows rank 3 of 8 owns under
+      the nnz-balanced cut.
 
 value = algorithmic bytes of all ranks' products / max-over-ranks wall time of the K timed steps (barrier +
 synchronize on both sides), operands resident in HBM.  Algorithmic bytes per product:
 (12 | 4)*nnz + 4*(nrow+1) + 8k*nrow + 8k*ncol.
 
-Prints ONE JSON line on rank 0 with `roofline` (HIP-event timed inside the timed region) and, at N = 1,
-`cpu_baseline` (the oracle's OpenMP restatement built with the reference's flags and, where oracle/_ref travelled,
-the real reference's serial loop, on a stated bounded sample).
+`roofline` comes from HIP events inside the timed region: at N = 1 ONE pair around the K steps (events around every
+product cost 1 % of a 0.86 ms product: profiles/r03_gap_probe.jsonl), at N > 1 a pair around every rank-local product
+(the exchanges run on RCCL's stream).  `roofline.design_ceiling_frac` = algorithmic bytes / bytes the kept kernel really moves
+(PMC, profiles/traffic_*.json) x the 6.29 TB/s a copy reaches on this chip / 8 TB/s: what THIS algorithm could reach.
+`cpu_baseline` (N = 1): the oracle's OpenMP restatement built with the reference's flags and, where oracle/_ref travelled,
+the real reference's serial loop, on a stated bounded sample.
 """
 import argparse
 import json
@@ -42,7 +57,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0          # what a float4 copy reaches on this chip (same guide): the rate a streaming kernel can hope for
 SEED_C2 = 0x5EED0002
 SEED_C3 = 0x5EED0003
 SEED_C5 = 0x5EED0005
@@ -123,6 +139,7 @@ class HipProvider:
         import torch
         from libfastsparse_amd import capi
         self.torch, self.capi, self.dev = torch, capi, dev
+        self._tables = {}
         # the library allocates and launches on the calling thread's current HIP device: make it this rank's, whatever
         # torch has done about it so far
         capi.check(capi.lib().fs_set_device(dev.index if dev.index is not None else 0), "fs_set_device")
@@ -152,6 +169,9 @@ class HipProvider:
         g.manual_seed(seed)
         return t.randint(-1000, 1001, (n,), device=self.dev, generator=g).to(t.float64)
 
+    def uniform(self, nrow, ncol, per, seed, row_offset=0, valued=True):
+        return self.capi.synth_uniform(nrow, ncol, per, seed, row_offset=row_offset, valued=valued)
+
     def powerlaw_lengths(self, nrow, row_offset):
         t = self.torch
         lens = t.empty(nrow, dtype=t.int32, device=self.dev)
@@ -169,14 +189,55 @@ class HipProvider:
                                                       vals.data_ptr() if valued else None, self.stream()))
         return cols, vals
 
-    def csr(self, nrow, ncol, rp, cc, vv):
-        return self.capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+    def csr(self, nrow, ncol, rp, cc, vv, transpose=False):
+        M = self.capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+        if transpose:
+            M.build_transpose(self.stream())
+        return M
 
     def coo(self, nrow, ncol, rows, cols, vals):
         return self.capi.Matrix.from_coo(nrow, ncol, rows, cols, vals)
 
     def spmv(self, A, y, x, transposed=False):
         A.spmv(y, x, self.stream(), transposed=transposed)
+
+    def spmv_strict(self, A, y, x, transposed=False):
+        """the same product on the storage-order kernel (the self-checks' yardstick)"""
+        self.capi.set_option("strict_order", 1)
+        try:
+            A.spmv(y, x, self.stream(), transposed=transposed)
+        finally:
+            self.capi.set_option("strict_order", 0)
+
+    def parts(self, A, transposed=False):
+        from libfastsparse_amd import dist as fsd
+        return fsd.HipParts(A, transposed)
+
+    def copy_segments(self, dst, src, dst_off, src_off, counts):
+        """fs_copy_segments: the unpack of a padded all-gather buffer in one launch; the offset table lives in HBM, made once"""
+        if not counts:
+            return
+        key = (tuple(dst_off), tuple(src_off), tuple(counts))
+        tab = self._tables.get(key)
+        if tab is None:
+            tab = self.torch.tensor(list(dst_off) + list(src_off) + list(counts), dtype=self.torch.int64, device=self.dev)
+            self._tables[key] = tab
+        self.capi.check(self.capi.lib().fs_copy_segments(len(counts), tab.data_ptr(), max(counts), src.data_ptr(), dst.data_ptr(),
+                                                        self.stream()), "fs_copy_segments")
+
+    def kernel_name(self, A, transposed=False):
+        return A.kernel_name(transposed)
+
+    def candidate_ms(self, A, transposed=False):
+        return A.candidate_ms(transposed)
+
+    def release(self):
+        """between workloads: everything the previous one held goes back to the device"""
+        import gc
+        gc.collect()
+        self._tables.clear()
+        self.capi.lib().fs_release_all()
+        self.torch.cuda.empty_cache()
 
 
 def in_turns(fn, prov, world, rank, nccl):
@@ -197,7 +258,8 @@ def in_turns(fn, prov, world, rank, nccl):
 
 
 def timed_steps(prov, step, drain, steps, warmup, world, backend_is_nccl):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks (seconds)"""
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks (seconds); also the
+    duration of the K steps between ONE pair of events on the launch stream (ms, this rank)"""
     import torch
     import torch.distributed as dist
     for _ in range(warmup):
@@ -207,20 +269,24 @@ def timed_steps(prov, step, drain, steps, warmup, world, backend_is_nccl):
     if world > 1:
         dist.barrier()
     evs = [[prov.event() for _ in range(4)] for _ in range(steps)]
+    e0, e1 = prov.event(), prov.event()
     prov.synchronize()
     t0 = time.perf_counter()
+    e0.record()
     for k in range(steps):
         step(evs[k])
     drain()
+    e1.record()
     prov.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    region_ms = prov.elapsed_ms(e0, e1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=prov.dev if backend_is_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, evs
+    return elapsed, evs, region_ms
 
 
 def stream_probe(prov):
@@ -424,15 +490,42 @@ def _traffic(kernels, workload, rows, per):
         return None
 
 
-def run_c2(args, prov, world, rank, nccl):
+def _roofline(kernel, achieved, traffic, alg_bytes, avg_ms, launches, traffic_file=None):
+    """the `roofline` object; design_ceiling_frac: algorithmic bytes / the bytes the kept kernel really moves (PMC) x what a copy
+    reaches on this chip: the fraction of peak THIS algorithm could reach if both its streams ran at the copy rate"""
+    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+         "avg_launch_ms": avg_ms, "launches_timed": launches}
+    if traffic:
+        r["design_ceiling_frac"] = alg_bytes / traffic * HBM_COPY_GBS / HBM_PEAK_GBS
+        r["frac_of_design_ceiling"] = r["frac"] / r["design_ceiling_frac"]
+        r["design_ceiling_source"] = ("algorithmic bytes / PMC traffic of the kept kernel (%s) x 6.29 TB/s copy rate "
+                                      "(MI355X_MICROARCH.md) / 8 TB/s" % (traffic_file or "profiles/traffic_*.json"))
+    return r
+
+
+def _same_on_all_ranks(values, dev_or_cpu):
+    """True when every rank holds the same few doubles (checksums of gathered vectors)"""
     import torch
     import torch.distributed as dist
-    from libfastsparse_amd import capi
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev_or_cpu)
+    lo_, hi_ = t.clone(), t.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo_, hi_))
+
+
+def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
+    """BASELINE config 2.  N = 1: y = A x, z = A' u.  N > 1: every rank a row shard (weak: a config-2 matrix per rank; strong:
+    the one matrix cut over the ranks), both products as "rows + all-gather" with the exchange INSIDE the product
+    (`out`, a dict, receives the final vectors: the gloo rehearsal in tests/ checks them against the oracle)"""
+    import torch
+    import torch.distributed as dist
     from libfastsparse_amd import dist as fsd
     dev = prov.dev
     per = args.per_row
     ncol = args.rows                    # column space stays config 2's at every N
-    if args.strong and world > 1:       # strong scaling: the one 10 M-row matrix cut into equal row shards
+    if strong and world > 1:            # strong scaling: the one 10 M-row matrix cut into equal row shards (SURVEY 8d)
         n_global = args.rows
         sb = fsd.even_row_partition(n_global, world)
         lo, n_local = sb[rank], sb[rank + 1] - sb[rank]
@@ -440,149 +533,224 @@ def run_c2(args, prov, world, rank, nccl):
         n_local = args.rows
         n_global = n_local * world
         lo = rank * n_local
-    st = capi.current_stream()
+    cdev = dev if (nccl and world > 1) else "cpu"
+    nparts = max(1, args.parts)
+    z_scheme = "local" if world == 1 else args.z_scheme
+    z_err = None
 
-    # ---- this rank's shard: rows lo .. lo+n_local of the (N*10M) x 10M matrix ------------------------
-    rp, cc, vv = capi.synth_uniform(n_local, ncol, per, SEED_C2, row_offset=lo)
-    def build():
-        M = capi.Matrix.from_csr(n_local, ncol, rp, cc, vv, borrow=True)
-        M.build_transpose(st)
-        return M
-    A = in_turns(build, prov, world, rank, nccl)
+    # ---- this rank's shard: rows lo .. lo+n_local of the n_global x 10M matrix ---------------------------------
+    rp, cc, vv = prov.uniform(n_local, ncol, per, SEED_C2, row_offset=lo)
     bounds = fsd.even_row_partition(n_global, world)
-    bytes_a = A.algorithmic_bytes()
-    bytes_t = csr_bytes(n_local * per, ncol, n_local)   # same entries, nrow and ncol swap roles
-    op_a = fsd.ShardedOperator(fsd.hip_local_spmv(A), bounds)
-    op_t = fsd.TransposedShardedOperator(
-        lambda z, u_local: A.spmv(z, u_local, capi.current_stream(), transposed=True), bounds)
+    cb = fsd.even_row_partition(ncol, world)
+    At = None
+    if world > 1 and z_scheme == "gather":
+        # z = A' u as "row shards of A' + all-gather": this rank owns rows cb[rank] .. cb[rank+1] of A' (= those columns of
+        # A), built once by an all-to-all of the entries; moves F doubles per product where the all-reduce moves 2 F
+        try:
+            tr, tc, tv = fsd.build_transposed_shard(rp, cc, vv, lo, cb)
+            At = in_turns(lambda: prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), tv),
+                          prov, world, rank, nccl)
+            del tr, tc, tv
+        except Exception as ex:          # never ran on more than one GPU before the driver's run: keep the number, say why
+            z_scheme, z_err, At = "reduce", repr(ex), None
+        if world > 1:                    # every rank takes the same scheme
+            flag = torch.tensor([1.0 if z_scheme == "gather" else 0.0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 0.0 and z_scheme == "gather":
+                z_scheme, z_err, At = "reduce", "another rank could not build its shard of A'", None
+    A = in_turns(lambda: prov.csr(n_local, ncol, rp, cc, vv, transpose=(z_scheme != "gather")), prov, world, rank, nccl)
+    nnz_local = n_local * per
+    bytes_a = csr_bytes(nnz_local, n_local, ncol)
+    if z_scheme == "gather":
+        nnz_t = int(At.nnz)
+        bytes_t = csr_bytes(nnz_t, cb[rank + 1] - cb[rank], n_global)
+    else:
+        bytes_t = csr_bytes(nnz_local, ncol, n_local)   # same entries, nrow and ncol swap roles
+
+    op_a = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments)
+    if z_scheme == "gather":
+        op_t = fsd.ShardedOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb, parts=prov.parts(At), copy_segments=prov.copy_segments)
+    elif z_scheme == "reduce":
+        op_t = fsd.TransposedShardedOperator(lambda zf, ul: prov.spmv(A, zf, ul, transposed=True), bounds)
+    else:
+        op_t = None
 
     x = prov.sin_vector(ncol, 7.0, 0.3)             # bench_a_mul_b.c:142
     u = prov.sin_vector(n_global, 11.0, -0.2)       # 2nd column of X2col, :145
-    y = torch.empty(n_global, dtype=torch.float64, device=dev)
-    z = torch.empty(ncol, dtype=torch.float64, device=dev)
+    y = prov.empty(n_global)
+    z = prov.empty(ncol)
 
-    # Two y buffers (and two operators with their own shard buffers) alternate, so that the all-gather of step k may
-    # run until the end of step k+1: at 8 GPUs the 640 MB gather is longer than one local product, and only the
-    # transposed product of the same step would otherwise be there to hide it.
-    op_a2 = [op_a, fsd.ShardedOperator(fsd.hip_local_spmv(A), bounds)] if world > 1 else [op_a, op_a]
-    ybufs = [y, torch.empty_like(y)] if world > 1 else [y, y]
-    pending = [None]   # the all-reduce of the previous step's z, still in flight
-    gather = [None]    # the all-gather of the previous step's y, still in flight
-    count = [0]
-
-    def step(ev=None):
-        """one step: ev[0]|A x|ev[1]  start all-gather(y_k)  ev[2]|A' u|ev[3]  wait all-gather(y_k-1), start all-reduce(z).
-        The two products are independent, so each exchange overlaps the following local products (RCCL runs on its
-        own stream); every collective is waited for before its buffers are reused and before the clock stops."""
-        b = count[0] & 1
-        count[0] += 1
+    def step(ev=None, exchange=True):
+        """N = 1: A x, A' u.  N > 1, the iterating consumer's order (cg.h:15-16): [A x in parts, the all-gather of the finished
+        rows under the later parts], y complete; [A' u likewise], z complete.  ev[0..1] / ev[2..3] bracket this rank's kernels
+        of the two products on the launch stream (the exchanges run on RCCL's stream)."""
+        if world == 1:
+            prov.spmv(A, y, x)
+            prov.spmv(A, z, u, transposed=True)
+            return
         if ev is not None:
             ev[0].record()
-        yl = op_a2[b].local(ybufs[b], x)
+        if exchange:
+            hy = op_a.apply_overlapped_async(y, x, nparts)
+        else:
+            op_a.local(y, x)
         if ev is not None:
             ev[1].record()
-        g = op_a2[b].gather_async(ybufs[b], yl)
-        if pending[0] is not None:
-            pending[0].wait()            # z of the previous step is complete before it is overwritten
-            pending[0] = None
+        if exchange:
+            hy.wait()
         if ev is not None:
             ev[2].record()
-        op_t.apply_local(z, u)
+        if z_scheme == "gather":
+            if exchange:
+                hz = op_t.apply_overlapped_async(z, u, nparts)
+            else:
+                op_t.local(z, u)
+        else:
+            op_t.apply_local(z, u)
+            if exchange:
+                hz = op_t.reduce_async(z)
         if ev is not None:
             ev[3].record()
-        if gather[0] is not None:
-            gather[0].wait()             # the other y buffer is complete before the next step writes its shard buffer
-        gather[0] = g
-        pending[0] = op_t.reduce_async(z)
+        if exchange:
+            hz.wait()
 
-    def drain():
-        if gather[0] is not None:
-            gather[0].wait()
-            gather[0] = None
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-
-    elapsed, evs = timed_steps(prov, step, drain, args.steps, args.warmup, world, nccl)
-
-    # per-product durations inside the timed region (HIP events on the launch stream); a product is the kernel
-    # pair expand + reduce of the two-pass SpMV (or one launch of the tiled / streaming kernel if the format
-    # builder chose those)
-    ka = [e[0].elapsed_time(e[1]) for e in evs]
-    kt = [e[2].elapsed_time(e[3]) for e in evs]
+    elapsed, evs, region_ms = timed_steps(prov, step, lambda: None, args.steps, args.warmup, world, nccl)
     launches = 2 * args.steps
-    avg_ms = (sum(ka) + sum(kt)) / launches
+    if world == 1:
+        avg_ms = region_ms / launches                # ONE event pair around the K steps
+    else:
+        avg_ms = sum(prov.elapsed_ms(e[0], e[1]) + prov.elapsed_ms(e[2], e[3]) for e in evs) / launches
     bytes_per_launch = (bytes_a + bytes_t) / 2.0
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    tb = torch.tensor([float(bytes_a + bytes_t)], dtype=torch.float64, device=dev if (nccl and world > 1) else "cpu")
+    tb = torch.tensor([float(bytes_a + bytes_t)], dtype=torch.float64, device=cdev)
     if world > 1:
-        dist.all_reduce(tb)             # shards may differ by a row under --strong
+        dist.all_reduce(tb)             # shards may differ by a row under strong scaling
     total_bytes = float(tb.item()) * args.steps
     value = total_bytes / elapsed / 1e9
 
+    # the two products apart (outside the timed region): A x and A' u, a few runs each
+    split = {}
+    if world == 1:
+        e = [prov.event() for _ in range(3)]
+        e[0].record()
+        for _ in range(5):
+            prov.spmv(A, y, x)
+        e[1].record()
+        for _ in range(5):
+            prov.spmv(A, z, u, transposed=True)
+        e[2].record()
+        prov.synchronize()
+        split = {"A_mul_B_ms": prov.elapsed_ms(e[0], e[1]) / 5, "At_mul_B_ms": prov.elapsed_ms(e[1], e[2]) / 5}
+    else:
+        split = {"A_mul_B_ms": sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs),
+                 "At_mul_B_ms": sum(prov.elapsed_ms(e[2], e[3]) for e in evs) / len(evs)}
+    noex = None
+    if world > 1:   # the same loop without any exchange: what the exchanges cost on top of the local products
+        noex, _, _ = timed_steps(prov, lambda ev=None: step(None, exchange=False), lambda: None, args.steps, 1, world, nccl)
+
     # self-check outside the timed region (no oracle here: that is the tests' job): the products the timed loop left in
     # y and z against the storage-order chunk-streaming kernel on the same operands, and, at N > 1, every rank holding
-    # the same gathered y / reduced z
+    # the same gathered y / z
     self_check = {}
     try:
-        y_ref = torch.empty(n_local, dtype=torch.float64, device=dev)
-        capi.set_option("strict_order", 1)
-        try:
-            A.spmv(y_ref, x, capi.current_stream())
-            z_ref = torch.empty(ncol, dtype=torch.float64, device=dev)
-            A.spmv(z_ref, u[lo:lo + n_local], capi.current_stream(), transposed=True)
-        finally:
-            capi.set_option("strict_order", 0)
-        y_last = ybufs[(count[0] - 1) & 1]                       # the y the last timed step produced
-        self_check["A_mul_B_max_abs_diff_vs_storage_order_kernel"] = float((y_last[lo:lo + n_local] - y_ref).abs().max())
         if world > 1:
-            zr = z_ref.clone()
-            fsd.all_reduce_sum(zr)                                    # sum of the ranks' partial products
-            sums = torch.tensor([float(y_last.sum()), float(z.sum())], dtype=torch.float64, device=dev if nccl else "cpu")
-            lo_, hi_ = sums.clone(), sums.clone()
-            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
-            self_check["ranks_hold_identical_y_and_z"] = bool(torch.equal(lo_, hi_))
+            step(None)                                                # y, z of a complete step (the no-exchange loop ran last)
+        y_ref = prov.empty(n_local)
+        prov.spmv_strict(A, y_ref, x)
+        self_check["A_mul_B_max_abs_diff_vs_storage_order_kernel"] = float((y[lo:lo + n_local] - y_ref).abs().max())
+        if z_scheme == "gather":
+            z_ref = prov.empty(cb[rank + 1] - cb[rank])
+            prov.spmv_strict(At, z_ref, u)
+            dz = float((z[cb[rank]:cb[rank + 1]] - z_ref).abs().max()) if z_ref.numel() else 0.0
         else:
-            zr = z_ref
-        self_check["At_mul_B_max_abs_diff_vs_storage_order_kernel"] = float((z - zr).abs().max())
+            z_ref = prov.empty(ncol)
+            prov.spmv_strict(A, z_ref, u[lo:lo + n_local], transposed=True)
+            if world > 1:
+                fsd.all_reduce_sum(z_ref)                             # sum of the ranks' partial products
+            dz = float((z - z_ref).abs().max())
+        self_check["At_mul_B_max_abs_diff_vs_storage_order_kernel"] = dz
+        if world > 1:
+            self_check["ranks_hold_identical_y_and_z"] = _same_on_all_ranks([float(y.sum()), float(z.sum())], cdev)
         self_check["ok"] = bool(self_check["A_mul_B_max_abs_diff_vs_storage_order_kernel"] <= 1e-11 and
-                                self_check["At_mul_B_max_abs_diff_vs_storage_order_kernel"] <= 1e-11 * world and
+                                dz <= 1e-11 * max(1, world if z_scheme == "reduce" else 8) and
                                 self_check.get("ranks_hold_identical_y_and_z", True))
-        del y_ref, z_ref, zr
+        del y_ref, z_ref
     except Exception as ex:   # a failed check must show in the line, not kill it
         self_check = {"ok": False, "error": repr(ex)}
+    if out is not None:
+        out["y"], out["z"], out["bounds"], out["z_scheme"] = y, z, bounds, z_scheme
+
+    # what fixed-order sums would cost (VERDICT r2 item 7): the same matrix created under "reproducible" keeps a kernel whose
+    # additions have a fixed order (the two-pass kernels add a row's terms of one band with LDS atomics in arrival order)
+    repro = None
+    if world == 1 and hasattr(prov, "capi") and not args.no_reproducible_cost:
+        try:
+            prov.capi.set_option("reproducible", 1)
+            try:
+                A2 = prov.capi.Matrix.from_csr(n_local, ncol, rp, cc, vv, borrow=True)
+                for _ in range(2):
+                    A2.spmv(y, x, prov.stream())
+                e0, e1 = prov.event(), prov.event()
+                e0.record()
+                for _ in range(10):
+                    A2.spmv(y, x, prov.stream())
+                e1.record()
+                prov.synchronize()
+                ms = prov.elapsed_ms(e0, e1) / 10
+                repro = {"kernel": A2.kernel_name(), "A_mul_B_ms": ms,
+                         "reproducible_cost_pct": 100.0 * (ms / split["A_mul_B_ms"] - 1.0)}
+                del A2
+            finally:
+                prov.capi.set_option("reproducible", 0)
+        except Exception as ex:
+            repro = {"error": repr(ex)}
 
     if rank != 0:
         return None
-    stream_gbs = stream_probe(prov)
-    kname, kname_t = A.kernel_name(), A.kernel_name(True)
+    stream_gbs = stream_probe(prov) if hasattr(prov, "torch") else None
+    kname = prov.kernel_name(A)
+    kname_t = prov.kernel_name(At) if z_scheme == "gather" else prov.kernel_name(A, True)
+    F8 = 8.0 * ncol
+    if world == 1:
+        what = "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B" % (n_global, ncol, per)
+    else:
+        what = ("%s: CSR %d x %d, %d rows/GPU, %d nnz/row, step = (A_mul_B in %d parts with the all-gather of y inside the product) "
+                "then (At_mul_B, %s)" % ("BASELINE config 2 cut over %d GPUs (strong scaling)" % world if strong else
+                                         "config-2 shards, weak scaling by rows", n_global, ncol, n_local, per, nparts,
+                                         "row shards of A' + all-gather of z inside the product" if z_scheme == "gather" else
+                                         "local A_r' u_r + all-reduce of z"))
+    traffic = _traffic((kname, kname_t), "c2", n_local, per) if world == 1 else None
     rec = {
         "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B"
-                               % (n_global, ncol, per) if world == 1 else
-                               ("BASELINE config 2 cut over %d GPUs (strong scaling): CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
-                                "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (world, n_global, ncol, n_local, per)
-                                if args.strong else
-                                "config-2 shards, weak scaling by rows: CSR %d x %d, %d rows/GPU, %d nnz/row, step = "
-                                "(A_mul_B + all-gather y) + (At_mul_B + all-reduce z)" % (n_global, ncol, n_local, per)),
-                   "rows_per_gpu": n_local, "nnz_per_gpu": n_local * per, "parallelism": "rows x%d" % world,
+        "scaling": "strong" if (strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": what,
+                   "rows_per_gpu": n_local, "nnz_per_gpu": nnz_local, "parallelism": "rows x%d" % world,
                    "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
                    "stream_read_GBs_measured": stream_gbs,
                    "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
-                   "A_mul_B_ms": sum(ka) / len(ka), "At_mul_B_ms": sum(kt) / len(kt),
+                   "A_mul_B_ms": split["A_mul_B_ms"], "At_mul_B_ms": split["At_mul_B_ms"],
                    "self_check": self_check,
                    "kernel_A": kname, "kernel_At": kname_t,
-                   "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": A.candidate_ms(True)},
-        "roofline": {"bound": "hbm", "kernel": _klabel(kname, kname_t), "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": _traffic((kname, kname_t), "c2", n_local, per) if world == 1 else None,
-                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                     "launches_timed": launches},
+                   "builder_timed_ms_A": prov.candidate_ms(A),
+                   "builder_timed_ms_At": prov.candidate_ms(At) if z_scheme == "gather" else prov.candidate_ms(A, True)},
+        "roofline": _roofline(_klabel(kname, kname_t), achieved, traffic, bytes_per_launch, avg_ms, launches,
+                              "profiles/traffic_spmv_%s.json" % kname.replace("-", "_")),
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if repro is not None:
+        rec["config"]["fixed_order_sums"] = repro
+        rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    if world > 1:
+        rec["config"].update({
+            "exchange": {"y": "all-gather of the y shards, started part by part inside the product (%d parts)" % nparts,
+                         "z_scheme": z_scheme, "z_scheme_fallback_reason": z_err,
+                         "bytes_received_per_rank_per_step": {
+                             "y_all_gather": 8.0 * (n_global - n_local),
+                             "z_row_shards_of_At_plus_all_gather": F8 * (world - 1) / world,
+                             "z_all_reduce_ring": 2.0 * F8 * (world - 1) / world}},
+            "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
+            "rccl_status": "first contact: no multi-GPU machine was available to the builder; numbers above are the driver's"})
+    if world == 1 and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
             rec["cpu_baseline"] = cpu_baseline_c2(n_local, ncol, per)
         except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
@@ -621,20 +789,21 @@ def run_c3(args, prov, world, rank, nccl):
     bytes_t = csr_bytes(nnz, ncol, nrow, valued=False)
 
     def step(ev=None):
-        if ev is not None:
-            ev[0].record()
         A.spmv(y, x, st)
-        if ev is not None:
-            ev[1].record()
-            ev[2].record()
         At.spmv(z, u, st)
-        if ev is not None:
-            ev[3].record()
 
-    elapsed, evs = timed_steps(prov, step, lambda: None, args.steps, args.warmup, 1, nccl)
-    ka = [e[0].elapsed_time(e[1]) for e in evs]
-    kt = [e[2].elapsed_time(e[3]) for e in evs]
-    avg_ms = (sum(ka) + sum(kt)) / (2 * args.steps)
+    elapsed, _, region_ms = timed_steps(prov, step, lambda: None, args.steps, args.warmup, 1, nccl)
+    avg_ms = region_ms / (2 * args.steps)            # ONE event pair around the K steps
+    e = [prov.event() for _ in range(3)]             # the two products apart, outside the timed region
+    e[0].record()
+    for _ in range(5):
+        A.spmv(y, x, st)
+    e[1].record()
+    for _ in range(5):
+        At.spmv(z, u, st)
+    e[2].record()
+    prov.synchronize()
+    ka, kt = [prov.elapsed_ms(e[0], e[1]) / 5], [prov.elapsed_ms(e[1], e[2]) / 5]
     bpl = (bytes_a + bytes_t) / 2.0
     achieved = bpl / (avg_ms * 1e-3) / 1e9
     value = (bytes_a + bytes_t) * args.steps / elapsed / 1e9
@@ -671,13 +840,12 @@ def run_c3(args, prov, world, rank, nccl):
                    "device_coo_to_csr_and_format_s": {"A": t_build_a, "At": t_build_t},
                    "kernel_A": ka_name, "kernel_At": kt_name,
                    "builder_timed_ms_A": A.candidate_ms(), "builder_timed_ms_At": At.candidate_ms(), "self_check": sc},
-        "roofline": {"bound": "hbm", "kernel": _klabel(ka_name, kt_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic((ka_name,), "c3", nrow, per),
-                     "algorithmic_bytes_per_launch": bpl, "avg_launch_ms": avg_ms, "launches_timed": 2 * args.steps},
+        "roofline": _roofline(_klabel(ka_name, kt_name), achieved, _traffic((ka_name,), "c3", nrow, per), bpl, avg_ms,
+                              2 * args.steps, "profiles/traffic_c3_%s.json" % ka_name.replace("-", "_")),
     }
     if not args.no_cpu_baseline:
         try:
-            rec["cpu_baseline"] = cpu_baseline_c3(nrow, ncol, per)
+            rec["cpu_baseline"] = cpu_baseline_c3(nrow, ncol, per, sample_rows=args.cpu_sample_rows or 2_500_000)
         except Exception as ex:
             rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     return rec
@@ -706,16 +874,13 @@ def run_c4(args, prov, world, rank, nccl):
     nbytes = A.algorithmic_bytes(k)
     capi.set_option("spmm_kernel", args.spmm_kernel)
 
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        A.spmm(Y, X, k, st)
-        if ev is not None:
-            ev[1].record()
+    A.prepare(k, st)                       # nothing to build for k = 32 (row kernel); the call is part of the protocol
 
-    elapsed, evs = timed_steps(prov, step, lambda: None, args.steps, args.warmup, 1, nccl)
-    kms = [e[0].elapsed_time(e[1]) for e in evs]
-    avg_ms = sum(kms) / len(kms)
+    def step(ev=None):
+        A.spmm(Y, X, k, st)
+
+    elapsed, _, region_ms = timed_steps(prov, step, lambda: None, args.steps, args.warmup, 1, nccl)
+    avg_ms = region_ms / args.steps
     achieved = nbytes / (avg_ms * 1e-3) / 1e9
     value = nbytes * args.steps / elapsed / 1e9
     sc = {}
@@ -737,8 +902,13 @@ def run_c4(args, prov, world, rank, nccl):
     small = {}
     for kk in (2, 4, 8):
         Xk, Yk = make_x(kk), torch.empty(n, kk, dtype=torch.float64, device=dev)
+        prov.synchronize()
+        t0 = time.perf_counter()
+        A.prepare(kk, st)                 # the k-column two-pass copy (k = 2, 4): one-time work, never inside a product
+        prov.synchronize()
+        t_prep = time.perf_counter() - t0
         for _ in range(2):
-            A.spmm(Yk, Xk, kk, st)        # the first call builds the k-column copy
+            A.spmm(Yk, Xk, kk, st)
         e0, e1 = prov.event(), prov.event()
         e0.record()
         for _ in range(5):
@@ -747,7 +917,8 @@ def run_c4(args, prov, world, rank, nccl):
         prov.synchronize()
         ms = e0.elapsed_time(e1) / 5
         small["k%d" % kk] = {"ms": ms, "GBs": A.algorithmic_bytes(kk) / (ms * 1e-3) / 1e9,
-                             "frac_of_peak": A.algorithmic_bytes(kk) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "frac_of_peak": A.algorithmic_bytes(kk) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "kernel": A.spmm_plan(kk), "prepare_s": t_prep}
         del Xk, Yk
     rec = {
         "metric": "fp64 CSR SpMM (k = 32) effective GB/s (% HBM3E peak)", "value": value, "unit": "GB/s", "n_gpus": 1,
@@ -760,15 +931,15 @@ def run_c4(args, prov, world, rank, nccl):
                            "--spmm-kernel 4 runs the v_mfma_f64_16x16x4_f64 experiment" if args.spmm_kernel != 4 else
                            "v_mfma_f64_16x16x4_f64 row kernel (1/16 of each instruction's multiply-adds useful)",
                    "self_check": sc},
-        "roofline": {"bound": "hbm", "kernel": "fs::spmm_kernel<valued, 5> (32 lanes per row)" if args.spmm_kernel != 4 else
-                     "fs::spmm_mfma_kernel<valued>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": _traffic(("spmm_k32",), "c4", n, per),
-                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_timed": args.steps},
+        "roofline": _roofline("fs::spmm_kernel<valued, 5> (32 lanes per row)" if args.spmm_kernel != 4 else
+                              "fs::spmm_mfma_kernel<valued>", achieved, _traffic(("spmm_k32",), "c4", n, per), nbytes, avg_ms,
+                              args.steps, "profiles/traffic_c4_spmm_k32.json"),
     }
+    rec["config"]["hbm_held_by_the_handle_bytes"] = dict(zip(("csr_and_schedule", "kept_single_vector_copy", "k_column_copies_and_scratch"),
+                                                             A.device_bytes()))
     if not args.no_cpu_baseline:
         try:
-            rec["cpu_baseline"] = cpu_baseline_c4(n, per, k)
+            rec["cpu_baseline"] = cpu_baseline_c4(n, per, k, sample_rows=args.cpu_sample_rows or 400_000)
         except Exception as ex:
             rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     return rec
@@ -818,7 +989,8 @@ def c5_shard(prov, lo, hi, ncol):
 
 def run_c5(args, prov, world, rank, nccl, out=None):
     """BASELINE config 5 (`out`, a dict, receives the final vectors: the gloo rehearsal in tests/ checks them against
-    the oracle's product with the whole matrix)"""
+    the oracle's product with the whole matrix).  Timed loop 1: y = A x (local product in parts, all-gather inside the product);
+    with --transpose a second timed loop adds z = A' u on row shards of A'."""
     import torch
     import torch.distributed as dist
     from libfastsparse_amd import dist as fsd
@@ -826,6 +998,8 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     ncol = n_global
     parts = world if world > 1 else 8
     mine = rank if world > 1 else min(3, parts - 1)     # N = 1: the shard rank 3 of 8 owns
+    nparts = max(1, args.parts)
+    cdev = prov.dev if (nccl and world > 1) else "cpu"
     bounds, cum_nnz, total_nnz = c5_partition(prov, n_global, parts)
     lo, hi = bounds[mine], bounds[mine + 1]
     rp, cc, vv, nnz = c5_shard(prov, lo, hi, ncol)
@@ -835,16 +1009,16 @@ def run_c5(args, prov, world, rank, nccl, out=None):
 
     x = prov.sin_vector(ncol, 7.0, 0.3)
     if world > 1:
-        op = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds)
-        ops = [op, fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds)]
-        ybufs = [prov.empty(n_global), prov.empty(n_global)]
+        op = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments)
+        y = prov.empty(n_global)
     else:
-        ops, ybufs = None, [prov.empty(n_local)] * 2
+        op, y = None, prov.empty(n_local)
 
     # A' u as "row shards of A' + all-gather" (N > 1 with --transpose): columns are uniform, so an even cut of the
     # rows of A' is balanced; the shard is built once by an all-to-all of the entries
     opt = At = None
     t_err = None
+    bytes_t = 0
     if world > 1 and args.transpose:
         try:
             cb = fsd.even_row_partition(ncol, world)
@@ -853,124 +1027,157 @@ def run_c5(args, prov, world, rank, nccl, out=None):
                           prov, world, rank, nccl)
             del tr, tc, tv
             opt = fsd.TransposedGatherOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb)
+            opt.parts, opt.copy_segments = prov.parts(At), prov.copy_segments
             u = prov.sin_vector(n_global, 11.0, -0.2)
             z = prov.empty(ncol)
             bytes_t = csr_bytes(int(At.nnz), cb[rank + 1] - cb[rank], n_global)
         except Exception as ex:      # the transposed direction is an extra: report, keep the config-5 number
             opt, t_err = None, repr(ex)
-    gather = [None]
-    zg = [None]
-    count = [0]
+        ok_t = torch.tensor([1.0 if opt is not None else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if float(ok_t.item()) == 0.0 and opt is not None:
+            opt, t_err = None, "another rank could not build its shard of A'"
 
-    def step(ev=None):
-        b = count[0] & 1
-        count[0] += 1
+    def step(ev=None, exchange=True, transpose=False):
+        if world == 1:
+            ev = None                  # one GPU: ONE event pair around the K steps (timed_steps)
         if ev is not None:
             ev[0].record()
         if world == 1:
-            prov.spmv(A, ybufs[0], x)
-            yl = None
+            prov.spmv(A, y, x)
+        elif exchange:
+            hy = op.apply_overlapped_async(y, x, nparts)
         else:
-            yl = ops[b].local(ybufs[b], x)
+            op.local(y, x)
         if ev is not None:
             ev[1].record()
-        g = ops[b].gather_async(ybufs[b], yl) if world > 1 else None
-        if opt is not None:
-            if zg[0] is not None:
-                zg[0].wait()
+        if world > 1 and exchange:
+            hy.wait()
+        if transpose:
             if ev is not None:
                 ev[2].record()
-            zl = opt.local(z, u)
+            if exchange:
+                hz = opt.apply_overlapped_async(z, u, nparts)
+            else:
+                opt.local(z, u)
             if ev is not None:
                 ev[3].record()
-            zg[0] = opt.gather_async(z, zl)
-        if gather[0] is not None:
-            gather[0].wait()          # the other y buffer is complete before the next step reuses its shard buffer
-        gather[0] = g
+            if exchange:
+                hz.wait()
 
-    def drain():
-        for h in (gather, zg):
-            if h[0] is not None:
-                h[0].wait()
-                h[0] = None
+    elapsed, evs, region_ms = timed_steps(prov, step, lambda: None, args.steps, args.warmup, world, nccl)
+    local_ms = region_ms / args.steps if world == 1 else sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs)
 
-    elapsed, evs = timed_steps(prov, step, drain, args.steps, args.warmup, world, nccl)
-    ka = [prov.elapsed_ms(e[0], e[1]) for e in evs]
-    local_ms = sum(ka) / len(ka)
-    kt_ms = sum(prov.elapsed_ms(e[2], e[3]) for e in evs) / len(evs) if opt is not None else None
+    def all_ranks(v):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(t)
+        return float(t.item())
 
-    # the same loop without any exchange: what the all-gather costs on top of the local products
-    noex = None
-    if world > 1:
-        def step_local(ev=None):
-            ops[0].local(ybufs[0], x)
-            if opt is not None:
-                opt.local(z, u)
-        noex, _ = timed_steps(prov, step_local, lambda: None, args.steps, 1, world, nccl)
-
-    tot = torch.tensor([float(bytes_local), float(bytes_t) if opt is not None else 0.0], dtype=torch.float64,
-                       device=prov.dev if (nccl and world > 1) else "cpu")
-    if world > 1:
-        dist.all_reduce(tot)
-    bytes_all = float(tot[0].item()) + float(tot[1].item())
+    bytes_all = all_ranks(bytes_local)
     value = bytes_all * args.steps / elapsed / 1e9
+    noex = with_t = None
+    if world > 1:   # the same loop without any exchange: what the all-gather costs on top of the local products
+        noex, _, _ = timed_steps(prov, lambda ev=None: step(None, exchange=False), lambda: None, args.steps, 1, world, nccl)
+    if opt is not None:
+        el_t, evs_t, _ = timed_steps(prov, lambda ev=None: step(ev, transpose=True), lambda: None, args.steps, 1, world, nccl)
+        noex_t, _, _ = timed_steps(prov, lambda ev=None: step(None, exchange=False, transpose=True), lambda: None, args.steps, 1,
+                                   world, nccl)
+        bytes_both = bytes_all + all_ranks(bytes_t)
+        with_t = {"value": bytes_both * args.steps / el_t / 1e9, "unit": "GB/s", "ms_per_step": el_t / args.steps * 1e3,
+                  "ms_per_step_without_exchanges": noex_t / args.steps * 1e3,
+                  "local_At_mul_B_ms_rank0": sum(prov.elapsed_ms(e[2], e[3]) for e in evs_t) / len(evs_t),
+                  "pct_of_hbm_peak": 100.0 * bytes_both * args.steps / el_t / 1e9 / (HBM_PEAK_GBS * world),
+                  "step": "y = A x, then z = A' u on row shards of A' (all-gather of y and of z inside the products)"}
 
     sc = {}
     try:
-        y_last = ybufs[(count[0] - 1) & 1]
-        if out is not None:
-            out["y"], out["z"], out["bounds"] = y_last, (z if opt is not None else None), bounds
         if world > 1:
-            sums = torch.tensor([float(y_last.sum())], dtype=torch.float64, device=prov.dev if nccl else "cpu")
-            lo_, hi_ = sums.clone(), sums.clone()
-            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
-            sc["ranks_hold_identical_y"] = bool(torch.equal(lo_, hi_))
-        if hasattr(prov, "capi"):
-            y_ref = prov.empty(n_local)
-            prov.capi.set_option("strict_order", 1)
-            try:
-                prov.spmv(A, y_ref, x)
-            finally:
-                prov.capi.set_option("strict_order", 0)
-            mine_y = y_last[lo:hi] if world > 1 else y_last
-            lens = (rp[1:] - rp[:-1]).to(torch.float64).clamp(min=1.0)
-            sc["rows_within_1e-12_x_row_length_of_storage_order_kernel"] = bool(((mine_y - y_ref).abs() <= 1e-12 * lens).all())
+            step(None, transpose=opt is not None)     # complete vectors (a no-exchange loop ran last)
+        if out is not None:
+            out["y"], out["z"], out["bounds"] = y, (z if opt is not None else None), bounds
+        if world > 1:
+            sc["ranks_hold_identical_y"] = _same_on_all_ranks([float(y.sum())], cdev)
+        y_ref = prov.empty(n_local)
+        prov.spmv_strict(A, y_ref, x)
+        mine_y = y[lo:hi] if world > 1 else y
+        lens = (rp[1:] - rp[:-1]).to(torch.float64).clamp(min=1.0)
+        sc["rows_within_1e-12_x_row_length_of_storage_order_kernel"] = bool(((mine_y - y_ref).abs() <= 1e-12 * lens).all())
         sc["ok"] = all(v for v in sc.values())
     except Exception as ex:
         sc = {"ok": False, "error": repr(ex)}
     if rank != 0:
         return None
-    kname = A.kernel_name() if hasattr(A, "kernel_name") else "injected"
+    kname = prov.kernel_name(A)
     achieved = bytes_local / (local_ms * 1e-3) / 1e9
     rec = {
         "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE config 5: CSR %d x %d power-law (mean %.1f nnz/row, clipped at %d), rows cut by "
-                                "non-zeros over %d GPUs, x replicated, step = local SpMV + all-gather of y%s"
-                                % (n_global, ncol, total_nnz / n_global, C5_MAXLEN, world,
-                                   " + A'u (row shards of A' + all-gather of z)" if opt is not None else "")) if world > 1 else
+                                "non-zeros over %d GPUs, x replicated, step = local SpMV in %d parts with the all-gather of y "
+                                "inside the product" % (n_global, ncol, total_nnz / n_global, C5_MAXLEN, world, nparts)) if world > 1 else
                                ("ONE shard of BASELINE config 5 (CSR %d x %d power-law, %d non-zeros in all): the rows rank %d of "
                                 "%d owns under the nnz-balanced cut; one GPU cannot hold the matrix in a struct CSR "
                                 "(2^31-1 non-zeros)" % (n_global, ncol, total_nnz, mine, parts)),
                    "total_nnz": total_nnz, "rows_this_rank": n_local, "nnz_this_rank": nnz,
                    "row_bounds": bounds if len(bounds) <= 17 else None,
                    "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
-                   "local_A_mul_B_ms_rank0": local_ms, "local_At_mul_B_ms_rank0": kt_ms,
+                   "local_A_mul_B_ms_rank0": local_ms,
                    "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
-                   "transpose_error": t_err, "kernel": kname,
-                   "builder_timed_ms": A.candidate_ms() if hasattr(A, "candidate_ms") else None, "self_check": sc},
-        "roofline": {"bound": "hbm", "kernel": _klabel(kname), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic((kname,), "c5", n_local, 0) if world == 1 else None,
-                     "algorithmic_bytes_per_launch": bytes_local, "avg_launch_ms": local_ms, "launches_timed": args.steps},
+                   "with_transpose": with_t, "transpose_error": t_err, "kernel": kname,
+                   "builder_timed_ms": prov.candidate_ms(A), "self_check": sc},
+        "roofline": _roofline(_klabel(kname), achieved, _traffic((kname,), "c5", n_local, 0) if world == 1 else None, bytes_local,
+                              local_ms, args.steps, "profiles/traffic_c5_%s.json" % kname.replace("-", "_")),
     }
+    if world > 1:
+        rec["config"]["rccl_status"] = "first contact: no multi-GPU machine was available to the builder"
     if world == 1 and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
-            rec["cpu_baseline"] = cpu_baseline_c5(lo, ncol)
+            rec["cpu_baseline"] = cpu_baseline_c5(lo, ncol, sample_rows=args.cpu_sample_rows or 1_000_000)
         except Exception as ex:
             rec["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     return rec
+
+
+def run_also(args, prov, world, rank, nccl):
+    """the other BASELINE configs behind the same command: a list of sub-records, each a full record of its
+    workload.  A workload that fails leaves {"workload": ..., "error": ...} -- it must not take the headline down."""
+    import copy
+    import torch
+    import torch.distributed as dist
+    recs = []
+    sub = copy.copy(args)
+    sub.cpu_sample_rows = args.cpu_sample_rows or 0
+    plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {})] if world == 1 else \
+           [("c2-strong", run_c2, {"strong": True}), ("c5", run_c5, {})]
+    for name, fn, kw in plan:
+        prov.release()
+        t0 = time.perf_counter()
+        a = copy.copy(sub)
+        if world == 1:       # bounded samples for the CPU baselines of the sub-records: the default run stays within minutes
+            a.cpu_sample_rows = args.cpu_sample_rows or {"c3": 1_000_000, "c4": 200_000, "c5": 500_000}[name]
+        else:
+            a.transpose = True
+        try:
+            rec = fn(a, prov, world, rank, nccl, **kw)
+            err = None
+        except BaseException as ex:   # incl. SystemExit of a workload's own argument checks
+            rec, err = None, repr(ex)
+        if world > 1:        # a rank that failed must not leave the others waiting in the next workload's collectives
+            bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=prov.dev if nccl else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if float(bad.item()) and not err:
+                rec, err = None, "another rank failed in this workload"
+        if rank == 0:
+            if rec is None:
+                rec = {"workload": name, "error": err}
+            rec["wall_s_incl_build"] = time.perf_counter() - t0
+            recs.append(rec)
+        if err and world > 1:
+            break            # collectives may be out of step after a failure: stop here
+    prov.release()
+    return recs
 
 
 def main():
@@ -978,7 +1185,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="all", choices=["all", "c2", "c3", "c4", "c5"],
+                    help="all (default): the config-2 line with the other BASELINE configs under its key \"also\"")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (config 2 / 3 / 4: 10M)")
     ap.add_argument("--per-row", type=int, default=16)
     ap.add_argument("--c5-rows", type=int, default=100_000_000, help="rows = columns of the config-5 matrix")
@@ -986,7 +1194,12 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="c2, N > 1: strong scaling -- the ONE config-2 matrix (--rows rows in all) cut over the ranks (default: weak "
                          "scaling, --rows rows per rank)")
+    ap.add_argument("--parts", type=int, default=4, help="N > 1: parts of a local product; the all-gather of part p runs under part p+1")
+    ap.add_argument("--z-scheme", default="gather", choices=["gather", "reduce"],
+                    help="c2, N > 1: z = A'u by row shards of A' + all-gather (default) or local A_r'u_r + all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reproducible-cost", action="store_true", help="c2: skip the second, fixed-order copy of the matrix")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baselines' samples (0: the workload's default)")
     ap.add_argument("--spmm-kernel", type=int, default=0,
                     help="c4: 0 the product's choice, 1 row kernel, 4 the matrix-core experiment (profiling runs)")
     args = ap.parse_args()
@@ -1028,8 +1241,16 @@ def main():
         else:
             dist.init_process_group(backend)
     prov = HipProvider(dev)
-    run = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload]
-    rec = run(args, prov, world, rank, nccl)
+    if args.workload in ("all", "c2"):
+        rec = run_c2(args, prov, world, rank, nccl, strong=args.strong)
+        if args.workload == "all":
+            also = run_also(args, prov, world, rank, nccl)
+            if rank == 0 and rec is not None:
+                rec["also"] = also
+    else:
+        if args.workload != "c5" and world != 1:
+            raise SystemExit("--workload %s is a one-GPU workload" % args.workload)
+        rec = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload](args, prov, world, rank, nccl)
     if rank == 0 and rec is not None:
         print(json.dumps(rec), flush=True)
     if world > 1:

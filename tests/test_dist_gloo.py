@@ -225,8 +225,10 @@ class OracleProvider:
 
     def __init__(self):
         import bench
+        from libfastsparse_amd import dist as fsd
         from oracle import pyoracle, pysynth
-        self.B, self.O, self.L = bench, pyoracle, pysynth._lib()
+        self.B, self.O, self.S, self.L, self.fsd = bench, pyoracle, pysynth, pysynth._lib(), fsd
+        self.copy_segments = fsd.copy_segments_torch
 
     def stream(self):
         return None
@@ -246,6 +248,10 @@ class OracleProvider:
     def sin_vector(self, n, a, b):
         return torch.sin(a * torch.arange(n, dtype=torch.float64) + b)
 
+    def uniform(self, nrow, ncol, per, seed, row_offset=0, valued=True):
+        rp, cc, vv = self.S.uniform(nrow, ncol, per, seed, row_offset=row_offset, valued=valued)
+        return torch.from_numpy(rp), torch.from_numpy(cc), (torch.from_numpy(vv) if valued else None)
+
     def powerlaw_lengths(self, nrow, row_offset):
         lens = np.empty(nrow, np.int32)
         self.L.fso_synth_powerlaw_lengths(nrow, self.B.C5_SCALE, self.B.C5_MAXLEN, self.B.SEED_C5, row_offset, lens)
@@ -259,18 +265,36 @@ class OracleProvider:
         return torch.from_numpy(cc), torch.from_numpy(vv)
 
     class _M:
-        def __init__(self, nrow, rp, cc, vv):
-            self.nrow, self.rp, self.cc, self.vv, self.nnz = nrow, rp, cc, vv, len(cc)
+        def __init__(self, nrow, ncol, rp, cc, vv):
+            self.nrow, self.ncol, self.rp, self.cc, self.vv, self.nnz = nrow, ncol, rp, cc, vv, len(cc)
+            self.rows = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
 
-    def csr(self, nrow, ncol, rp, cc, vv):
-        return self._M(nrow, rp.numpy(), cc.numpy(), vv.numpy())
+    def csr(self, nrow, ncol, rp, cc, vv, transpose=False):
+        return self._M(nrow, ncol, rp.numpy(), cc.numpy(), vv.numpy())
 
     def coo(self, nrow, ncol, rows, cols, vals):
         rp, cc, vv = self.O.coo_to_csr(nrow, rows.numpy(), cols.numpy(), vals.numpy())
-        return self._M(nrow, rp, cc, vv)
+        return self._M(nrow, ncol, rp, cc, vv)
 
     def spmv(self, A, y, x, transposed=False):
-        y.copy_(torch.from_numpy(self.O.csr_mul(A.nrow, A.rp, A.cc, A.vv, x.numpy())))
+        if transposed:      # column sums in ascending-row order = what the cached CSR of A' gives
+            y.copy_(torch.from_numpy(self.O.coo_tmul(A.ncol, A.rows, A.cc, A.vv, x.numpy())))
+        else:
+            y.copy_(torch.from_numpy(self.O.csr_mul(A.nrow, A.rp, A.cc, A.vv, x.numpy())))
+
+    spmv_strict = spmv
+
+    def parts(self, A, transposed=False):
+        return self.fsd.EvenParts(lambda yl, xf: self.spmv(A, yl, xf, transposed), A.ncol if transposed else A.nrow)
+
+    def kernel_name(self, A, transposed=False):
+        return "oracle"
+
+    def candidate_ms(self, A, transposed=False):
+        return None
+
+    def release(self):
+        pass
 
 
 def _c5_worker(rank, world, port, n, ret):
@@ -284,7 +308,7 @@ def _c5_worker(rank, world, port, n, ret):
         from oracle import pyoracle as O
         from oracle import pysynth
         prov = OracleProvider()
-        args = argparse.Namespace(c5_rows=n, steps=2, warmup=1, transpose=True)
+        args = argparse.Namespace(c5_rows=n, steps=2, warmup=1, transpose=True, parts=3, no_cpu_baseline=True, cpu_sample_rows=0)
         out = {}
         rec = bench.run_c5(args, prov, world, rank, False, out=out)
         # the whole matrix on every rank (it is small here) with the same generator: the gathered y must be the
@@ -301,7 +325,8 @@ def _c5_worker(rank, world, port, n, ret):
         ok = ok and len(set(np.diff(b))) > 1            # the shards really are unequal: the padded async gather ran
         if rank == 0:
             ok = ok and rec is not None and rec["n_gpus"] == world and rec["value"] > 0 and rec["config"]["self_check"]["ok"] \
-                and rec["config"]["transpose_error"] is None and rec["config"]["total_nnz"] == int(rp[-1])
+                and rec["config"]["transpose_error"] is None and rec["config"]["total_nnz"] == int(rp[-1]) \
+                and rec["config"]["with_transpose"]["value"] > 0 and rec["config"]["ms_per_step_without_exchanges"] > 0
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -315,6 +340,63 @@ def test_bench_c5_workload_rehearsed_on_eight_gloo_ranks():
     ret = mgr.dict()
     mp.spawn(_c5_worker, args=(world, _free_port(), 60_000, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def _c2_worker(rank, world, port, z_scheme, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import argparse
+        import bench
+        from oracle import pyoracle as O
+        from oracle import pysynth
+        prov = OracleProvider()
+        n, per = 2500, 16
+        args = argparse.Namespace(rows=n, per_row=per, c5_rows=9000, steps=2, warmup=1, transpose=False, strong=False, parts=3,
+                                  z_scheme=z_scheme, no_cpu_baseline=True, no_reproducible_cost=True, cpu_sample_rows=0,
+                                  spmm_kernel=0)
+        out = {}
+        rec = bench.run_c2(args, prov, world, rank, False, out=out)
+        # weak scaling: the global matrix is (world * n) x n with the same generator row by row; y and z must be the oracle's
+        rp, cc, vv = pysynth.uniform(world * n, n, per, bench.SEED_C2)
+        x = prov.sin_vector(n, 7.0, 0.3).numpy()
+        u = prov.sin_vector(world * n, 11.0, -0.2).numpy()
+        ok = np.array_equal(out["y"].numpy(), O.csr_mul(world * n, rp, cc, vv, x))
+        rows_all = np.repeat(np.arange(world * n, dtype=np.int32), per)
+        zref = O.coo_tmul(n, rows_all, cc, vv, u)
+        if out["z_scheme"] == "gather":                     # rows of A' in ascending A-row order: the oracle's bits
+            ok = ok and np.array_equal(out["z"].numpy(), zref)
+        else:                                               # partial sums per rank, then the all-reduce: rounding apart
+            ok = ok and bool(np.all(np.abs(out["z"].numpy() - zref) <= 1e-12 * (1.0 + np.abs(zref))))
+        ok = ok and out["z_scheme"] == z_scheme
+        also = bench.run_also(args, prov, world, rank, False)
+        if rank == 0:
+            ex = rec["config"]["exchange"]
+            ok = ok and rec["n_gpus"] == world and rec["scaling"] == "weak" and rec["config"]["self_check"]["ok"] \
+                and ex["z_scheme"] == z_scheme and rec["config"]["ms_per_step_without_exchanges"] > 0 \
+                and ex["bytes_received_per_rank_per_step"]["z_all_reduce_ring"] == 2 * ex["bytes_received_per_rank_per_step"]["z_row_shards_of_At_plus_all_gather"]
+            names = [r.get("config", {}).get("workload", r.get("workload", "")) for r in also]
+            ok = ok and len(also) == 2 and "strong scaling" in names[0] and "config 5" in names[1] \
+                and all("error" not in r and r["config"]["self_check"]["ok"] and r["roofline"]["achieved"] > 0 for r in also) \
+                and also[0]["scaling"] == "strong" and also[1]["config"]["with_transpose"]["value"] > 0
+            ret["names"] = names
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("z_scheme", ["gather", "reduce"])
+def test_bench_default_workload_and_its_sub_records_rehearsed_on_two_gloo_ranks(z_scheme):
+    """`bench.py --gpus 2` = the config-2 line (weak scaling, the exchange inside the products, z by row
+    shards of A' + all-gather or by all-reduce) plus the "also" sub-records a multi-GPU run appends: config 2 under strong
+    scaling and config 5 across the ranks with and without the all-gather and with A'u -- every vector against the oracle"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_c2_worker, args=(world, _free_port(), z_scheme, ret), nprocs=world, join=True)
+    assert ret.get(0) is True and ret.get(1) is True, dict(ret)
 
 
 def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
