@@ -195,12 +195,17 @@ int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream);
  * Rows are cut into one contiguous shard per device with (almost) equal numbers of non-zeros, every device holds the
  * whole x, multiplies its shard with the single-GPU kernels and the y shards are all-gathered over RCCL (xGMI), so that
  * every device ends up with the whole y: the reference's row-parallel `omp parallel for` (csr.h:429) across devices
- * (SURVEY.md 8e).  librccl.so is loaded with dlopen when a context with more than one distinct device is created.
- * A C caller of csr_A_mul_B / bcsr_A_mul_B gets this path by setting FASTSPARSE_NGPU=N (optionally
- * FASTSPARSE_DEVICES=0,1,...) in the environment.
+ * (SURVEY.md 8e).  The exchange runs INSIDE the product: the local product is cut into FS_DIST_PARTS parts (default 4,
+ * fs_spmv_part) and the ncclAllGather of the rows a part finished -- one call per part on a padded buffer, the ranks' calls
+ * in one group -- runs on a second stream under the later parts; one fs_copy_segments launch unpacks.  z = A' u is the same
+ * scheme on row shards of A' (fs_dist_matrix_build_transpose), with u = the y of the last product in place.
+ * librccl.so is loaded with dlopen when a context with more than one distinct device is created.
+ * A C caller of csr_A_mul_B / bcsr_A_mul_B / csr_At_mul_B / bcsr_At_mul_B gets this path by setting FASTSPARSE_NGPU=N
+ * (optionally FASTSPARSE_DEVICES=0,1,...) in the environment.
  * devices == NULL means devices 0 .. ndev-1; ndev < 1 means every visible device.  A device may be listed more than once
- * ("virtual ranks" on one GPU, for testing the sharding on a one-GPU machine): such a context exchanges the shards
- * with device-to-device copies, because RCCL refuses duplicate devices. */
+ * ("virtual ranks" on one GPU, for testing the sharding on a one-GPU machine): such a context exchanges the parts
+ * with device-to-device copies, because RCCL refuses duplicate devices.  Products on one fs_dist_matrix_t are serialised
+ * by a lock (its vectors and part buffers are per matrix). */
 fs_dist_t fs_dist_create(int ndev, const int *devices);
 void fs_dist_destroy(fs_dist_t D);
 int  fs_dist_ndev(fs_dist_t D);
@@ -209,15 +214,27 @@ int  fs_dist_uses_rccl(fs_dist_t D);
 fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols,
                                     const double *vals);
 void fs_dist_matrix_destroy(fs_dist_matrix_t M);
+/* row shards of A' (columns of A cut by non-zeros; every row of A' in ascending A-row order) from the SAME host arrays the
+ * matrix was created from (the handle keeps no host copy); idempotent */
+int  fs_dist_matrix_build_transpose(fs_dist_matrix_t M, const int *row_ptr, const int *cols, const double *vals);
+int  fs_dist_matrix_has_transpose(fs_dist_matrix_t M);
 int  fs_dist_matrix_bounds(fs_dist_matrix_t M, int *bounds /* ndev + 1 */);
 int64_t fs_dist_matrix_shard_nnz(fs_dist_matrix_t M, int rank);
-/* y[nrow] = A x[ncol] with HOST vectors: x goes to every device over its own PCIe link, y comes back from device 0 */
+/* y[nrow] = A x[ncol] / z[ncol] = A' u[nrow] with HOST vectors: the input goes to every device over its own PCIe link
+ * through a pinned staging buffer (chunks, the host copy of the next under the uploads of the last), the output comes back
+ * from device 0 */
 int  fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host);
-/* device-resident form: fill fs_dist_x(M, r) (ncol doubles on rank r's device) on every rank, run, read fs_dist_y(M, r)
- * (nrow doubles, complete on every rank when the call returns) */
+int  fs_dist_spmv_t(fs_dist_matrix_t M, double *z_host, const double *u_host);
+/* device-resident forms for iterating callers: fill fs_dist_x(M, r) (ncol doubles on rank r's device) on every rank ONCE;
+ * fs_dist_spmv_resident leaves y = A x in fs_dist_y(M, r) (nrow doubles, complete on every rank when the call returns),
+ * fs_dist_spmv_t_resident leaves z = A' y in fs_dist_z(M, r) (y of the last product is u, in place), fs_dist_swap_xy makes y
+ * the next x (square matrices: power iteration) -- nothing crosses PCIe between products */
 int  fs_dist_spmv_resident(fs_dist_matrix_t M);
+int  fs_dist_spmv_t_resident(fs_dist_matrix_t M);
+int  fs_dist_swap_xy(fs_dist_matrix_t M);
 double *fs_dist_x(fs_dist_matrix_t M, int rank);
 double *fs_dist_y(fs_dist_matrix_t M, int rank);
+double *fs_dist_z(fs_dist_matrix_t M, int rank);
 
 /* ---- format construction on the device ------------------------------------------------ */
 /* Stable bucketing of host COO entries, the operation behind new_csr / new_bcsr (csr.h:375-422, 30-67: kind 0, key =

@@ -26,6 +26,8 @@ DEVICE_API = [
     "fs_synth_uniform", "fs_synth_powerlaw_lengths", "fs_synth_fill", "fs_bucket_coo", "fs_device_build_wanted",
     "fs_dist_create", "fs_dist_destroy", "fs_dist_ndev", "fs_dist_uses_rccl", "fs_dist_csr_create", "fs_dist_matrix_destroy",
     "fs_dist_matrix_bounds", "fs_dist_matrix_shard_nnz", "fs_dist_spmv", "fs_dist_spmv_resident", "fs_dist_x", "fs_dist_y",
+    "fs_dist_matrix_build_transpose", "fs_dist_matrix_has_transpose", "fs_dist_spmv_t", "fs_dist_spmv_t_resident", "fs_dist_swap_xy",
+    "fs_dist_z",
 ]
 REFERENCE_API = [
     # sparse.h
@@ -137,8 +139,12 @@ def lib():
     L.fs_dist_matrix_shard_nnz.argtypes = [vp, C.c_int]
     L.fs_dist_matrix_shard_nnz.restype = C.c_int64
     L.fs_dist_spmv.argtypes = [vp, vp, vp]
-    L.fs_dist_spmv_resident.argtypes = [vp]
-    for f in ("fs_dist_x", "fs_dist_y"):
+    L.fs_dist_spmv_t.argtypes = [vp, vp, vp]
+    L.fs_dist_matrix_build_transpose.argtypes = [vp, vp, vp, vp]
+    L.fs_dist_matrix_has_transpose.argtypes = [vp]
+    for f in ("fs_dist_spmv_resident", "fs_dist_spmv_t_resident", "fs_dist_swap_xy"):
+        getattr(L, f).argtypes = [vp]
+    for f in ("fs_dist_x", "fs_dist_y", "fs_dist_z"):
         getattr(L, f).restype = vp
         getattr(L, f).argtypes = [vp, C.c_int]
     _lib = L

@@ -289,7 +289,7 @@ fs_dist_t dist_context(const char *who)
 // y = A x on the node's GPUs: host vectors (device vectors are staged through the host: the multi-GPU entry point for
 // resident data is fs_dist_spmv_resident)
 void dist_csr_mul(double *y, const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols,
-                  const double *vals, double *x, const char *who)
+                  const double *vals, double *x, const char *who, bool transposed = false)
 {
   fs_dist_t D = dist_context(who);
   const bool full = hash_in_full((int64_t)nnz * (vals ? 12 : 4) + 4 * ((int64_t)nrow + 1));
@@ -297,17 +297,20 @@ void dist_csr_mul(double *y, const void *host, int nrow, int ncol, long nnz, con
   h = mix(mix(mix(h, (uint64_t)(uintptr_t)row_ptr), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
   h = print_doubles(print_ints(print_ints(h, row_ptr, (int64_t)nrow + 1, full), cols, nnz, full), vals, nnz, full);
   EntryP e = lookup(host, kDist, h, [&](Entry &n) { n.dm = fs_dist_csr_create(D, nrow, ncol, nnz, row_ptr, cols, vals); }, who);
+  // the transposed product: row shards of A' on the same devices, built from the same host arrays on first use
+  if (transposed) FS_MUST(fs_dist_matrix_build_transpose(e->dm, row_ptr, cols, vals), who);
+  const size_t nx = (size_t)(transposed ? nrow : ncol), ny = (size_t)(transposed ? ncol : nrow);
   std::vector<double> xs, ys;
   const double *xh = x;
   double *yh = y;
   if (on_device(x)) {
-    xs.resize((size_t)ncol);
-    if (hipMemcpy(xs.data(), x, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost) != hipSuccess) { fs::set_error("copy of x failed"); die(who); }
+    xs.resize(nx);
+    if (hipMemcpy(xs.data(), x, sizeof(double) * nx, hipMemcpyDeviceToHost) != hipSuccess) { fs::set_error("copy of x failed"); die(who); }
     xh = xs.data();
   }
-  if (on_device(y)) { ys.resize((size_t)nrow); yh = ys.data(); }
-  FS_MUST(fs_dist_spmv(e->dm, yh, xh), who);
-  if (yh != y && hipMemcpy(y, yh, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice) != hipSuccess) {
+  if (on_device(y)) { ys.resize(ny); yh = ys.data(); }
+  FS_MUST(transposed ? fs_dist_spmv_t(e->dm, yh, xh) : fs_dist_spmv(e->dm, yh, xh), who);
+  if (yh != y && hipMemcpy(y, yh, sizeof(double) * ny, hipMemcpyHostToDevice) != hipSuccess) {
     fs::set_error("copy of y failed"); die(who);
   }
 }
@@ -611,6 +614,7 @@ void parallel_bcsr_AA_mul_B(double *y, struct BinaryCSR *A, double *x, double *y
 
 void bcsr_At_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
+  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, x, "bcsr_At_mul_B", true); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_At_mul_B");
   fs_matrix_t m = e->m;
   product(m, true, y, A->ncol, x, A->nrow, "bcsr_At_mul_B");
@@ -626,6 +630,7 @@ void csr_A_mul_B(double *y, struct CSR *A, double *x)
 
 void csr_At_mul_B(double *y, struct CSR *A, double *x)
 {
+  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, x, "csr_At_mul_B", true); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, true, "csr_At_mul_B");
   fs_matrix_t m = e->m;
   product(m, true, y, A->ncol, x, A->nrow, "csr_At_mul_B");

@@ -1457,6 +1457,51 @@ def test_native_multi_gpu_context_shards_by_nonzeros(hip, ranks):
                 assert np.all(np.abs(y - ref) <= TOL * np.maximum(O.csr_abs_scale(nrow, rp, cc, vals, x), 1e-300))
             for r in range(ranks):       # every rank holds the whole y
                 assert np.array_equal(_dist_download(L, L.fs_dist_y(M, r), nrow), y), r
+            # z = A' u on row shards of A' built from the same host arrays: host vectors ...
+            assert L.fs_dist_matrix_has_transpose(M) == 0
+            assert L.fs_dist_matrix_build_transpose(M, rp.ctypes.data, cc.ctypes.data, None if vals is None else vals.ctypes.data) == 0, \
+                L.fs_last_error()
+            assert L.fs_dist_matrix_has_transpose(M) == 1
+            u = S.x_int(6, nrow) if vals is None else np.sin(11.0 * np.arange(nrow) - 0.2)
+            z = np.full(ncol, -1.0)
+            assert L.fs_dist_spmv_t(M, z.ctypes.data, u.ctypes.data) == 0, L.fs_last_error()
+            rows_all = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+            zref = O.coo_tmul(ncol, rows_all, cc, vals, u)
+            if vals is None:
+                assert np.array_equal(z, zref)
+            else:
+                assert np.all(np.abs(z - zref) <= TOL * np.maximum(O.coo_tmul(ncol, rows_all, cc, np.abs(vals), np.abs(u)), 1e-300))
+            # ... and resident, iterating: x uploaded ONCE, then y = A x, z = A' y, y -> x (square), again; nothing crosses PCIe
+            for r in range(ranks):
+                assert L.fs_copy_to_device(L.fs_dist_x(M, r), x.ctypes.data, 8 * ncol) == 0
+            xi = x.copy()
+            for _ in range(2):
+                assert L.fs_dist_spmv_resident(M) == 0, L.fs_last_error()
+                assert L.fs_dist_spmv_t_resident(M) == 0, L.fs_last_error()
+                yi = O.csr_mul(nrow, rp, cc, vals, xi)
+                zi = O.coo_tmul(ncol, rows_all, cc, vals, yi)
+                for r in range(ranks):
+                    gy, gz = _dist_download(L, L.fs_dist_y(M, r), nrow), _dist_download(L, L.fs_dist_z(M, r), ncol)
+                    if vals is None:
+                        assert np.array_equal(gy, yi) and np.array_equal(gz, zi), r
+                    else:
+                        assert np.allclose(gy, yi, rtol=1e-10, atol=1e-9 * np.abs(yi).max()) and \
+                            np.allclose(gz, zi, rtol=1e-10, atol=1e-9 * np.abs(zi).max()), r
+                assert L.fs_dist_swap_xy(M) == 0            # y is the next x
+                xi = yi if vals is not None else np.mod(yi, 1024.0)     # keep the integers small: take them mod 1024 on the host ...
+                if vals is None:                                           # ... and put that x on every rank
+                    for r in range(ranks):
+                        assert L.fs_copy_to_device(L.fs_dist_x(M, r), xi.ctypes.data, 8 * ncol) == 0
+            # a kernel choice that moved after the plan was made (strict_order: the chunk-streaming kernel, one part) is followed
+            capi.set_option("strict_order", 1)
+            try:
+                y2 = np.full(nrow, -1.0)
+                assert L.fs_dist_spmv(M, y2.ctypes.data, x.ctypes.data) == 0, L.fs_last_error()
+                assert np.array_equal(y2, ref)
+            finally:
+                capi.set_option("strict_order", 0)
+            assert L.fs_dist_spmv(M, y2.ctypes.data, x.ctypes.data) == 0, L.fs_last_error()
+            assert np.array_equal(y2, y)
             L.fs_dist_matrix_destroy(M)
     finally:
         L.fs_dist_destroy(D)
@@ -1489,6 +1534,17 @@ if mode == "dropin":
     assert np.all(np.abs(y - O.csr_mul(nrow, rp, cc, vv, x)) <= 1e-12 * np.maximum(O.csr_abs_scale(nrow, rp, cc, vv, x), 1e-300))
     L.bcsr_A_mul_B(H._dp(y), C.byref(B), H._dp(xi))
     assert np.array_equal(y, O.csr_mul(nrow, rp, cc, None, xi))
+    # the transposed entry points honour FASTSPARSE_NGPU too (row shards of A' + all-gather)
+    L.csr_At_mul_B.restype = None; L.bcsr_At_mul_B.restype = None
+    rows_all = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+    ui = (np.arange(nrow) %% 11 - 5).astype(np.float64)
+    z = np.full(ncol, -1.0)
+    L.bcsr_At_mul_B(H._dp(z), C.byref(B), H._dp(ui))
+    assert np.array_equal(z, O.coo_tmul(ncol, rows_all, cc, None, ui))
+    us = np.sin(11.0 * np.arange(nrow) - 0.2)
+    L.csr_At_mul_B(H._dp(z), C.byref(A), H._dp(us))
+    zr = O.coo_tmul(ncol, rows_all, cc, vv, us)
+    assert np.all(np.abs(z - zr) <= 1e-12 * np.maximum(O.coo_tmul(ncol, rows_all, cc, np.abs(vv), np.abs(us)), 1e-300))
     L.fs_release_all()
 else:
     D = L.fs_dist_create(1, None)
@@ -1497,6 +1553,11 @@ else:
     y = np.full(nrow, -1.0)
     assert L.fs_dist_spmv(M, y.ctypes.data, xi.ctypes.data) == 0, L.fs_last_error()
     assert np.array_equal(y, O.csr_mul(nrow, rp, cc, None, xi))
+    assert L.fs_dist_matrix_build_transpose(M, rp.ctypes.data, cc.ctypes.data, None) == 0, L.fs_last_error()
+    ui = (np.arange(nrow) %% 11 - 5).astype(np.float64)
+    z = np.full(ncol, -1.0)
+    assert L.fs_dist_spmv_t(M, z.ctypes.data, ui.ctypes.data) == 0, L.fs_last_error()
+    assert np.array_equal(z, O.coo_tmul(ncol, np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp)), cc, None, ui))
     L.fs_dist_matrix_destroy(M); L.fs_dist_destroy(D)
 print("OK")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
