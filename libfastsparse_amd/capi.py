@@ -8,6 +8,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfastsparse_hip.so")
+# FS_HOST_ONLY_LIB=<path>: a library holding ONLY the host half (fs_host.c, fs_sort.c: constructors, loaders, sorters) -- the
+# sanitizer build tests/test_host_sanitizers.py runs the host tests against; no device entry point is declared on it
+HOST_ONLY_LIB = os.environ.get("FS_HOST_ONLY_LIB")
 
 FS_HOST, FS_DEVICE = 0, 1
 
@@ -61,6 +64,9 @@ def lib():
     both use the same HIP runtime (same SONAME libamdhip64.so.7)."""
     global _lib
     if _lib is not None:
+        return _lib
+    if HOST_ONLY_LIB:
+        _lib = C.CDLL(HOST_ONLY_LIB)
         return _lib
     if not os.path.exists(LIB_PATH):
         # a fresh checkout: compile the HIP sources in-tree (hipcc cross-compiles gfx950 without a GPU)
