@@ -142,6 +142,7 @@ struct BinnedCsr {
   double *prod = nullptr;      // n * kw, pass-2 order: written by pass 1, read by pass 2
   unsigned *band_ptr = nullptr;  // B + 1: first pass-1 group of every band
   int nwg1 = 0;                // pass-1 workgroups (persistent, one per CU)
+  int slots = 0;               // pass-2 workgroups resident together (one per CU: the y slice fills LDS)
   unsigned *bin_ptr = nullptr; // P + 1: first pass-2 group of every panel
   int *panel_row = nullptr;    // P + 1: first (virtual) row of every panel
   int split = 0, nvrow = 0;    // virtual rows, as in TiledCsr

@@ -1280,6 +1280,10 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   static const double fill = [] { const char *v = getenv("FS_BIN_FILL"); return v && *v ? atof(v) / 100.0 : 0.8; }();
   int64_t want = (int64_t)((double)nvrow / (fill * R)) + 1;
   if (want > slots) want = (want + slots - 1) / slots * slots;
+  // fewer panels than CUs (a shard of 1-3 M rows: strong scaling cuts config 2 into such): pass 2 would leave most of the chip
+  // idle, so the panels are made smaller until every CU has one (FS_BIN_MIN_PANELS=0 keeps the tall panels: A/B runs)
+  static const int min_panels = [] { const char *v = getenv("FS_BIN_MIN_PANELS"); return v && *v ? atoi(v) : 1; }();
+  if (min_panels && want < slots && (int64_t)nvrow >= (int64_t)slots * 256 && kw == 1) want = slots;
   std::vector<int> panel_row;
   {
     int r = 0;
@@ -1304,7 +1308,7 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   if (nruns >= (1ll << 28)) return FS_OK;
   // padding would dominate (a run is padded to whole groups: (ge - 1) / 2 entries on average)
   if (o.binning == 1 && (double)A.nnz / (double)nruns < 1.5 * ge) return FS_OK;
-  N->P = P; N->B = B;
+  N->P = P; N->B = B; N->slots = slots;
   FS_HIP(traced_malloc(&N->panel_row, sizeof(int) * panel_row.size()));
   FS_HIP(hipMemcpyAsync(N->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
 

@@ -1615,7 +1615,7 @@ int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int *
   std::vector<int> rows((size_t)nparts + 1, A.nrow), units((size_t)nparts + 1, 0);
   rows[0] = 0;
   bool cut = false;
-  if (kind == 7 && A.binned->nwg1 > 0 && nparts > 1 && A.binned->P >= nparts) {
+  if (kind == 7 && A.binned->nwg1 > 0 && nparts > 1 && A.binned->P > (A.binned->slots > 0 ? A.binned->slots : 256)) {
     BinnedCsr &N = *A.binned;
     if (!N.h_panel_row) {
       int *hp = (int *)malloc(sizeof(int) * ((size_t)N.P + 1));
@@ -1629,8 +1629,15 @@ int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int *
       vfirst.resize((size_t)A.nrow + 1);
       FS_HIP(hipMemcpy(vfirst.data(), N.vfirst, sizeof(int) * vfirst.size(), hipMemcpyDeviceToHost));
     }
+    // one pass-2 workgroup per CU (its y slice fills LDS) and launches of one stream run one after the other: a part is a
+    // whole number of generations of resident workgroups -- 4 parts of 192 panels on 256 CUs would take 4 generations where
+    // the undivided pass takes 3 (config 2: 768 panels)
+    const int slots = N.slots > 0 ? N.slots : 256;
+    const int gens = (N.P + slots - 1) / slots;
+    const int c = nparts < gens ? nparts : gens;
     for (int p = 0; p <= nparts; ++p) {
-      units[(size_t)p] = (int)((int64_t)N.P * p / nparts);
+      const int64_t w = p >= c ? N.P : (int64_t)slots * ((int64_t)gens * p / c);
+      units[(size_t)p] = (int)(w < N.P ? w : N.P);
       const int vcut = N.h_panel_row[units[(size_t)p]];
       // cut rows: the rows whose every piece lies below the virtual row vcut
       rows[(size_t)p] = !N.split ? vcut : p == nparts ? A.nrow :

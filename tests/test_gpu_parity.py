@@ -1049,7 +1049,7 @@ def test_product_in_parts_finishes_rows_range_by_range(hip, kind):
     import torch
     from libfastsparse_amd import capi
     rng = np.random.default_rng(len(kind))
-    opt, nrow, ncol, per = {"two-pass": ("binning", 1_200_000, 700_001, 8), "two-pass cut rows": ("binning", 600_000, 700_001, 8),
+    opt, nrow, ncol, per = {"two-pass": ("binning", 4_000_000, 700_001, 3), "two-pass cut rows": ("binning", 3_600_000, 700_001, 3),
                             # panel kernels are cut between generations of resident workgroups: more panels than CUs
                             "lds-staged": ("ldsx", 4_000_000, 4_096, 6), "tiled": ("tiling", 4_000_000, 300_000, 5),
                             "stream": (None, 50_000, 20_000, 10)}[kind]
