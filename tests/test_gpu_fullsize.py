@@ -44,6 +44,17 @@ def test_config2_fp64_csr_10m(hip_env):
     A.spmv(y, x, st)
     for lo in (0, 4_999_000, n - 3000):
         _window_check(capi, O, rp, cc, vv, x, y, lo, lo + 3000, exact=False)
+    # (1b) the same product in parts: three generations of panels = three real parts; every part's rows within the bound of
+    #      the whole product (valued: the sums are not run-to-run identical), rows of later parts still poisoned
+    rows = A.part_rows(4)
+    assert rows[0] == 0 and rows[-1] == n and all(a <= b for a, b in zip(rows, rows[1:]))
+    if A.kernel_name() == "two-pass":
+        assert sum(b > a for a, b in zip(rows, rows[1:])) == 3, rows
+    yp = torch.full((n,), -7.0, dtype=torch.float64, device="cuda")
+    for part in range(4):
+        A.spmv_part(yp, x, part, 4, st)
+        assert float((yp[:rows[part + 1]] - y[:rows[part + 1]]).abs().max()) <= 1e-12 * 16.0, part
+        assert rows[part + 1] == n or float(yp[rows[part + 1]:].max()) == -7.0
     # (2) linearity: A(2x) == 2 A(x) up to the order of the sums (the two-pass kernels add in arrival order)
     y2 = torch.empty_like(y)
     A.spmv(y2, 2.0 * x, st)
@@ -195,6 +206,17 @@ def test_config5_one_real_shard_rank3_of_8(hip_env):
     for a in range(0, nnz, step):
         total_i += int(xl[cc[a:a + step].long()].sum().item())
     assert int(y.to(torch.int64).sum().item()) == total_i, (kernel, Ap.kernel_name())
+    # the product in parts (what the all-gather inside the product rides on): with cut rows the combine pass follows by ranges
+    # of rows; rows below every cut are final after that part, and all parts together are the whole product bit for bit
+    rows = Ap.part_rows(4)
+    assert rows[0] == 0 and rows[-1] == nrow and all(a <= b for a, b in zip(rows, rows[1:]))
+    if Ap.kernel_name() == "two-pass":
+        assert sum(b > a for a, b in zip(rows, rows[1:])) >= 3, rows
+    yp = torch.full((nrow,), -7.0, dtype=torch.float64, device="cuda")
+    for part in range(4):
+        Ap.spmv_part(yp, xi, part, 4, st)
+        assert bool(torch.equal(yp[:rows[part + 1]], y[:rows[part + 1]])), part
+    assert bool(torch.equal(yp, y))
 
 
 def test_config3_through_its_own_entry_points_coo(hip_env):
