@@ -27,6 +27,7 @@ Options &options()
     if (const char *v = getenv("FS_TILED_FLAGS")) q.tiled_flags = atoi(v);
     if (const char *v = getenv("FS_BIN_ROWS")) q.bin_rows = atoi(v);
     if (const char *v = getenv("FS_TILE_COLS")) q.tile_cols = atoi(v);
+    if (const char *v = getenv("FS_LONG_ROWS")) q.long_rows = atoi(v);
     return q;
   }();
   return o;
@@ -141,6 +142,8 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "bin_rows")) { fs::options().bin_rows = value; return FS_OK; }
   if (!strcmp(name, "ldsx")) { fs::options().ldsx = value; return FS_OK; }
   if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
+  if (!strcmp(name, "long_rows")) { fs::options().long_rows = value; return FS_OK; }
+  if (!strcmp(name, "long_min_len")) { fs::options().long_min_len = value; return FS_OK; }
   if (!strcmp(name, "spmm_kernel")) { fs::options().spmm_kernel = value; return FS_OK; }
   if (!strcmp(name, "ata_kernel")) { fs::options().ata_kernel = value; return FS_OK; }
   if (!strcmp(name, "device_build")) { fs::options().device_build = value; return FS_OK; }
@@ -157,6 +160,7 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "tile_cols")) return fs::options().tile_cols;
   if (name && !strcmp(name, "tile_split")) return fs::options().tile_split;
   if (name && !strcmp(name, "binning")) return fs::options().binning;
+  if (name && !strcmp(name, "long_rows")) return fs::options().long_rows;
   if (name && !strcmp(name, "ldsx")) return fs::options().ldsx;
   if (name && !strcmp(name, "reproducible")) return fs::options().reproducible;
   if (name && !strcmp(name, "spmm_kernel")) return fs::options().spmm_kernel;
@@ -334,6 +338,17 @@ int fs_copy_segments(int nseg, const int64_t *table_dev, int64_t max_count, cons
 
 // ---- diagnostics (not part of include/fastsparse_hip.h; used by tools/trace_tiled.py and the tests) --------
 int fs_debug_last_host_path(void) { return fs::last_host_path(); }
+
+// rows taken out of the two-pass copy (LongRows) and their entries incl. padding; 0 / 0 when the copy has none
+int fs_debug_long_rows(fs_matrix_t A, int transposed, int64_t *out2)
+{
+  if (!A || !out2 || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  const fs::LongRows *L = (a.binned && a.binned->built) ? a.binned->lr : nullptr;
+  out2[0] = L ? L->nlong : 0;
+  out2[1] = L ? L->n : 0;
+  return FS_OK;
+}
 
 int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
 {

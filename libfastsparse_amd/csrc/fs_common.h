@@ -127,8 +127,29 @@ constexpr int kBinGroup = 1 << kBinGroupLog;  // entries per group = one 128-byt
                                                // lines were measured 19 % slower in pass 1: 0.459 vs 0.386 ms)
 constexpr int kBinShareMin = 8192;     // a pass-1 workgroup streams at least this many entries
 
+// The longest rows of a heavy-tailed matrix (BASELINE config 5: power-law lengths up to 10^6), taken OUT of the two-pass copy.
+// A row with many more entries than there are column bands has several entries per band; the two-pass pair would ship each of
+// them through the product stream (16 bytes written and read back per entry).  A few thousand such rows hold 40 % of a config-5
+// shard's entries, and their accumulators -- 8 bytes each -- fit into LDS NEXT TO a band of x: spmv_longrows_kernel sweeps the
+// bands like pass 1 and adds every product straight into its row's LDS accumulator, no intermediate at all (10 bytes per entry).
+constexpr int kLongRowsMax = 3072;     // accumulators in LDS: 24 KiB next to the 128 KiB band of x
+struct LongRows {
+  int nlong = 0;                // rows taken out (ascending row ids)
+  int64_t n = 0;                // their entries, every band padded to an even count
+  int B = 0;                    // bands of kBinCols columns
+  int *row = nullptr;           // nlong: row id
+  uint16_t *lcol = nullptr;     // n, (band, long row) order: column - band * kBinCols; padding = kBinCols (the zero slot)
+  uint16_t *lrow = nullptr;     // n: index of the long row; padding = the previous entry's
+  double *vals = nullptr;       // n (nullptr: pattern-only)
+  int64_t *band_ptr = nullptr;  // B + 1: first entry of every band
+  double *ylong = nullptr;      // nlong: the sums of one product, zeroed before and scattered into y after
+  int nwg = 0;                  // persistent workgroups
+  int *h_row = nullptr;         // host mirror of row (products in parts scatter the rows of a range)
+};
+
 struct BinnedCsr {
   bool built = false;
+  LongRows *lr = nullptr;      // the rows that are NOT in this copy (their product: spmv_longrows_kernel)
   int kw = 1;                  // right-hand sides one sweep serves: bands of kBinCols / kw columns (kw * 8 bytes of X per
                                // column in LDS), panels of at most kBinRowsMax / kw rows, groups of kBinGroup / kw entries
                                // (a group is always kBinGroup products = one 128-byte line)
@@ -241,6 +262,9 @@ struct Options {
   int bin_rows = 0;      // override the rows per panel of the two-pass copy (0 = kBinRowsMax)
   int ldsx = 1;          // the copy for the LDS-staged kernel: 1 when the estimates do not rule it out, 2 always, 0 never
   int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
+  int long_rows = 1;     // the longest rows of a heavy-tailed matrix outside the two-pass copy (LongRows): 1 when it pays, 2 always
+                         // (every row of at least long_min_len entries, at most kLongRowsMax of them), 0 never
+  int long_min_len = 0;  // override of the length from which a row counts as long (0 = twice the number of column bands)
   int device_build = -1; // format constructors (new_csr, new_bcsr, new_cbcsr, new_bsbm, new_bsdm): -1 = FS_DEVICE_BUILD or 1;
                          // 0 host loops, 1 on the device from 4 M entries, 2 on the device whenever one is visible
   int ata_kernel = 0;    // fs_ata_mul: 0 / 1 two products (A, then the cached A'), 2 the fused single kernel (no copy of A')

@@ -136,9 +136,21 @@ static void free_tiled_slot(TiledCsr *&T)
 static void free_tiled(DeviceCsr &A) { free_tiled_slot(A.tiled); }
 static void free_tiledx(DeviceCsr &A) { free_tiled_slot(A.tiledx); }
 
+static void free_long_rows(LongRows *&L)
+{
+  if (!L) return;
+  void *owned[] = {L->row, L->lcol, L->lrow, L->vals, L->band_ptr, L->ylong};
+  for (void *q : owned)
+    if (q) (void)traced_free(q);
+  free(L->h_row);
+  delete L;
+  L = nullptr;
+}
+
 static void free_binned_slot(BinnedCsr *&N)
 {
   if (!N) return;
+  free_long_rows(N->lr);
   void *owned[] = {N->lcol, N->vals, N->gdst, N->lrow, N->prod, N->band_ptr, N->bin_ptr, N->panel_row, N->vfirst, N->yv};
   for (void *q : owned)
     if (q) (void)traced_free(q);
@@ -187,6 +199,7 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
     int64_t b = N->n * (2 + 2 + 8ll * N->kw + (N->vals ? 8 : 0)) + 4 * (N->n / (kBinGroup / N->kw)) + 4ll * (N->B + 1) + 8ll * (N->P + 1);
     if (N->vfirst) b += 4ll * (A.nrow + 1);
     if (N->yv) b += 8ll * N->nvrow * N->kw;
+    if (N->lr) b += N->lr->n * (4 + (N->lr->vals ? 8 : 0)) + 12ll * N->lr->nlong + 8ll * (N->lr->B + 1);
     return b;
   };
   out[0] = (A.owns ? 4ll * (A.nrow + 1) + 4 * A.nnz + (A.vals ? 8 * A.nnz : 0) : 0) + 4ll * (A.nchunks + 1) + 16ll * A.nchunks;
@@ -1205,10 +1218,239 @@ __global__ void bin_ptr_kernel(int B, int P, const unsigned *__restrict__ start1
 
 static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int kw);
 
+// ---- the longest rows of a heavy-tailed matrix, outside the two-pass copy (LongRows, fs_common.h) -------------------------
+__global__ void long_candidates_kernel(int nrow, int minlen, const int *__restrict__ row_ptr, int *__restrict__ count, int cap,
+                                       int2 *__restrict__ out)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrow) return;
+  const int len = row_ptr[r + 1] - row_ptr[r];
+  if (len < minlen) return;
+  const int k = atomicAdd(count, 1);
+  if (k < cap) out[k] = make_int2(r, len);
+}
+
+__global__ void long_mark_kernel(int nlong, const int *__restrict__ rows, int *__restrict__ row_to_long)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nlong) row_to_long[rows[i]] = i;
+}
+
+__global__ void main_len_kernel(int nrow, const int *__restrict__ row_ptr, const int *__restrict__ row_to_long, int *__restrict__ len)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrow) return;
+  len[r] = (r == nrow || row_to_long[r] >= 0) ? 0 : row_ptr[r + 1] - row_ptr[r];
+}
+
+// every entry goes either to its place in the CSR without the long rows or, as (key = band * nlong + long row, source index),
+// to the list the long rows' copy is sorted from
+__global__ void split_entries_kernel(int nrow, int64_t nnz, int nlong, const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                     const double *__restrict__ vals, const int *__restrict__ row_to_long,
+                                     const int *__restrict__ main_rp, const int64_t *__restrict__ long_ptr,
+                                     int *__restrict__ main_cols, double *__restrict__ main_vals, unsigned *__restrict__ lkey,
+                                     unsigned *__restrict__ lsrc)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const int r = last_le(row_ptr, nrow, i);
+  const int64_t k = i - row_ptr[r];
+  const int l = row_to_long[r];
+  if (l < 0) {
+    const int64_t d = (int64_t)main_rp[r] + k;
+    main_cols[d] = cols[i];
+    if (vals) main_vals[d] = vals[i];
+  } else {
+    const int64_t d = long_ptr[l] + k;
+    lkey[d] = (unsigned)(cols[i] / kBinCols) * (unsigned)nlong + (unsigned)l;
+    lsrc[d] = (unsigned)i;
+  }
+}
+
+__global__ void long_band_start_kernel(int B, int nlong, int64_t n, const unsigned *__restrict__ skeys, int64_t *__restrict__ start)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > B) return;
+  const uint64_t key = (uint64_t)b * (uint64_t)nlong;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if ((uint64_t)skeys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  start[b] = lo;
+}
+
+__global__ void long_scatter_kernel(int64_t n, int nlong, const unsigned *__restrict__ skeys, const unsigned *__restrict__ ssrc,
+                                    const int64_t *__restrict__ shift, const int *__restrict__ cols, const double *__restrict__ vals,
+                                    uint16_t *__restrict__ lcol, uint16_t *__restrict__ lrow, double *__restrict__ lvals)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const unsigned key = skeys[k], src = ssrc[k];
+  const unsigned b = key / (unsigned)nlong, l = key - b * (unsigned)nlong;
+  const int64_t d = k + shift[b];
+  lcol[d] = (uint16_t)(cols[src] - (int)b * kBinCols);
+  lrow[d] = (uint16_t)l;
+  if (lvals) lvals[d] = vals[src];
+}
+
+// a band with an odd number of entries ends in one padding entry: column = the zero slot, value 0, row = its neighbour's
+__global__ void long_pad_kernel(int B, const int64_t *__restrict__ start, const int64_t *__restrict__ band_ptr,
+                                uint16_t *__restrict__ lcol, uint16_t *__restrict__ lrow, double *__restrict__ lvals)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t cnt = start[b + 1] - start[b];
+  if (cnt & 1) {
+    const int64_t d = band_ptr[b] + cnt;
+    lcol[d] = (uint16_t)kBinCols;
+    lrow[d] = lrow[d - 1];
+    if (lvals) lvals[d] = 0.0;
+  }
+}
+
+// Takes the longest rows out: on success *out holds their copy and main_* a CSR of the same shape without their entries
+// (temporaries of the caller's build).  *out stays NULL when the matrix has no such rows or they would not pay.
+static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Scratch<int> &main_rp, Scratch<int> &main_cols,
+                           Scratch<double> &main_vals, int64_t *main_nnz)
+{
+  *out = nullptr;
+  const Options &o = options();
+  if (o.long_rows == 0 || o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz < (4 << 20) || A.ncol > kBinCols * 60000ll) return FS_OK;
+  const int B = (A.ncol + kBinCols - 1) / kBinCols;
+  // a row pays from a few entries per band on: twice the number of bands (its ~2 entries per band become one LDS add)
+  const int minlen = o.long_min_len > 0 ? o.long_min_len : (2 * B > 1024 ? 2 * B : 1024);
+  constexpr int kCap = 1 << 18;
+  Scratch<int> cnt;
+  Scratch<int2> cand;
+  FS_HIP(cnt.alloc(1));
+  FS_HIP(cand.alloc(kCap));
+  FS_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
+  hipLaunchKernelGGL(long_candidates_kernel, dim3(grid_for(A.nrow)), dim3(256), 0, s, A.nrow, minlen, A.row_ptr, cnt.p, kCap, cand.p);
+  FS_HIP(hipGetLastError());
+  int ncand = 0;
+  FS_HIP(hipMemcpyAsync(&ncand, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  if (ncand == 0 || ncand > kCap) return FS_OK;     // none, or so many that "long" means nothing here
+  std::vector<int2> h((size_t)ncand);
+  FS_HIP(hipMemcpy(h.data(), cand, sizeof(int2) * (size_t)ncand, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.y != b.y ? a.y > b.y : a.x < b.x; });
+  if ((int)h.size() > kLongRowsMax) h.resize(kLongRowsMax);        // the longest ones
+  std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
+  const int nlong = (int)h.size();
+  int64_t nl = 0;
+  std::vector<int> rows((size_t)nlong);
+  std::vector<int64_t> lptr((size_t)nlong + 1, 0);
+  for (int i = 0; i < nlong; ++i) { rows[(size_t)i] = h[(size_t)i].x; lptr[(size_t)i + 1] = lptr[(size_t)i] + h[(size_t)i].y; }
+  nl = lptr[(size_t)nlong];
+  if (o.long_rows == 1 && (double)nl < 0.10 * (double)A.nnz) return FS_OK;   // not worth a second kernel
+  if ((uint64_t)B * (uint64_t)nlong >= (1ull << 32)) return FS_OK;
+
+  LongRows *L = new LongRows();
+  struct Guard { LongRows *&p; bool keep = false; ~Guard() { if (!keep) free_long_rows(p); } } guard{L};
+  L->nlong = nlong; L->B = B;
+  FS_HIP(traced_malloc(&L->row, sizeof(int) * (size_t)nlong));
+  FS_HIP(hipMemcpyAsync(L->row, rows.data(), sizeof(int) * (size_t)nlong, hipMemcpyHostToDevice, s));
+  L->h_row = (int *)malloc(sizeof(int) * (size_t)nlong);
+  if (!L->h_row) { set_error("out of host memory"); return FS_ERR_HIP; }
+  memcpy(L->h_row, rows.data(), sizeof(int) * (size_t)nlong);
+  FS_HIP(traced_malloc(&L->ylong, sizeof(double) * (size_t)nlong));
+
+  // ---- split the entries -------------------------------------------------------------------------------------------
+  Scratch<int> row_to_long, mlen;
+  Scratch<int64_t> long_ptr, start, shift;
+  Scratch<unsigned> lkey, lsrc, skey, ssrc;
+  Scratch<char> tmp;
+  FS_HIP(row_to_long.alloc((size_t)A.nrow));
+  FS_HIP(mlen.alloc((size_t)A.nrow + 1));
+  FS_HIP(main_rp.alloc((size_t)A.nrow + 1));
+  FS_HIP(long_ptr.alloc((size_t)nlong + 1));
+  FS_HIP(hipMemsetAsync(row_to_long, 0xff, sizeof(int) * (size_t)A.nrow, s));
+  FS_HIP(hipMemcpyAsync(long_ptr, lptr.data(), sizeof(int64_t) * lptr.size(), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(long_mark_kernel, dim3(grid_for(nlong)), dim3(256), 0, s, nlong, L->row, row_to_long.p);
+  hipLaunchKernelGGL(main_len_kernel, dim3(grid_for((int64_t)A.nrow + 1)), dim3(256), 0, s, A.nrow, A.row_ptr, row_to_long.p, mlen.p);
+  FS_HIP(hipGetLastError());
+  size_t tmp_bytes = 0;
+  FS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, mlen.p, main_rp.p, 0, (size_t)A.nrow + 1, rocprim::plus<int>(), s));
+  FS_HIP(tmp.alloc(tmp_bytes));
+  FS_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, mlen.p, main_rp.p, 0, (size_t)A.nrow + 1, rocprim::plus<int>(), s));
+  const int64_t nm = A.nnz - nl;
+  *main_nnz = nm;
+  FS_HIP(main_cols.alloc((size_t)(nm > 0 ? nm : 1)));
+  if (A.vals) FS_HIP(main_vals.alloc((size_t)(nm > 0 ? nm : 1)));
+  FS_HIP(lkey.alloc((size_t)nl));
+  FS_HIP(lsrc.alloc((size_t)nl));
+  FS_HIP(skey.alloc((size_t)nl));
+  FS_HIP(ssrc.alloc((size_t)nl));
+  hipLaunchKernelGGL(split_entries_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, nlong, A.row_ptr, A.cols, A.vals,
+                     row_to_long.p, main_rp.p, long_ptr.p, main_cols.p, A.vals ? main_vals.p : nullptr, lkey.p, lsrc.p);
+  FS_HIP(hipGetLastError());
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < (uint64_t)B * (uint64_t)nlong) ++bits;
+  rocprim::double_buffer<unsigned> dk(lkey.p, skey.p), dv(lsrc.p, ssrc.p);
+  Scratch<char> tmp2;
+  tmp_bytes = 0;
+  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, (size_t)nl, 0, bits, s));     // stable: CSR order inside a run
+  FS_HIP(tmp2.alloc(tmp_bytes));
+  FS_HIP(rocprim::radix_sort_pairs((void *)tmp2.p, tmp_bytes, dk, dv, (size_t)nl, 0, bits, s));
+  FS_HIP(start.alloc((size_t)B + 1));
+  FS_HIP(shift.alloc((size_t)B + 1));
+  hipLaunchKernelGGL(long_band_start_kernel, dim3(grid_for((int64_t)B + 1)), dim3(256), 0, s, B, nlong, nl, dk.current(), start.p);
+  FS_HIP(hipGetLastError());
+  std::vector<int64_t> hs((size_t)B + 1), hp((size_t)B + 1, 0), hsh((size_t)B + 1, 0);
+  FS_HIP(hipMemcpyAsync(hs.data(), start, sizeof(int64_t) * hs.size(), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < B; ++b) {
+    const int64_t c = hs[(size_t)b + 1] - hs[(size_t)b];
+    hp[(size_t)b + 1] = hp[(size_t)b] + ((c + 1) & ~(int64_t)1);
+    hsh[(size_t)b] = hp[(size_t)b] - hs[(size_t)b];
+  }
+  L->n = hp[(size_t)B];
+  FS_HIP(traced_malloc(&L->band_ptr, sizeof(int64_t) * ((size_t)B + 1)));
+  FS_HIP(hipMemcpyAsync(L->band_ptr, hp.data(), sizeof(int64_t) * hp.size(), hipMemcpyHostToDevice, s));
+  FS_HIP(hipMemcpyAsync(shift, hsh.data(), sizeof(int64_t) * hsh.size(), hipMemcpyHostToDevice, s));
+  FS_HIP(traced_malloc(&L->lcol, sizeof(uint16_t) * (size_t)(L->n + 2)));
+  FS_HIP(traced_malloc(&L->lrow, sizeof(uint16_t) * (size_t)(L->n + 2)));
+  if (A.vals) FS_HIP(traced_malloc(&L->vals, sizeof(double) * (size_t)(L->n + 2)));
+  hipLaunchKernelGGL(long_scatter_kernel, dim3(grid_for(nl)), dim3(256), 0, s, nl, nlong, dk.current(), dv.current(), shift.p, A.cols,
+                     A.vals, L->lcol, L->lrow, L->vals);
+  hipLaunchKernelGGL(long_pad_kernel, dim3(grid_for(B)), dim3(256), 0, s, B, start.p, L->band_ptr, L->lcol, L->lrow, L->vals);
+  FS_HIP(hipGetLastError());
+  int dev = 0, ncu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+  const int64_t by_size = (L->n + kBinShareMin - 1) / kBinShareMin;
+  L->nwg = (int)(by_size < ncu ? by_size : ncu);
+  FS_HIP(hipStreamSynchronize(s));
+  guard.keep = true;
+  *out = L;
+  return FS_OK;
+}
+
 // Like the tiled copy, an optimisation: a failed build leaves the matrix on the other kernels.
 int build_binned(DeviceCsr &A, hipStream_t s)
 {
-  const int rc = build_binned_impl(A, s, A.binned, 1);
+  LongRows *lr = nullptr;
+  Scratch<int> main_rp, main_cols;
+  Scratch<double> main_vals;
+  int64_t main_nnz = 0;
+  if (split_long_rows(A, s, &lr, main_rp, main_cols, main_vals, &main_nnz) != FS_OK) {
+    free_long_rows(lr);
+    (void)hipGetLastError();
+  }
+  int rc;
+  if (lr) {
+    // the copy is built from the CSR WITHOUT the long rows (a temporary of this build: the copy keeps nothing of it)
+    DeviceCsr M;
+    M.nrow = A.nrow; M.ncol = A.ncol; M.nnz = main_nnz;
+    M.row_ptr = main_rp.p; M.cols = main_cols.p; M.vals = A.vals ? main_vals.p : nullptr; M.owns = false;
+    rc = build_binned_impl(M, s, A.binned, 1);
+    if (rc == FS_OK && A.binned && A.binned->built) { A.binned->lr = lr; lr = nullptr; }
+    M = DeviceCsr();
+  } else {
+    rc = build_binned_impl(A, s, A.binned, 1);
+  }
+  free_long_rows(lr);
   if (rc != FS_OK || (A.binned && !A.binned->built)) {
     free_binned(A);
     (void)hipGetLastError();

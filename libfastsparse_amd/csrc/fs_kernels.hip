@@ -1253,6 +1253,119 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
   reduce_panel<NTLD>(ytile, pbase + blockIdx.x, bin_ptr, panel_row, lrow, prod, y, ys);
 }
 
+// ------------------------------------------------------------------------------------------
+// The longest rows of a heavy-tailed matrix in ONE pass (LongRows, fs_common.h): persistent workgroups stream equal shares of
+// the (band, long row)-ordered entries; the band of x (128 KiB) AND one accumulator per long row (<= 24 KiB) sit in LDS.
+// A lane takes two consecutive entries; entries are sorted by row inside a band, so a wave adds up the products of equal rows
+// with a segmented scan over its lanes (a row of 10^6 entries has ~160 of them per band: 64 lanes hammering one LDS
+// address would serialise) and only the last lane of every run adds to the accumulator (ds_add_f64).  At the end of its
+// share a workgroup adds its accumulators to ylong in HBM (one atomic per row it touched).  10 bytes per entry where the
+// two-pass pair moves 28.
+// ------------------------------------------------------------------------------------------
+template <bool VALUED>
+__global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
+    int ncol, int B, int nlong, const int64_t *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
+    const uint16_t *__restrict__ lrow, const double *__restrict__ vals, const double *__restrict__ x, int xs,
+    double *__restrict__ ylong)
+{
+  __shared__ double xband[kBinCols + 8];
+  __shared__ double acc[kLongRowsMax];
+  const int t = threadIdx.x, lane = t & 63;
+  for (int i = t; i < nlong; i += kBinBlock) acc[i] = 0.0;
+  const int64_t pairs = band_ptr[B] >> 1;                         // every band holds an even number of entries
+  const int64_t e_beg = 2 * (pairs * blockIdx.x / gridDim.x), e_end = 2 * (pairs * (blockIdx.x + 1) / gridDim.x);
+  if (e_beg < e_end) {
+    int b;
+    {
+      int lo = 0, hi = B - 1;
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo + 1) >> 1);
+        if (band_ptr[mid] <= e_beg) lo = mid; else hi = mid - 1;
+      }
+      b = lo;
+    }
+    for (int64_t e = e_beg; e < e_end; ++b) {
+      const int64_t eb = band_ptr[b + 1] < e_end ? band_ptr[b + 1] : e_end;
+      if (eb <= e) continue;
+      const int c0 = b * kBinCols;
+      const int w = (ncol - c0 < kBinCols) ? ncol - c0 : kBinCols;
+      __syncthreads();
+      {
+        double r[kBinCols / kBinBlock];
+#pragma unroll
+        for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+          const int i = j * kBinBlock + t;
+          r[j] = __builtin_nontemporal_load(x + (int64_t)(c0 + (i < w ? i : w - 1)) * xs);
+        }
+#pragma unroll
+        for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+          const int i = j * kBinBlock + t;
+          xband[i] = (i < w) ? r[j] : 0.0;
+        }
+        if (t < 8) xband[kBinCols + t] = 0.0;
+      }
+      __syncthreads();
+      // whole rounds of the workgroup (2048 entries); lanes past the end of the segment carry a sentinel key and add nothing
+      for (int64_t o0 = e; o0 < eb; o0 += 2 * kBinBlock) {
+        const int64_t o = o0 + 2 * t;
+        const bool live = o < eb;
+        const int64_t oc = live ? o : e;                             // clamped address, masked below
+        const unsigned a = *reinterpret_cast<const unsigned *>(lcol + oc);
+        const unsigned rr = *reinterpret_cast<const unsigned *>(lrow + oc);
+        v2d p = {xband[a & 0xffffu], xband[a >> 16]};
+        if (VALUED) { const v2d v = *reinterpret_cast<const v2d *>(vals + oc); p.x *= v.x; p.y *= v.y; }
+        unsigned key = 0xffffffffu;
+        double sum = 0.0;
+        if (live) {
+          const unsigned r0 = rr & 0xffffu, r1 = rr >> 16;
+          if (r0 == r1) { key = r0; sum = p.x + p.y; }
+          else { __hip_atomic_fetch_add(&acc[r0], p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); key = r1; sum = p.y; }
+        }
+        // segmented inclusive scan over the wave: keys are sorted, so an equal key d lanes down means one run
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const unsigned ku = __shfl_up(key, d);
+          const double su = __shfl_up(sum, d);
+          if (lane >= d && ku == key) sum += su;
+        }
+        const unsigned kn = __shfl_down(key, 1);
+        if (live && (lane == 63 || kn != key))
+          __hip_atomic_fetch_add(&acc[key], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      e = eb;
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < nlong; i += kBinBlock) {
+    const double v = acc[i];
+    if (v != 0.0) unsafeAtomicAdd(ylong + i, v);
+  }
+}
+
+// y[row[i]] = ylong[i] for the long rows inside [row0, row1): the two-pass pair wrote 0 there (their entries are not in it)
+__global__ __launch_bounds__(kBlock) void longrows_scatter_kernel(int nlong, const int *__restrict__ row, const double *__restrict__ ylong,
+                                                                 double *__restrict__ y, int ys, int row0, int row1)
+{
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nlong) return;
+  const int r = row[i];
+  if (r >= row0 && r < row1) y[(int64_t)r * ys] = 0.0 + ylong[i];
+}
+
+static int launch_longrows(const DeviceCsr &A, const LongRows &L, const double *x, int xs, hipStream_t s)
+{
+  FS_HIP(hipMemsetAsync(L.ylong, 0, sizeof(double) * (size_t)L.nlong, s));
+  if (L.n == 0 || L.nwg == 0) return FS_OK;
+  if (A.vals)
+    hipLaunchKernelGGL(spmv_longrows_kernel<true>, dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, L.lcol, L.lrow,
+                       L.vals, x, xs, L.ylong);
+  else
+    hipLaunchKernelGGL(spmv_longrows_kernel<false>, dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, L.lcol, L.lrow,
+                       L.vals, x, xs, L.ylong);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 // (Both passes in ONE persistent launch behind a device-wide arrival counter were built and measured in round 3 and withdrawn:
 // on config 2 the single launch took 1.13 ms against 0.857 ms for the pair -- every wave's agent-scope release is a
 // buffer_wbl2 over the XCD's whole L2 -- and the kernel trace shows there is nothing to win: pass 2 starts 0.0 us after pass 1
@@ -1573,6 +1686,8 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
 #undef FS_EXPAND
     FS_HIP(hipGetLastError());
   }
+  if (N.lr && p0 == 0)          // behind pass 1, in front of pass 2: HBM-bound like both
+    if (int rc = launch_longrows(A, *N.lr, x, xs, s)) return rc;
   if (p1 > p0) {
     if (N.bcols == kBinColsBig)
       hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row,
@@ -1588,6 +1703,11 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   if (N.split && row1 > row0) {
     hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)(row1 - row0) + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                        row1, N.vfirst, N.yv, y, ys, row0);
+    FS_HIP(hipGetLastError());
+  }
+  if (N.lr && row1 > row0) {   // the long rows of this range: their sums were left in ylong by the launch behind pass 1
+    hipLaunchKernelGGL(longrows_scatter_kernel, dim3((unsigned)((N.lr->nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, N.lr->nlong,
+                       N.lr->row, N.lr->ylong, y, ys, row0, row1);
     FS_HIP(hipGetLastError());
   }
   return FS_OK;
@@ -1895,7 +2015,7 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
   const Options &o = options();
   const size_t nx = A.ncol > 0 ? (size_t)A.ncol : 1, ny = (size_t)A.nrow;
   if (int rc = host_pipe_ready(H, nx, ny, want_chunks)) return rc;
-  const bool two_pass = A.binned && A.binned->built && !A.binned->split && A.binned->nwg1 > 0 && !o.strict_order &&
+  const bool two_pass = A.binned && A.binned->built && !A.binned->split && !A.binned->lr && A.binned->nwg1 > 0 && !o.strict_order &&
                         !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7) && o.bin_flags == 0 && want_chunks > 1;
   if (!two_pass) {
     // the panel kernels (LDS-staged, L2-tiled) need all of x, but a workgroup that owns its rows finishes them: launched in

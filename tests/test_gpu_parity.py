@@ -1085,6 +1085,79 @@ def test_product_in_parts_finishes_rows_range_by_range(hip, kind):
             capi.set_option(opt, 1)
 
 
+@pytest.mark.parametrize("valued", [False, True])
+def test_longest_rows_outside_the_two_pass_copy(hip, valued):
+    """LongRows (round 3; BASELINE config 5's heavy tail): the longest rows of a power-law matrix are taken out of the two-pass
+    copy and summed in ONE pass with their accumulators in LDS next to the band of x.  Forced here on a small matrix (rows from
+    64 entries on, more candidates than the 3072 accumulators: the longest are taken), every row against the oracle; the
+    product in parts; a strided 3-column product (one sweep per column); and the same matrix without the long-row path."""
+    import ctypes as C
+    import torch
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    nrow, ncol = 300_000, 400_003
+    rp, cc, vv = pysynth.powerlaw(nrow, ncol, 2.3, 150_000, 0x10C6, valued=valued)
+    if not valued:
+        vv = None
+    st = capi.current_stream()
+    L = capi.lib()
+    x = S.x_int(3, ncol) if not valued else np.sin(7.0 * np.arange(ncol) + 0.3)
+    ref = O.csr_mul(nrow, rp, cc, vv, x)
+    scale = O.csr_abs_scale(nrow, rp, cc, vv, x) if valued else None
+
+    def check(got, what):
+        if valued:
+            assert np.all(np.abs(got - ref) <= TOL * np.maximum(scale, 1e-300)), what
+        else:
+            assert np.array_equal(got, ref), what
+
+    capi.set_option("binning", 2)
+    try:
+        for mode in (2, 0):
+            capi.set_option("long_rows", mode)
+            capi.set_option("long_min_len", 64)
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+            assert A.kernel_name() == "two-pass"
+            info = (C.c_int64 * 2)()
+            assert L.fs_debug_long_rows(A.h, 0, info) == 0
+            lens = np.diff(rp)
+            if mode == 2:
+                assert info[0] == 3072 and int((lens >= 64).sum()) > 3072           # the cap: the longest 3072 rows
+                assert info[1] >= int(np.sort(lens)[-3072:].sum())                   # all their entries (+ padding)
+            else:
+                assert info[0] == 0
+            xd = torch.from_numpy(x).cuda()
+            y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+            A.spmv(y, xd, st)
+            check(y.cpu().numpy(), ("whole", mode))
+            rows = A.part_rows(3)
+            yp = torch.full((nrow,), -7.0, dtype=torch.float64, device="cuda")
+            for part in range(3):
+                A.spmv_part(yp, xd, part, 3, st)
+                got = yp.cpu().numpy()
+                if valued:
+                    assert np.all(np.abs(got[:rows[part + 1]] - ref[:rows[part + 1]]) <= TOL * np.maximum(scale[:rows[part + 1]], 1e-300))
+                else:
+                    assert np.array_equal(got[:rows[part + 1]], ref[:rows[part + 1]]), (mode, part)
+            X = np.ascontiguousarray(np.stack([x, 2.0 * x, -x], 1))
+            Y = torch.full((nrow, 3), -1.0, dtype=torch.float64, device="cuda")
+            assert A.spmm_plan(3) == "two-pass per column"
+            A.spmm(Y, torch.from_numpy(X).cuda(), 3, st)
+            Yh = Y.cpu().numpy()
+            for j, f in enumerate((1.0, 2.0, -1.0)):
+                if valued:
+                    assert np.all(np.abs(Yh[:, j] - f * ref) <= 2 * TOL * np.maximum(scale, 1e-300)), j
+                else:
+                    assert np.array_equal(Yh[:, j], f * ref), j
+            yh = np.full(nrow, -1.0)
+            A.spmv_host(yh, x)                                   # host vectors: copy, product, copy (no band ranges with long rows)
+            check(yh, ("host", mode))
+            del A
+    finally:
+        for k_, v_ in (("binning", 1), ("long_rows", 1), ("long_min_len", 0)):
+            capi.set_option(k_, v_)
+
+
 def test_copy_segments_unpacks_a_padded_gather(hip):
     """fs_copy_segments: the one-launch unpack of the padded receive buffer of an all-gather of unequal shards"""
     import torch
