@@ -28,6 +28,7 @@ Options &options()
     if (const char *v = getenv("FS_BIN_ROWS")) q.bin_rows = atoi(v);
     if (const char *v = getenv("FS_TILE_COLS")) q.tile_cols = atoi(v);
     if (const char *v = getenv("FS_LONG_ROWS")) q.long_rows = atoi(v);
+    if (const char *v = getenv("FS_LONG_GEOMETRY")) q.long_geometry = atoi(v);
     return q;
   }();
   return o;
@@ -144,6 +145,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "binning")) { fs::options().binning = value; return FS_OK; }
   if (!strcmp(name, "long_rows")) { fs::options().long_rows = value; return FS_OK; }
   if (!strcmp(name, "long_min_len")) { fs::options().long_min_len = value; return FS_OK; }
+  if (!strcmp(name, "long_geometry")) { fs::options().long_geometry = value; return FS_OK; }
   if (!strcmp(name, "spmm_kernel")) { fs::options().spmm_kernel = value; return FS_OK; }
   if (!strcmp(name, "ata_kernel")) { fs::options().ata_kernel = value; return FS_OK; }
   if (!strcmp(name, "device_build")) { fs::options().device_build = value; return FS_OK; }

@@ -132,13 +132,16 @@ constexpr int kBinShareMin = 8192;     // a pass-1 workgroup streams at least th
 // them through the product stream (16 bytes written and read back per entry).  A few thousand such rows hold 40 % of a config-5
 // shard's entries, and their accumulators -- 8 bytes each -- fit into LDS NEXT TO a band of x: spmv_longrows_kernel sweeps the
 // bands like pass 1 and adds every product straight into its row's LDS accumulator, no intermediate at all (10 bytes per entry).
-constexpr int kLongRowsMax = 3072;     // accumulators in LDS: 24 KiB next to the 128 KiB band of x
+// two geometries of the 152 KiB of LDS: a wide band with few accumulators, or a narrower band with four times as many rows
+constexpr int kLongBandA = 16384, kLongRowsA = 3072;      // 128 KiB of x + 24 KiB of accumulators
+constexpr int kLongBandB = 8192, kLongRowsB = 12032;      //  64 KiB of x + 94 KiB of accumulators (160 KiB with the zero slots)
 struct LongRows {
   int nlong = 0;                // rows taken out (ascending row ids)
   int64_t n = 0;                // their entries, every band padded to an even count
-  int B = 0;                    // bands of kBinCols columns
+  int bcols = kLongBandA;       // columns per band (kLongBandA or kLongBandB)
+  int B = 0;                    // bands of bcols columns
   int *row = nullptr;           // nlong: row id
-  uint16_t *lcol = nullptr;     // n, (band, long row) order: column - band * kBinCols; padding = kBinCols (the zero slot)
+  uint16_t *lcol = nullptr;     // n, (band, long row) order: column - band * bcols; padding = bcols (the zero slot)
   uint16_t *lrow = nullptr;     // n: index of the long row; padding = the previous entry's
   double *vals = nullptr;       // n (nullptr: pattern-only)
   int64_t *band_ptr = nullptr;  // B + 1: first entry of every band
@@ -264,7 +267,8 @@ struct Options {
   int binning = 1;       // 1: build the two-pass copy when the heuristic says it pays, 2: always, 0: never
   int long_rows = 1;     // the longest rows of a heavy-tailed matrix outside the two-pass copy (LongRows): 1 when it pays, 2 always
                          // (every row of at least long_min_len entries, at most kLongRowsMax of them), 0 never
-  int long_min_len = 0;  // override of the length from which a row counts as long (0 = twice the number of column bands)
+  int long_min_len = 0;  // override of the length from which a row counts as long (0 = auto)
+  int long_geometry = 0; // 0 auto, 1 wide band / 3072 rows, 2 narrow band / 12288 rows (LongRows)
   int device_build = -1; // format constructors (new_csr, new_bcsr, new_cbcsr, new_bsbm, new_bsdm): -1 = FS_DEVICE_BUILD or 1;
                          // 0 host loops, 1 on the device from 4 M entries, 2 on the device whenever one is visible
   int ata_kernel = 0;    // fs_ata_mul: 0 / 1 two products (A, then the cached A'), 2 the fused single kernel (no copy of A')

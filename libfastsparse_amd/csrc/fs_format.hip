@@ -1245,7 +1245,7 @@ __global__ void main_len_kernel(int nrow, const int *__restrict__ row_ptr, const
 
 // every entry goes either to its place in the CSR without the long rows or, as (key = band * nlong + long row, source index),
 // to the list the long rows' copy is sorted from
-__global__ void split_entries_kernel(int nrow, int64_t nnz, int nlong, const int *__restrict__ row_ptr, const int *__restrict__ cols,
+__global__ void split_entries_kernel(int nrow, int64_t nnz, int nlong, int bcols, const int *__restrict__ row_ptr, const int *__restrict__ cols,
                                      const double *__restrict__ vals, const int *__restrict__ row_to_long,
                                      const int *__restrict__ main_rp, const int64_t *__restrict__ long_ptr,
                                      int *__restrict__ main_cols, double *__restrict__ main_vals, unsigned *__restrict__ lkey,
@@ -1262,7 +1262,7 @@ __global__ void split_entries_kernel(int nrow, int64_t nnz, int nlong, const int
     if (vals) main_vals[d] = vals[i];
   } else {
     const int64_t d = long_ptr[l] + k;
-    lkey[d] = (unsigned)(cols[i] / kBinCols) * (unsigned)nlong + (unsigned)l;
+    lkey[d] = (unsigned)(cols[i] / bcols) * (unsigned)nlong + (unsigned)l;
     lsrc[d] = (unsigned)i;
   }
 }
@@ -1280,7 +1280,7 @@ __global__ void long_band_start_kernel(int B, int nlong, int64_t n, const unsign
   start[b] = lo;
 }
 
-__global__ void long_scatter_kernel(int64_t n, int nlong, const unsigned *__restrict__ skeys, const unsigned *__restrict__ ssrc,
+__global__ void long_scatter_kernel(int64_t n, int nlong, int bcols, const unsigned *__restrict__ skeys, const unsigned *__restrict__ ssrc,
                                     const int64_t *__restrict__ shift, const int *__restrict__ cols, const double *__restrict__ vals,
                                     uint16_t *__restrict__ lcol, uint16_t *__restrict__ lrow, double *__restrict__ lvals)
 {
@@ -1289,13 +1289,13 @@ __global__ void long_scatter_kernel(int64_t n, int nlong, const unsigned *__rest
   const unsigned key = skeys[k], src = ssrc[k];
   const unsigned b = key / (unsigned)nlong, l = key - b * (unsigned)nlong;
   const int64_t d = k + shift[b];
-  lcol[d] = (uint16_t)(cols[src] - (int)b * kBinCols);
+  lcol[d] = (uint16_t)(cols[src] - (int)b * bcols);
   lrow[d] = (uint16_t)l;
   if (lvals) lvals[d] = vals[src];
 }
 
 // a band with an odd number of entries ends in one padding entry: column = the zero slot, value 0, row = its neighbour's
-__global__ void long_pad_kernel(int B, const int64_t *__restrict__ start, const int64_t *__restrict__ band_ptr,
+__global__ void long_pad_kernel(int B, int bcols, const int64_t *__restrict__ start, const int64_t *__restrict__ band_ptr,
                                 uint16_t *__restrict__ lcol, uint16_t *__restrict__ lrow, double *__restrict__ lvals)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1303,7 +1303,7 @@ __global__ void long_pad_kernel(int B, const int64_t *__restrict__ start, const 
   const int64_t cnt = start[b + 1] - start[b];
   if (cnt & 1) {
     const int64_t d = band_ptr[b] + cnt;
-    lcol[d] = (uint16_t)kBinCols;
+    lcol[d] = (uint16_t)bcols;
     lrow[d] = lrow[d - 1];
     if (lvals) lvals[d] = 0.0;
   }
@@ -1316,10 +1316,16 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
 {
   *out = nullptr;
   const Options &o = options();
-  if (o.long_rows == 0 || o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz < (4 << 20) || A.ncol > kBinCols * 60000ll) return FS_OK;
-  const int B = (A.ncol + kBinCols - 1) / kBinCols;
-  // a row pays from a few entries per band on: twice the number of bands (its ~2 entries per band become one LDS add)
-  const int minlen = o.long_min_len > 0 ? o.long_min_len : (2 * B > 1024 ? 2 * B : 1024);
+  if (o.long_rows == 0 || o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz < (4 << 20)) return FS_OK;
+  // geometry: the narrow band with 12032 accumulators covers more entries (a config-5 shard: 50 % against 40 %) at twice the
+  // number of band loads; measured on the config-5 shard: 2.24 ms against 2.29 (and 2.71 without this path), so it is the
+  // default; long_geometry / FS_LONG_GEOMETRY force either
+  const bool narrow = o.long_geometry != 1;
+  const int bcols = narrow ? kLongBandB : kLongBandA, cap_rows = narrow ? kLongRowsB : kLongRowsA;
+  const int B = (A.ncol + bcols - 1) / bcols;
+  // ANY row saves its intermediate products here; what limits the path is the number of accumulators, so the longest rows
+  // are taken.  Candidates: rows of at least 512 entries (shorter ones are too many to be worth collecting).
+  const int minlen = o.long_min_len > 0 ? o.long_min_len : 512;
   constexpr int kCap = 1 << 18;
   Scratch<int> cnt;
   Scratch<int2> cand;
@@ -1335,7 +1341,7 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   std::vector<int2> h((size_t)ncand);
   FS_HIP(hipMemcpy(h.data(), cand, sizeof(int2) * (size_t)ncand, hipMemcpyDeviceToHost));
   std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.y != b.y ? a.y > b.y : a.x < b.x; });
-  if ((int)h.size() > kLongRowsMax) h.resize(kLongRowsMax);        // the longest ones
+  if ((int)h.size() > cap_rows) h.resize((size_t)cap_rows);          // the longest ones
   std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
   const int nlong = (int)h.size();
   int64_t nl = 0;
@@ -1348,7 +1354,7 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
 
   LongRows *L = new LongRows();
   struct Guard { LongRows *&p; bool keep = false; ~Guard() { if (!keep) free_long_rows(p); } } guard{L};
-  L->nlong = nlong; L->B = B;
+  L->nlong = nlong; L->B = B; L->bcols = bcols;
   FS_HIP(traced_malloc(&L->row, sizeof(int) * (size_t)nlong));
   FS_HIP(hipMemcpyAsync(L->row, rows.data(), sizeof(int) * (size_t)nlong, hipMemcpyHostToDevice, s));
   L->h_row = (int *)malloc(sizeof(int) * (size_t)nlong);
@@ -1382,7 +1388,7 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   FS_HIP(lsrc.alloc((size_t)nl));
   FS_HIP(skey.alloc((size_t)nl));
   FS_HIP(ssrc.alloc((size_t)nl));
-  hipLaunchKernelGGL(split_entries_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, nlong, A.row_ptr, A.cols, A.vals,
+  hipLaunchKernelGGL(split_entries_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, nlong, bcols, A.row_ptr, A.cols, A.vals,
                      row_to_long.p, main_rp.p, long_ptr.p, main_cols.p, A.vals ? main_vals.p : nullptr, lkey.p, lsrc.p);
   FS_HIP(hipGetLastError());
   int bits = 1;
@@ -1412,9 +1418,9 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   FS_HIP(traced_malloc(&L->lcol, sizeof(uint16_t) * (size_t)(L->n + 2)));
   FS_HIP(traced_malloc(&L->lrow, sizeof(uint16_t) * (size_t)(L->n + 2)));
   if (A.vals) FS_HIP(traced_malloc(&L->vals, sizeof(double) * (size_t)(L->n + 2)));
-  hipLaunchKernelGGL(long_scatter_kernel, dim3(grid_for(nl)), dim3(256), 0, s, nl, nlong, dk.current(), dv.current(), shift.p, A.cols,
+  hipLaunchKernelGGL(long_scatter_kernel, dim3(grid_for(nl)), dim3(256), 0, s, nl, nlong, bcols, dk.current(), dv.current(), shift.p, A.cols,
                      A.vals, L->lcol, L->lrow, L->vals);
-  hipLaunchKernelGGL(long_pad_kernel, dim3(grid_for(B)), dim3(256), 0, s, B, start.p, L->band_ptr, L->lcol, L->lrow, L->vals);
+  hipLaunchKernelGGL(long_pad_kernel, dim3(grid_for(B)), dim3(256), 0, s, B, bcols, start.p, L->band_ptr, L->lcol, L->lrow, L->vals);
   FS_HIP(hipGetLastError());
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;

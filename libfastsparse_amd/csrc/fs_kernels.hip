@@ -1262,14 +1262,14 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
 // share a workgroup adds its accumulators to ylong in HBM (one atomic per row it touched).  10 bytes per entry where the
 // two-pass pair moves 28.
 // ------------------------------------------------------------------------------------------
-template <bool VALUED>
+template <bool VALUED, int BC, int NACC>
 __global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
     int ncol, int B, int nlong, const int64_t *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
     const uint16_t *__restrict__ lrow, const double *__restrict__ vals, const double *__restrict__ x, int xs,
     double *__restrict__ ylong)
 {
-  __shared__ double xband[kBinCols + 8];
-  __shared__ double acc[kLongRowsMax];
+  __shared__ double xband[BC + 8];
+  __shared__ double acc[NACC];
   const int t = threadIdx.x, lane = t & 63;
   for (int i = t; i < nlong; i += kBinBlock) acc[i] = 0.0;
   const int64_t pairs = band_ptr[B] >> 1;                         // every band holds an even number of entries
@@ -1287,22 +1287,22 @@ __global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
     for (int64_t e = e_beg; e < e_end; ++b) {
       const int64_t eb = band_ptr[b + 1] < e_end ? band_ptr[b + 1] : e_end;
       if (eb <= e) continue;
-      const int c0 = b * kBinCols;
-      const int w = (ncol - c0 < kBinCols) ? ncol - c0 : kBinCols;
+      const int c0 = b * BC;
+      const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
       __syncthreads();
       {
-        double r[kBinCols / kBinBlock];
+        double r[BC / kBinBlock];
 #pragma unroll
-        for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+        for (int j = 0; j < BC / kBinBlock; ++j) {
           const int i = j * kBinBlock + t;
           r[j] = __builtin_nontemporal_load(x + (int64_t)(c0 + (i < w ? i : w - 1)) * xs);
         }
 #pragma unroll
-        for (int j = 0; j < kBinCols / kBinBlock; ++j) {
+        for (int j = 0; j < BC / kBinBlock; ++j) {
           const int i = j * kBinBlock + t;
           xband[i] = (i < w) ? r[j] : 0.0;
         }
-        if (t < 8) xband[kBinCols + t] = 0.0;
+        if (t < 8) xband[BC + t] = 0.0;
       }
       __syncthreads();
       // whole rounds of the workgroup (2048 entries); lanes past the end of the segment carry a sentinel key and add nothing
@@ -1356,12 +1356,12 @@ static int launch_longrows(const DeviceCsr &A, const LongRows &L, const double *
 {
   FS_HIP(hipMemsetAsync(L.ylong, 0, sizeof(double) * (size_t)L.nlong, s));
   if (L.n == 0 || L.nwg == 0) return FS_OK;
-  if (A.vals)
-    hipLaunchKernelGGL(spmv_longrows_kernel<true>, dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, L.lcol, L.lrow,
-                       L.vals, x, xs, L.ylong);
-  else
-    hipLaunchKernelGGL(spmv_longrows_kernel<false>, dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, L.lcol, L.lrow,
-                       L.vals, x, xs, L.ylong);
+#define FS_LONG(V, BC, NA)                                                                                                   \
+  hipLaunchKernelGGL((spmv_longrows_kernel<V, BC, NA>), dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, L.lcol, \
+                     L.lrow, L.vals, x, xs, L.ylong)
+  if (L.bcols == kLongBandB) { if (A.vals) FS_LONG(true, kLongBandB, kLongRowsB); else FS_LONG(false, kLongBandB, kLongRowsB); }
+  else                       { if (A.vals) FS_LONG(true, kLongBandA, kLongRowsA); else FS_LONG(false, kLongBandA, kLongRowsA); }
+#undef FS_LONG
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -1085,8 +1085,9 @@ def test_product_in_parts_finishes_rows_range_by_range(hip, kind):
             capi.set_option(opt, 1)
 
 
+@pytest.mark.parametrize("geometry", [1, 2])
 @pytest.mark.parametrize("valued", [False, True])
-def test_longest_rows_outside_the_two_pass_copy(hip, valued):
+def test_longest_rows_outside_the_two_pass_copy(hip, valued, geometry):
     """LongRows (round 3; BASELINE config 5's heavy tail): the longest rows of a power-law matrix are taken out of the two-pass
     copy and summed in ONE pass with their accumulators in LDS next to the band of x.  Forced here on a small matrix (rows from
     64 entries on, more candidates than the 3072 accumulators: the longest are taken), every row against the oracle; the
@@ -1116,14 +1117,20 @@ def test_longest_rows_outside_the_two_pass_copy(hip, valued):
         for mode in (2, 0):
             capi.set_option("long_rows", mode)
             capi.set_option("long_min_len", 64)
+            capi.set_option("long_geometry", geometry)          # 1: 16384-column band + 3072 rows, 2: 8192 + 12032 rows
             A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
             assert A.kernel_name() == "two-pass"
             info = (C.c_int64 * 2)()
+            L.fs_debug_long_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
             assert L.fs_debug_long_rows(A.h, 0, info) == 0
             lens = np.diff(rp)
             if mode == 2:
-                assert info[0] == 3072 and int((lens >= 64).sum()) > 3072           # the cap: the longest 3072 rows
-                assert info[1] >= int(np.sort(lens)[-3072:].sum())                   # all their entries (+ padding)
+                cand = int((lens >= 64).sum())
+                cap = 3072 if geometry == 1 else 12032
+                want = min(cand, cap)
+                assert geometry == 2 or cand > cap                                   # geometry 1 exercises the cap: the longest 3072 rows
+                assert info[0] == want, (info[0], want)
+                assert info[1] >= int(np.sort(lens)[-want:].sum())                   # all their entries (+ padding)
             else:
                 assert info[0] == 0
             xd = torch.from_numpy(x).cuda()
@@ -1154,7 +1161,7 @@ def test_longest_rows_outside_the_two_pass_copy(hip, valued):
             check(yh, ("host", mode))
             del A
     finally:
-        for k_, v_ in (("binning", 1), ("long_rows", 1), ("long_min_len", 0)):
+        for k_, v_ in (("binning", 1), ("long_rows", 1), ("long_min_len", 0), ("long_geometry", 0)):
             capi.set_option(k_, v_)
 
 
