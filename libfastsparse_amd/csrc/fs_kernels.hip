@@ -1284,27 +1284,35 @@ __global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
       }
       b = lo;
     }
+    // a band holds few entries here (config-5 shard: 16 K per 64 KiB of x), so the band of x is requested one band AHEAD into
+    // registers and only copied to LDS at the band switch: its latency hides under the entries of the band before
+    double rn[BC / kBinBlock];
+    int have = -1;                                                   // band whose x is in rn
+    auto request = [&](int bb) {
+      const int cb = bb * BC;
+      const int wb = (ncol - cb < BC) ? ncol - cb : BC;
+#pragma unroll
+      for (int j = 0; j < BC / kBinBlock; ++j) {
+        const int i = j * kBinBlock + t;
+        rn[j] = __builtin_nontemporal_load(x + (int64_t)(cb + (i < wb ? i : wb - 1)) * xs);
+      }
+      have = bb;
+    };
     for (int64_t e = e_beg; e < e_end; ++b) {
       const int64_t eb = band_ptr[b + 1] < e_end ? band_ptr[b + 1] : e_end;
       if (eb <= e) continue;
       const int c0 = b * BC;
       const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
-      __syncthreads();
-      {
-        double r[BC / kBinBlock];
+      if (have != b) request(b);                                     // the first band of the share (or after empty bands)
+      __syncthreads();                                               // everyone is done with the previous band
 #pragma unroll
-        for (int j = 0; j < BC / kBinBlock; ++j) {
-          const int i = j * kBinBlock + t;
-          r[j] = __builtin_nontemporal_load(x + (int64_t)(c0 + (i < w ? i : w - 1)) * xs);
-        }
-#pragma unroll
-        for (int j = 0; j < BC / kBinBlock; ++j) {
-          const int i = j * kBinBlock + t;
-          xband[i] = (i < w) ? r[j] : 0.0;
-        }
-        if (t < 8) xband[BC + t] = 0.0;
+      for (int j = 0; j < BC / kBinBlock; ++j) {
+        const int i = j * kBinBlock + t;
+        xband[i] = (i < w) ? rn[j] : 0.0;
       }
+      if (t < 8) xband[BC + t] = 0.0;
       __syncthreads();
+      if (b + 1 < B && eb < e_end) request(b + 1);
       // whole rounds of the workgroup (2048 entries); lanes past the end of the segment carry a sentinel key and add nothing
       for (int64_t o0 = e; o0 < eb; o0 += 2 * kBinBlock) {
         const int64_t o = o0 + 2 * t;
