@@ -37,6 +37,15 @@ def check(name, nrow, ncol, rp, cc, vv=None, k=0):
         for a in range(0, nnz, 100_000_000):
             tot += int(xl[cc[a:a + 100_000_000].long()].sum().item())
         ok = ok and int(y.to(torch.int64).sum().item()) == tot
+    # the same product in parts (fs_spmv_part): rows final range by range, all parts together the whole product
+    rows = A.part_rows(4)
+    y3 = torch.full((nrow,), -7.0, dtype=torch.float64, device="cuda")
+    for part in range(4):
+        A.spmv_part(y3, x, part, 4, st)
+        r1 = rows[part + 1]
+        okp = bool(torch.equal(y3[:r1], y[:r1])) if vv is None else bool(((y3[:r1] - y2[:r1]).abs() <= 1e-9 * (1 + y2[:r1].abs())).all())
+        ok = ok and okp
+    ok = ok and rows[0] == 0 and rows[-1] == nrow
     if k:
         X = torch.stack([x + j for j in range(k)], 1).contiguous()
         Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
@@ -49,7 +58,7 @@ def check(name, nrow, ncol, rp, cc, vv=None, k=0):
                 capi.set_option("strict_order", 0)
             okj = bool(torch.equal(Y[:, j], y2)) if vv is None else bool(((Y[:, j] - y2).abs() <= 1e-9 * (1 + y2.abs())).all())
             ok = ok and okj
-    print("%-55s %-10s build %.2fs  %s" % (name, A.kernel_name(), tb, "OK" if ok else "FAIL"), flush=True)
+    print("%-55s %-10s build %.2fs  parts %s  %s" % (name, A.kernel_name(), tb, rows, "OK" if ok else "FAIL"), flush=True)
     return ok
 
 
@@ -76,6 +85,12 @@ def main():
     cc = torch.randint(0, 70_000_000, (nnz,), device=dev, dtype=torch.int32)
     good &= check("30M x 70M, two thirds empty rows, rows of 20M and 5M entries (%dM)" % (nnz // 1_000_000), 30_000_000, 70_000_000,
                   rp.to(torch.int32), cc, k=4)
+    # heavy tail with more long rows than accumulators (LongRows takes the longest 12 032), valued
+    from libfastsparse_amd.capi import synth_powerlaw
+    rp, cc, vv = synth_powerlaw(6_000_000, 50_000_000, 6.0, 400_000, 0xBEEF)
+    good &= check("6M x 50M power-law (scale 6, max 400K): %dM entries, valued" % (int(cc.numel()) // 1_000_000), 6_000_000, 50_000_000,
+                  rp, cc, vv, k=3)
+    del rp, cc, vv
     # valued, close to the int limit
     nrow, per = 67_108_860, 31
     rp, cc, vv = capi.synth_uniform(nrow, 9_999_999, per, 77)
