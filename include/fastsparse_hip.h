@@ -232,6 +232,10 @@ int  fs_dist_spmv_t(fs_dist_matrix_t M, double *z_host, const double *u_host);
 int  fs_dist_spmv_resident(fs_dist_matrix_t M);
 int  fs_dist_spmv_t_resident(fs_dist_matrix_t M);
 int  fs_dist_swap_xy(fs_dist_matrix_t M);
+/* (A'A + lambda I) x = b by conjugate gradients on the sharded matrix (bsbm_cg, cg.h:25-82, across the GPUs): everything
+ * resident, two products with their all-gathers inside per iteration, the vector steps replicated on every device (identical
+ * vectors everywhere: the dots need no exchange); b_host, x_host: ncol doubles; stops at ||r|| <= tol ||b|| */
+int  fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double lambda, double tol, int *out_iter);
 double *fs_dist_x(fs_dist_matrix_t M, int rank);
 double *fs_dist_y(fs_dist_matrix_t M, int rank);
 double *fs_dist_z(fs_dist_matrix_t M, int rank);

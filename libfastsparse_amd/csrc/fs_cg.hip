@@ -209,6 +209,39 @@ struct Workspace {
   ~Workspace() { for (void *p : bufs) (void)hipFree(p); }
 };
 
+// ---- the vector steps of CG as launchers, for callers that bring their own products (fs_dist_cg: the same steps on every
+// device of a row-sharded matrix).  part: kCgPartDoubles doubles of scratch, red: 1 double; each leaves its reduced value in red[0].
+int cg_step_init(int n, const double *b, double *x, double *r, double *p, double *part, double *red, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_init_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, b, x, r, p, part);
+  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_step_shift_dot(int n, double lambda, double *q, const double *p, double *part, double *red, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_shift_dot_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, lambda, q, p, part);
+  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_step_update(int n, double alpha, double *x, double *r, const double *p, const double *q, double *part, double *red, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_update_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, alpha, x, r, p, q, part);
+  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_step_direction(int n, double beta, double *p, const double *r, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_direction_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, beta, p, r);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 }  // namespace fs
 
 using namespace fs;

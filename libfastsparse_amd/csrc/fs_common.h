@@ -292,6 +292,14 @@ int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t
 int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const double *x_host);
 int last_host_path();
 
+// ---- the vector steps of CG (fs_cg.hip) for callers with their own products; every step leaves its dot / norm in red[0]
+constexpr int kCgPartDoubles = 3 * 1024;
+int cg_step_init(int n, const double *b, double *x, double *r, double *p, double *part, double *red, hipStream_t s);       // x = 0, r = p = b; b.b
+int cg_step_shift_dot(int n, double lambda, double *q, const double *p, double *part, double *red, hipStream_t s);          // q += lambda p; q.p
+int cg_step_update(int n, double alpha, double *x, double *r, const double *p, const double *q, double *part, double *red,
+                   hipStream_t s);                                                                                            // x += a p, r -= a q; r.r
+int cg_step_direction(int n, double beta, double *p, const double *r, hipStream_t s);                                        // p = r + beta p
+
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);
 int build_tiled(DeviceCsr &A, hipStream_t s);       // no-op unless options/heuristic ask for it

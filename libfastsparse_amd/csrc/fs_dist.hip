@@ -25,6 +25,7 @@
 // real devices.  RCCL with MORE THAN ONE rank has not run anywhere yet (no multi-GPU machine was available to the
 // builder); FS_DIST_FORCE_RCCL=1 takes a one-device context through the same group calls.
 #include <dlfcn.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -612,6 +613,86 @@ int fs_dist_swap_xy(fs_dist_matrix_t M)
   if (M->nrow != M->ncol) { fs::set_error("fs_dist_swap_xy: the matrix is not square"); return FS_ERR_ARG; }
   std::lock_guard<std::mutex> g(M->lock);
   M->x.swap(M->y);
+  return FS_OK;
+}
+
+// (A'A + lambda I) x = b on the row-sharded matrix: bsbm_cg (cg.h:25-82) across the GPUs, everything resident.  Every device
+// keeps the WHOLE x, r, p, q (fs_dist_x is p, fs_dist_z is q) and runs the same fused vector kernels on them -- identical
+// inputs, identical kernels, so every device holds identical vectors and the dots need no exchange: the host reads 8 bytes
+// from device 0 per reduction.  Per iteration: y = A p and q = A' y, each with its all-gather inside the product.  The O(F)
+// vector work is replicated, not divided, by the number of devices (libfastsparse_amd/dist.py ShardedCG's "gather" scheme
+// divides it; here the products dominate).  b_host / x_host: F = ncol doubles on the host.
+int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double lambda, double tol, int *out_iter)
+{
+  if (!M || !x_host || !b_host) { fs::set_error("fs_dist_cg: NULL argument"); return FS_ERR_ARG; }
+  if (!M->t.built) { fs::set_error("fs_dist_cg: call fs_dist_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(M->lock);
+  DeviceGuard guard;
+  fs_dist_t D = M->D;
+  const int n = D->n, F = M->ncol;
+  struct Work {
+    fs_dist_t D;
+    std::vector<double *> sol, r, b, part, red;
+    ~Work()
+    {
+      for (size_t d = 0; d < sol.size(); ++d) {
+        (void)hipSetDevice(D->dev[d]);
+        for (double *p : {sol[d], r[d], b[d], part[d], red[d]})
+          if (p) (void)hipFree(p);
+      }
+    }
+  } W{D, std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr),
+      std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr)};
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    FS_HIP(hipMalloc(&W.sol[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
+    FS_HIP(hipMalloc(&W.r[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
+    FS_HIP(hipMalloc(&W.b[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
+    FS_HIP(hipMalloc(&W.part[(size_t)d], sizeof(double) * fs::kCgPartDoubles));
+    FS_HIP(hipMalloc(&W.red[(size_t)d], sizeof(double) * 4));
+  }
+  if (int rc = upload_all(M, W.b, b_host, (size_t)F)) return rc;
+  auto reduced = [&](double *out) -> int {     // the value every device just reduced, from device 0
+    FS_HIP(hipSetDevice(D->dev[0]));
+    FS_HIP(hipMemcpyAsync(out, W.red[0], sizeof(double), hipMemcpyDeviceToHost, D->stream[0]));
+    FS_HIP(hipStreamSynchronize(D->stream[0]));
+    return FS_OK;
+  };
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    if (int rc = fs::cg_step_init(F, W.b[(size_t)d], W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d], D->stream[d])) return rc;
+  }
+  double rsq_old = 0.0;
+  if (int rc = reduced(&rsq_old)) return rc;
+  const double stop = tol * sqrt(rsq_old);
+  int iter;
+  for (iter = 0; iter < F; iter++) {
+    if (int rc = dist_product(D, M->a, M->x, M->y)) return rc;      // y = A p
+    if (int rc = dist_product(D, M->t, M->y, M->z)) return rc;      // q = A' y
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg_step_shift_dot(F, lambda, M->z[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d], D->stream[d])) return rc;
+    }
+    double pq = 0.0;
+    if (int rc = reduced(&pq)) return rc;
+    const double alpha = rsq_old / pq;
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg_step_update(F, alpha, W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], M->z[(size_t)d], W.part[(size_t)d], W.red[(size_t)d],
+                                      D->stream[d])) return rc;
+    }
+    double rsq_new = 0.0;
+    if (int rc = reduced(&rsq_new)) return rc;
+    if (sqrt(rsq_new) <= stop) break;
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg_step_direction(F, rsq_new / rsq_old, M->x[(size_t)d], W.r[(size_t)d], D->stream[d])) return rc;
+    }
+    rsq_old = rsq_new;
+  }
+  if (int rc = download_from(M, 0, x_host, W.sol[0], (size_t)F)) return rc;
+  if (int rc = dist_sync(D)) return rc;
+  if (out_iter) *out_iter = iter;
   return FS_OK;
 }
 

@@ -1575,6 +1575,17 @@ def test_native_multi_gpu_context_shards_by_nonzeros(hip, ranks):
                 if vals is None:                                           # ... and put that x on every rank
                     for r in range(ranks):
                         assert L.fs_copy_to_device(L.fs_dist_x(M, r), xi.ctypes.data, 8 * ncol) == 0
+            # bsbm_cg across the ranks, resident (pattern-only like the reference's BlockedSBM): against the oracle's solver
+            if vals is None:
+                bvec = np.sin(0.37 * np.arange(ncol) + 1.0)
+                xs = np.full(ncol, -1.0)
+                it = C.c_int(-1)
+                assert L.fs_dist_cg(M, xs.ctypes.data, bvec.ctypes.data, 3.0, 1e-8, C.byref(it)) == 0, L.fs_last_error()
+                xref, itref = O.cg_normal(nrow, ncol, rows_all, cc, bvec, 3.0, 1e-8)
+                assert abs(it.value - itref) <= max(2, itref // 20) and np.max(np.abs(xs - xref)) <= 1e-7 * max(1.0, np.abs(xref).max()), \
+                    (it.value, itref)
+                for r in range(ranks):                       # x of the next products is whatever the caller puts there
+                    assert L.fs_copy_to_device(L.fs_dist_x(M, r), x.ctypes.data, 8 * ncol) == 0
             # a kernel choice that moved after the plan was made (strict_order: the chunk-streaming kernel, one part) is followed
             capi.set_option("strict_order", 1)
             try:
