@@ -1140,19 +1140,22 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     return rec
 
 
-def run_also(args, prov, world, rank, nccl):
+def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     """the other BASELINE configs behind the same command: a list of sub-records, each a full record of its
-    workload.  A workload that fails leaves {"workload": ..., "error": ...} -- it must not take the headline down."""
+    workload.  A workload that fails leaves {"workload": ..., "error": ...} -- it must not take the headline down.  `recs` fills
+    as the workloads finish and `state["current"]` names the one running (the budget watchdog of main() prints what is there)."""
     import copy
     import torch
     import torch.distributed as dist
-    recs = []
+    recs = [] if recs is None else recs
+    state = {} if state is None else state
     sub = copy.copy(args)
     sub.cpu_sample_rows = args.cpu_sample_rows or 0
     plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {})] if world == 1 else \
            [("c2-strong", run_c2, {"strong": True}), ("c5", run_c5, {})]
     for name, fn, kw in plan:
         prov.release()
+        state["current"] = name
         t0 = time.perf_counter()
         a = copy.copy(sub)
         if world == 1:       # bounded samples for the CPU baselines of the sub-records: the default run stays within minutes
@@ -1176,8 +1179,28 @@ def run_also(args, prov, world, rank, nccl):
             recs.append(rec)
         if err and world > 1:
             break            # collectives may be out of step after a failure: stop here
+    state["current"] = None
     prov.release()
     return recs
+
+
+def budget_watchdog(seconds, rank, headline, recs, state):
+    """The headline must survive whatever the sub-workloads do: a rank that dies inside a collective of config 5 would leave the
+    others waiting for RCCL's own timeout, longer than the driver waits.  After `seconds` (FS_BENCH_BUDGET_S, default 480) every
+    rank ends itself; rank 0 first prints the line with the sub-records finished so far and the name of the one that was not."""
+    import threading
+
+    def fire():
+        if rank == 0 and headline is not None:
+            rec = dict(headline)
+            rec["also"] = list(recs) + [{"workload": state.get("current"), "error": "not finished within the %d s budget" % seconds}]
+            print(json.dumps(rec), flush=True)
+        os._exit(0 if headline is not None or rank != 0 else 1)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -1203,6 +1226,7 @@ def main():
     ap.add_argument("--spmm-kernel", type=int, default=0,
                     help="c4: 0 the product's choice, 1 row kernel, 4 the matrix-core experiment (profiling runs)")
     args = ap.parse_args()
+    t_start = time.perf_counter()
 
     # ---- ranks: a launcher's world must be the one asked for; without a launcher, start the ranks here, before this
     # process does anything with the GPU (a process that has initialised HIP must not be replaced or forked) -------
@@ -1244,7 +1268,11 @@ def main():
     if args.workload in ("all", "c2"):
         rec = run_c2(args, prov, world, rank, nccl, strong=args.strong)
         if args.workload == "all":
-            also = run_also(args, prov, world, rank, nccl)
+            also, state = [], {}
+            budget = float(os.environ.get("FS_BENCH_BUDGET_S", "480")) - (time.perf_counter() - t_start)
+            dog = budget_watchdog(max(budget, 30.0), rank, rec, also, state)
+            run_also(args, prov, world, rank, nccl, recs=also, state=state)
+            dog.cancel()
             if rank == 0 and rec is not None:
                 rec["also"] = also
     else:
