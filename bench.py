@@ -1270,7 +1270,7 @@ def main():
         if args.workload == "all":
             also, state = [], {}
             budget = float(os.environ.get("FS_BENCH_BUDGET_S", "480")) - (time.perf_counter() - t_start)
-            dog = budget_watchdog(max(budget, 30.0), rank, rec, also, state)
+            dog = budget_watchdog(max(budget, 5.0), rank, rec, also, state)
             run_also(args, prov, world, rank, nccl, recs=also, state=state)
             dog.cancel()
             if rank == 0 and rec is not None:
