@@ -418,4 +418,6 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
-    assert (p.stderr + p.stdout).count("bench.py needs a GPU") == 3
+    # every rank stops at the check -- unless the first one to fail got the others terminated before they reached it
+    # (spawn_ranks ends the survivors of a failed rank: they would wait in a collective for ever)
+    assert 1 <= (p.stderr + p.stdout).count("bench.py needs a GPU") <= 3
