@@ -60,6 +60,12 @@ def _worker(rank, world, port, ret):
             At = capi.Matrix.from_coo(thi - tlo, N, t_rows, t_cols, None)
             return A, At
         A, At = bench.in_turns(build, prov, world, rank, False)     # ranks sharing a card build one after the other
+
+        def prepare_two_columns():                                   # ... and so do the k-column copies (device sorts inside)
+            A.prepare(2, capi.current_stream())
+            A.prepare(2, capi.current_stream(), transposed=True)
+            At.prepare(2, capi.current_stream())
+        bench.in_turns(prepare_two_columns, prov, world, rank, False)
         ok, why = True, []
         assert A.kernel_name() == "two-pass", A.kernel_name()
         cuts = A.part_rows(3)
@@ -69,13 +75,13 @@ def _worker(rank, world, port, ret):
         st = capi.current_stream
         for k in (1, 2):
             def a_local(yl, xf):
-                (A.spmv(yl, xf, st()) if k == 1 else (A.prepare(k, st()), A.spmm(yl, xf, k, st())))
+                (A.spmv(yl, xf, st()) if k == 1 else A.spmm(yl, xf, k, st()))
 
             def t_local(zl, uf):
-                (At.spmv(zl, uf, st()) if k == 1 else (At.prepare(k, st()), At.spmm(zl, uf, k, st())))
+                (At.spmv(zl, uf, st()) if k == 1 else At.spmm(zl, uf, k, st()))
 
             def t_partial(zf, ul):
-                (A.spmv(zf, ul, st(), transposed=True) if k == 1 else (A.prepare(k, st(), transposed=True), A.spmm(zf, ul, k, st(), transposed=True)))
+                (A.spmv(zf, ul, st(), transposed=True) if k == 1 else A.spmm(zf, ul, k, st(), transposed=True))
 
             parts = fsd.HipParts(A) if k == 1 else None           # products in parts exist for single vectors
             op_a = fsd.ShardedOperator(a_local, rb, parts=parts, k=k, copy_segments=prov.copy_segments)
