@@ -10,7 +10,8 @@ process touches the GPU) and fails loudly if the world it finds is not N.
 ONE JSON line on rank 0.  The line itself is BASELINE config 2 (`metric`, `value`, `roofline`, `cpu_baseline` exactly as
 before); with the default `--workload all` its key "also" holds one sub-record per other BASELINE config, each with its own
 `value`, `roofline` (+ `traffic`), `self_check` and, at N = 1, `cpu_baseline`:
-    N = 1:  c3, c4 (k = 32, with k = 2 / 4 / 8 beside it), c5 as ONE real shard
+    N = 1:  c3, c4 (k = 32, with k = 2 / 4 / 8 beside it), c5 as ONE real shard, and the path's consumer: CG and
+            2-right-hand-side block CG on config 2's pattern
     N > 1:  c2 strong scaling (the one 10 M-row matrix cut over the ranks), c5 across the N ranks (with and without the
             all-gather, and with A'u)
 so that one driver command reaches every config (`--workload c2` prints the headline alone; c3 / c4 / c5 print that
@@ -1140,6 +1141,68 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     return rec
 
 
+def run_cg(args, prov, world, rank, nccl):
+    """SURVEY 8f-1, the consumer of the path: bsbm_cg / bsbm_cg2 (cg.h:25-82, 85-187) device resident on config 2's PATTERN (the
+    reference's CG runs on BlockedSBM, pattern-only): (A'A + 5 I) x = b to 1e-8, one and two right-hand sides.  Step = one solve;
+    the record's value = the algorithmic bytes of the two products of every iteration / time (the vector kernels ride on top)."""
+    import ctypes as C
+    import torch
+    from libfastsparse_amd import capi
+    if world != 1:
+        raise SystemExit("the CG sub-record is a one-GPU workload")
+    dev = prov.dev
+    n, per = args.rows, args.per_row
+    st = capi.current_stream()
+    rp, cc, _ = capi.synth_uniform(n, n, per, SEED_C2, valued=False)
+    A = capi.Matrix.from_csr(n, n, rp, cc, None, borrow=True)
+    rows = torch.arange(n, device=dev, dtype=torch.int32).repeat_interleave(per)
+    At = capi.Matrix.from_coo(n, n, cc, rows, None)           # A' as its own handle: the reference passes B and Bt
+    del rows
+    i = torch.arange(n, device=dev, dtype=torch.float64)
+    b1 = torch.sin(19.0 * i + 0.4)
+    b2 = torch.stack([b1, torch.cos(23.0 * i + 0.7)], 1).contiguous()
+    L = capi.lib()
+    out = {}
+    for k, b in ((1, b1), (2, b2)):
+        x = torch.empty_like(b)
+        it = C.c_int(0)
+        f = L.fs_cg if k == 1 else L.fs_cg2
+        capi.check(f(A.h, At.h, x.data_ptr(), b.data_ptr(), 5.0, 1e-8, C.byref(it), st), "fs_cg")      # warm (k = 2: prepares the copies)
+        prov.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps // 10)):
+            capi.check(f(A.h, At.h, x.data_ptr(), b.data_ptr(), 5.0, 1e-8, C.byref(it), st), "fs_cg")
+        prov.synchronize()
+        dt = (time.perf_counter() - t0) / max(1, args.steps // 10)
+        iters = it.value + 1
+        # self-check: the residual of the returned x, by two products and an axpy outside the solver
+        bb, xx = b.reshape(n, k), x.reshape(n, k)
+        worst = 0.0
+        t = torch.empty(n, dtype=torch.float64, device=dev)
+        q = torch.empty(n, dtype=torch.float64, device=dev)
+        for j in range(k):
+            xj = xx[:, j].contiguous()
+            A.spmv(t, xj, st)
+            At.spmv(q, t, st)
+            r = bb[:, j] - (q + 5.0 * xj)
+            worst = max(worst, float(r.norm() / bb[:, j].norm()))
+        bytes_it = 2 * csr_bytes(n * per, n, n, valued=False, k=k)
+        out[k] = {"iterations": iters, "ms_per_solve": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters,
+                  "products_GBs": bytes_it * iters / dt / 1e9, "relative_residual": worst, "ok": worst <= 2e-8,
+                  "product_kernel": A.kernel_name() if k == 1 else A.spmm_plan(2)}
+    v = out[2]
+    return {"metric": "block CG (2 right-hand sides) on config 2's pattern: algorithmic GB/s of its products", "value": v["products_GBs"],
+            "unit": "GB/s", "n_gpus": 1, "steps": max(1, args.steps // 10), "warmup": 1, "ms_per_step": v["ms_per_solve"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SURVEY 8f-1: bsbm_cg / bsbm_cg2 device resident, (A'A + 5 I) x = b, A = config 2's pattern %d x %d x %d"
+                                   % (n, n, per), "cg": out[1], "cg2": out[2],
+                       "self_check": {"relative_residuals": [out[1]["relative_residual"], out[2]["relative_residual"]],
+                                      "ok": out[1]["ok"] and out[2]["ok"]}},
+            "roofline": _roofline("fs::spmm_expand_kernel<false, 2> + fs::spmm_reduce_kernel<2> (the two products of an iteration)",
+                                  v["products_GBs"], None, csr_bytes(n * per, n, n, valued=False, k=2),
+                                  v["ms_per_iteration"] / 2.0, 2 * v["iterations"] * max(1, args.steps // 10))}
+
+
 def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     """the other BASELINE configs behind the same command: a list of sub-records, each a full record of its
     workload.  A workload that fails leaves {"workload": ..., "error": ...} -- it must not take the headline down.  `recs` fills
@@ -1151,7 +1214,7 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     state = {} if state is None else state
     sub = copy.copy(args)
     sub.cpu_sample_rows = args.cpu_sample_rows or 0
-    plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {})] if world == 1 else \
+    plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {}), ("cg", run_cg, {})] if world == 1 else \
            [("c2-strong", run_c2, {"strong": True}), ("c5", run_c5, {})]
     for name, fn, kw in plan:
         prov.release()
@@ -1159,7 +1222,7 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
         t0 = time.perf_counter()
         a = copy.copy(sub)
         if world == 1:       # bounded samples for the CPU baselines of the sub-records: the default run stays within minutes
-            a.cpu_sample_rows = args.cpu_sample_rows or {"c3": 1_000_000, "c4": 200_000, "c5": 500_000}[name]
+            a.cpu_sample_rows = args.cpu_sample_rows or {"c3": 1_000_000, "c4": 200_000, "c5": 500_000}.get(name, 0)
         else:
             a.transpose = True
         try:
