@@ -1381,7 +1381,8 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   std::vector<int64_t> lptr((size_t)nlong + 1, 0);
   for (int i = 0; i < nlong; ++i) { rows[(size_t)i] = h[(size_t)i].x; lptr[(size_t)i + 1] = lptr[(size_t)i] + h[(size_t)i].y; }
   nl = lptr[(size_t)nlong];
-  if (o.long_rows == 1 && (double)nl < 0.10 * (double)A.nnz) return FS_OK;   // not worth a second kernel
+  // worth a second kernel (and a second sweep over x: 8 bytes per column against 18 saved per entry)?
+  if (o.long_rows == 1 && ((double)nl < 0.10 * (double)A.nnz || 18.0 * (double)nl < 16.0 * (double)A.ncol)) return FS_OK;
   if ((uint64_t)B * (uint64_t)nlong >= (1ull << 32)) return FS_OK;
 
   LongRows *L = new LongRows();
