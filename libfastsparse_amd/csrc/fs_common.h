@@ -78,8 +78,6 @@ struct TiledCsr {
   bool ldsx = false;           // geometry of the LDS-staged kernel (W <= kLdsxCols, R <= kLdsxRows)
   int R = 0, W = 0, P = 0, J = 0, lcol_bits = kTiledColBits;
   unsigned *pk = nullptr;      // nnz packed (local row, local col)
-  uint8_t *pk25 = nullptr;     // LDS-staged copy only: the same entries at 25 bits each (14-bit local row | 11-bit local column), a
-                               // bit stream read by spmv_ldsx_dma_kernel: 3.125 instead of 4 bytes of HBM traffic per entry
   double *vals = nullptr;      // nnz permuted values (nullptr: pattern-only)
   int4 *items = nullptr;       // nitems: {first entry, count, band, 0}
   int *item_ptr = nullptr;     // P + 1
@@ -259,8 +257,7 @@ struct Options {
   int tile_cols = 0;     // override W (0 = auto)
   int tile_split = 0;    // rows longer than this are cut into virtual rows (0 = 256)
   int tiled_flags = 0;   // tuning switches of the tiled kernels (launch_spmv_tiled): bit 0 cached entry loads, bit 1 the first
-                         // LDS-staged kernel, bit 2 no LDS DMA for the x slices (spmv_ldsx_pipe_kernel), bit 3 32-bit entries
-                         // in the DMA kernel (not the 25-bit stream); FS_TILED_FLAGS presets it
+                         // LDS-staged kernel, bit 2 no LDS DMA for the x slices (spmv_ldsx_pipe_kernel); FS_TILED_FLAGS presets it
   int reproducible = 0;  // 1: only kernels whose sums are bit-identical run to run (the two-pass kernels add with LDS
                          // atomics in arrival order); read when a matrix is created and at every product
   int bin_wgs = 0;       // override the number of persistent pass-1 workgroups (0 = one per CU)

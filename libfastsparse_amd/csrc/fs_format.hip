@@ -123,7 +123,7 @@ struct Scratch {
 static void free_tiled_slot(TiledCsr *&T)
 {
   if (!T) return;
-  void *owned[] = {T->pk, T->pk25, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item};
+  void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item};
   for (void *q : owned)
     if (q) (void)traced_free(q);
   free(T->h_panel_row);
@@ -188,7 +188,7 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
 {
   auto tiled_bytes = [&](const TiledCsr *T) -> int64_t {
     if (!T) return 0;
-    int64_t b = 4 * A.nnz + (T->pk25 ? (25 * A.nnz + 7) / 8 : 0) + (T->vals ? 8 * A.nnz : 0) + 16ll * T->nitems + 4ll * (T->P + 1) * 2;
+    int64_t b = 4 * A.nnz + (T->vals ? 8 * A.nnz : 0) + 16ll * T->nitems + 4ll * (T->P + 1) * 2;
     if (T->vfirst) b += 4ll * (A.nrow + 1);
     if (T->yv) b += 8ll * (T->split ? T->nvrow : A.nrow);
     b += 12ll * T->nchunks;
@@ -694,25 +694,6 @@ constexpr int kReorderThreads = 256;
 constexpr int kReorderSegs = kReorderThreads / 32;               // the item is counted in 8 segments at once
 constexpr int kReorderPer = kTiledItem / kReorderThreads;        // entries per thread when the item is copied out
 
-// the entries of an LDS-staged copy once more as a stream of 25-bit fields (14-bit local row << 11 | 11-bit local column):
-// a thread packs 8 entries into 25 bytes
-__global__ void pack25_kernel(int64_t n, int lcol_bits, const unsigned *__restrict__ pk, uint8_t *__restrict__ out)
-{
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t base = 8 * g;
-  if (base >= n) return;
-  uint8_t *o = out + 25 * g;
-  uint64_t acc = 0;
-  int nb = 0;
-  for (int e = 0; e < 8; ++e) {
-    const unsigned w = base + e < n ? pk[base + e] : 0u;
-    const uint64_t v = ((uint64_t)(w >> lcol_bits) << 11) | (w & 0x7ffu);
-    acc |= v << nb;
-    nb += 25;
-    while (nb >= 8) { *o++ = (uint8_t)(acc & 0xffu); acc >>= 8; nb -= 8; }
-  }
-}
-
 template <bool ARRANGE>
 __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int4 *__restrict__ items, int lcol_bits,
                                                                       unsigned *__restrict__ pk, double *__restrict__ vals)
@@ -1084,19 +1065,6 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
       hipLaunchKernelGGL(ldsx_reorder_kernel<false>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
     FS_HIP(hipGetLastError());
     FS_HIP(hipStreamSynchronize(s));
-  }
-  if (ldsx && T->nitems > 0 && W <= 2048 && T->R <= 16384) {
-    // the 25-bit stream of the DMA kernel (the order of the entries is final now); an optimisation: without it the kernel
-    // reads the 32-bit words
-    const size_t bytes = (size_t)((25 * ((int64_t)A.nnz + 8) + 7) / 8) + 16;
-    if (traced_malloc(&T->pk25, bytes) == hipSuccess) {
-      FS_HIP(hipMemsetAsync(T->pk25, 0, bytes, s));
-      hipLaunchKernelGGL(pack25_kernel, dim3(grid_for((A.nnz + 7) / 8)), dim3(256), 0, s, A.nnz, T->lcol_bits, T->pk, T->pk25);
-      FS_HIP(hipGetLastError());
-    } else {
-      (void)hipGetLastError();
-      T->pk25 = nullptr;
-    }
   }
   if (ldsx) {
     // chunks: exactly `total` of them (a whole number of generations of resident workgroups: 264 equal chunks on 256

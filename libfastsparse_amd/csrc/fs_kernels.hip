@@ -658,36 +658,6 @@ __device__ __forceinline__ void ldsx_load2_entries(const int4 d, int t, const un
   }
 }
 
-// The same pair from the 25-bit stream (TiledCsr::pk25): entry e sits at bit 25 e, so the pair of a thread is 50 bits starting
-// at bit 25 e = 8 * byte + (e & 7) (25 = 1 mod 8): ONE unaligned 8-byte load, shifted and masked where the words are used
-// (ldsx_word) -- a select or shift next to the load would make the compiler wait for it on the spot.
-typedef unsigned long long u64_a1 __attribute__((aligned(1)));
-template <bool VALUED, bool NT>
-__device__ __forceinline__ void ldsx_load2_packed(const int4 d, int t, const uint8_t *__restrict__ pk25,
-                                                  const double *__restrict__ vals, unsigned (&w)[2], double (&v)[2])
-{
-  const int64_t e = (int64_t)d.x + (2 * t < d.y ? 2 * t : 0);
-  const u64_a1 *pp = reinterpret_cast<const u64_a1 *>(pk25 + ((25 * e) >> 3));
-  const unsigned long long raw = NT ? __builtin_nontemporal_load(pp) : *pp;
-  w[0] = (unsigned)raw; w[1] = (unsigned)(raw >> 32);
-  if (VALUED) {
-    const v2d_a8 *vp = reinterpret_cast<const v2d_a8 *>(vals + e);
-    const v2d_a8 pv = NT ? __builtin_nontemporal_load(vp) : *vp;
-    v[0] = pv.x; v[1] = pv.y;
-  }
-}
-
-// entry q of the pair a thread holds in w, as (local row << bits) | local column: the 32-bit word itself, or the q-th 25-bit
-// field of the pair loaded from the packed stream (d: the item's descriptor, t: the thread)
-template <bool P25>
-__device__ __forceinline__ unsigned ldsx_word(const unsigned (&w)[2], int q, const int4 d, int t)
-{
-  if (!P25) return w[q];
-  const unsigned sh = (unsigned)(d.x + (2 * t < d.y ? 2 * t : 0)) & 7u;
-  const unsigned long long raw = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
-  return (unsigned)(raw >> (sh + 25u * (unsigned)q)) & 0x1ffffffu;
-}
-
 #ifndef FS_PIPE_SETS
 #define FS_PIPE_SETS 6
 #endif
@@ -1001,14 +971,12 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-template <bool VALUED, bool NT, int NSETS, bool P25 = false>
+template <bool VALUED, bool NT, int NSETS>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
-    const int *__restrict__ panel_row, int W, int lcol_bits_in, int ncol, const int4 *__restrict__ items,
+    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
     const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int ys)
 {
-  // P25: pk is the 25-bit stream (TiledCsr::pk25): 14-bit local row << 11 | 11-bit local column
-  const int lcol_bits = P25 ? 11 : lcol_bits_in;
   static_assert(NSETS % 3 == 0, "the slice buffer of a phase is a compile-time constant");
   static_assert(NSETS >= 4, "the sweep starts NSETS - 1 phases early and the DMA of an item is sent three phases before it");
   __shared__ double ytile[kLdsxRows];
@@ -1060,7 +1028,7 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
       double gnew[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const unsigned a = xbase[(ph + 1) % 3] + ((ldsx_word<P25>(w[s1], q, dset[s1], t) & cmask) << 3);   // item IT+1: gathered now
+        const unsigned a = xbase[(ph + 1) % 3] + ((w[s1][q] & cmask) << 3);                // item IT+1: gathered now
         if (FS_DMA_ABL != 4) asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
         else gnew[q] = 1.0;
       }
@@ -1088,14 +1056,13 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
         if (2 * t + q < dset[s0].y) {
           double pr = gcur[q];
           if (VALUED) pr *= v[s0][q];
-          const unsigned a = ybase + ((ldsx_word<P25>(w[s0], q, dset[s0], t) >> lcol_bits) << 3);
+          const unsigned a = ybase + ((w[s0][q] >> lcol_bits) << 3);
           if (FS_DMA_ABL != 3) asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
         }
       }
       // (the entries after the adds: requested right behind the DMA, 0.70 -> 0.74 ms -- memory instructions issued in a
       // burst queue up in front of the address unit)
-      if (P25) ldsx_load2_packed<VALUED, NT>(dset[sl], t, reinterpret_cast<const uint8_t *>(pk), vals, w[sl], v[sl]);
-      else     ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
+      ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(VALUED ? 5 : 3, FS_DMA_ADDS_LAST ? 15 : 0));
 #if !FS_DMA_ADDS_LAST
@@ -1646,18 +1613,11 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
       // slices by LDS DMA: unit-stride x, 16-byte aligned, an even number of columns (bit 2 of tiled_flags turns it off)
       if (!(options().tiled_flags & (2 | 4)) && xs == 1 && A.ncol >= 2 && (A.ncol & 1) == 0 &&
           (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
-#define FS_LDSXD(V, N, P)                                                                                                     \
-  hipLaunchKernelGGL((spmv_ldsx_dma_kernel<V, N, kLdsxDmaSets, P>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W,      \
-                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0,                                       \
-                     P ? reinterpret_cast<const unsigned *>(T.pk25) : T.pk, T.vals, x, out, ost)
-        // the entries as a 25-bit stream (3.125 instead of 4 bytes per entry from HBM) unless bit 3 of tiled_flags says no
-        if (T.pk25 && !(options().tiled_flags & 8)) {
-          if (A.vals) { if (nt) FS_LDSXD(true, true, true); else FS_LDSXD(true, false, true); }
-          else        { if (nt) FS_LDSXD(false, true, true); else FS_LDSXD(false, false, true); }
-        } else {
-          if (A.vals) { if (nt) FS_LDSXD(true, true, false); else FS_LDSXD(true, false, false); }
-          else        { if (nt) FS_LDSXD(false, true, false); else FS_LDSXD(false, false, false); }
-        }
+#define FS_LDSXD(V, N)                                                                                              \
+  hipLaunchKernelGGL((spmv_ldsx_dma_kernel<V, N, kLdsxDmaSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
+                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, ost)
+        if (A.vals) { if (nt) FS_LDSXD(true, true); else FS_LDSXD(true, false); }
+        else        { if (nt) FS_LDSXD(false, true); else FS_LDSXD(false, false); }
 #undef FS_LDSXD
       } else if (options().tiled_flags & 2) {      // bit 1: the first version (gather and add of an item in one phase)
         if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
