@@ -458,8 +458,11 @@ int fs_matrix_prepare(fs_matrix_t A, int k, int transposed, fs_stream_t stream)
   if (!A || k < 1) { set_error("fs_matrix_prepare: bad argument"); return FS_ERR_ARG; }
   if (transposed && !A->has_t) { set_error("fs_matrix_prepare: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(A->lock);
-  const int rc = fs::prepare_spmm(transposed ? A->at : A->a, k, (hipStream_t)stream);
-  fs::pool_trim();
+  fs::DeviceCsr &a = transposed ? A->at : A->a;
+  int needs = 0;
+  (void)fs::spmm_plan(a, k, &needs);
+  const int rc = fs::prepare_spmm(a, k, (hipStream_t)stream);   // nothing left to do: a plan lookup (the drop-in asks on every call)
+  if (needs) fs::pool_trim();
   return rc;
 }
 
