@@ -232,6 +232,12 @@ class HipProvider:
     def candidate_ms(self, A, transposed=False):
         return A.candidate_ms(transposed)
 
+    def trim(self):
+        """inside a workload, after a matrix has been built: the builders' idle scratch and torch's cached blocks go back to the
+        device (config 5 at N = 2 holds 1.6 G entries per rank: the next build needs the room)"""
+        self.capi.lib().fs_release_all()        # side table of the drop-in (unused here) and the builders' scratch pool
+        self.torch.cuda.empty_cache()
+
     def release(self):
         """between workloads: everything the previous one held goes back to the device"""
         import gc
@@ -1007,6 +1013,8 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     n_local = hi - lo
     A = in_turns(lambda: prov.csr(n_local, ncol, rp, cc, vv), prov, world, rank, nccl)
     bytes_local = csr_bytes(nnz, n_local, ncol)
+    if hasattr(prov, "trim"):
+        prov.trim()
 
     x = prov.sin_vector(ncol, 7.0, 0.3)
     if world > 1:
@@ -1027,6 +1035,8 @@ def run_c5(args, prov, world, rank, nccl, out=None):
             At = in_turns(lambda: prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), tv),
                           prov, world, rank, nccl)
             del tr, tc, tv
+            if hasattr(prov, "trim"):
+                prov.trim()
             opt = fsd.TransposedGatherOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb)
             opt.parts, opt.copy_segments = prov.parts(At), prov.copy_segments
             u = prov.sin_vector(n_global, 11.0, -0.2)
