@@ -13,7 +13,7 @@ before); with the default `--workload all` its key "also" holds one sub-record p
     N = 1:  c3, c4 (k = 32, with k = 2 / 4 / 8 beside it), c5 as ONE real shard, and the path's consumer: CG and
             2-right-hand-side block CG on config 2's pattern
     N > 1:  c2 strong scaling (the one 10 M-row matrix cut over the ranks), c5 across the N ranks (with and without the
-            all-gather, and with A'u)
+            all-gather, and with A'u), and the row-sharded CG (ShardedCG) on config 2's pattern
 so that one driver command reaches every config (`--workload c2` prints the headline alone; c3 / c4 / c5 print that
 workload's record as the line).
 
@@ -1213,6 +1213,69 @@ def run_cg(args, prov, world, rank, nccl):
                                   v["ms_per_iteration"] / 2.0, 2 * v["iterations"] * max(1, args.steps // 10))}
 
 
+def run_cg_dist(args, prov, world, rank, nccl):
+    """The iterating consumer across the ranks: ShardedCG -- bsbm_cg (cg.h:25-82) row-sharded, scheme "gather"
+    (both directions rows + all-gather, the y exchange inside the product, slices of x / r / p per rank, dots as 1-double
+    all-reduces) -- on config 2's PATTERN, weak scaling by rows: (A'A + 5 I) x = b to 1e-8.  value = algorithmic bytes of the two
+    products of every iteration over all ranks / max-over-ranks time."""
+    import torch
+    import torch.distributed as dist
+    from libfastsparse_amd import dist as fsd
+    per = args.per_row
+    n_local, ncol = args.rows, args.rows
+    n_global, lo = n_local * world, rank * n_local
+    cdev = prov.dev if nccl else "cpu"
+    rp, cc, _ = prov.uniform(n_local, ncol, per, SEED_C2, row_offset=lo, valued=False)
+    bounds = fsd.even_row_partition(n_global, world)
+    cb = fsd.even_row_partition(ncol, world)
+    tr, tc, _ = fsd.build_transposed_shard(rp, cc, None, lo, cb)
+    At = in_turns(lambda: prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), None), prov, world, rank, nccl)
+    del tr, tc
+    A = in_turns(lambda: prov.csr(n_local, ncol, rp, cc, None), prov, world, rank, nccl)
+    op_a = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments)
+    op_t = fsd.ShardedOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb, copy_segments=prov.copy_segments)
+    cg = fsd.ShardedCG(op_a, op_t, scheme="gather", nparts=max(1, args.parts))
+    b = prov.sin_vector(ncol, 19.0, 0.4)
+    x, it = cg.solve(b, 5.0, 1e-8)                         # warm
+    prov.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    x, it = cg.solve(b, 5.0, 1e-8)
+    prov.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    iters = it + 1
+    # residual of the returned x through the operators themselves
+    y = prov.empty(n_global)
+    op_a.apply(y, x)
+    q = prov.empty(cb[rank + 1] - cb[rank])
+    prov.spmv(At, q, y)
+    sl = slice(cb[rank], cb[rank + 1])
+    r = b[sl] - (q + 5.0 * x[sl])
+    nn = torch.stack([torch.dot(r, r), torch.dot(b[sl], b[sl])]).to(torch.float64)
+    nn = nn.to(cdev) if not nccl else nn
+    dist.all_reduce(nn)
+    rel = float((nn[0] / nn[1]).sqrt().item())
+    same = _same_on_all_ranks([float(x.sum())], cdev)
+    if rank != 0:
+        return None
+    bytes_it = world * (csr_bytes(n_local * per, n_local, ncol, valued=False) + csr_bytes(n_local * per, ncol // world, n_global, valued=False))
+    return {"metric": "row-sharded CG on config 2's pattern: algorithmic GB/s of its products (all ranks)", "value": bytes_it * iters / dt / 1e9,
+            "unit": "GB/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SURVEY 8f-1 across the ranks: ShardedCG (bsbm_cg row-sharded, scheme gather, %d parts), (A'A + 5 I) x = b, A = "
+                                   "config-2 pattern shards %d x %d, %d rows/GPU" % (max(1, args.parts), n_global, ncol, n_local),
+                       "iterations": iters, "ms_per_iteration": dt * 1e3 / iters,
+                       "exchange_per_iteration": "all-gather of y (%d doubles) inside the product, all-gather of p (%d doubles), two 1-double "
+                                                 "all-reduces" % (n_global, ncol),
+                       "self_check": {"relative_residual": rel, "ranks_hold_identical_x": same, "ok": rel <= 2e-8 and same},
+                       "rccl_status": "first contact: no multi-GPU machine was available to the builder"},
+            "roofline": _roofline(_klabel(prov.kernel_name(A), prov.kernel_name(At)), bytes_it / world * iters / dt / 1e9, None,
+                                  bytes_it / world / 2.0, dt * 1e3 / iters / 2.0, 2 * iters)}
+
+
 def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     """the other BASELINE configs behind the same command: a list of sub-records, each a full record of its
     workload.  A workload that fails leaves {"workload": ..., "error": ...} -- it must not take the headline down.  `recs` fills
@@ -1225,7 +1288,7 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     sub = copy.copy(args)
     sub.cpu_sample_rows = args.cpu_sample_rows or 0
     plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {}), ("cg", run_cg, {})] if world == 1 else \
-           [("c2-strong", run_c2, {"strong": True}), ("c5", run_c5, {})]
+           [("c2-strong", run_c2, {"strong": True}), ("c5", run_c5, {}), ("cg", run_cg_dist, {})]
     for name, fn, kw in plan:
         prov.release()
         state["current"] = name

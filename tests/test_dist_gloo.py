@@ -270,10 +270,10 @@ class OracleProvider:
             self.rows = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
 
     def csr(self, nrow, ncol, rp, cc, vv, transpose=False):
-        return self._M(nrow, ncol, rp.numpy(), cc.numpy(), vv.numpy())
+        return self._M(nrow, ncol, rp.numpy(), cc.numpy(), None if vv is None else vv.numpy())
 
     def coo(self, nrow, ncol, rows, cols, vals):
-        rp, cc, vv = self.O.coo_to_csr(nrow, rows.numpy(), cols.numpy(), vals.numpy())
+        rp, cc, vv = self.O.coo_to_csr(nrow, rows.numpy(), cols.numpy(), None if vals is None else vals.numpy())
         return self._M(nrow, ncol, rp, cc, vv)
 
     def spmv(self, A, y, x, transposed=False):
@@ -378,7 +378,7 @@ def _c2_worker(rank, world, port, z_scheme, ret):
                 and ex["z_scheme"] == z_scheme and rec["config"]["ms_per_step_without_exchanges"] > 0 \
                 and ex["bytes_received_per_rank_per_step"]["z_all_reduce_ring"] == 2 * ex["bytes_received_per_rank_per_step"]["z_row_shards_of_At_plus_all_gather"]
             names = [r.get("config", {}).get("workload", r.get("workload", "")) for r in also]
-            ok = ok and len(also) == 2 and "strong scaling" in names[0] and "config 5" in names[1] \
+            ok = ok and len(also) == 3 and "strong scaling" in names[0] and "config 5" in names[1] and "ShardedCG" in names[2] \
                 and all("error" not in r and r["config"]["self_check"]["ok"] and r["roofline"]["achieved"] > 0 for r in also) \
                 and also[0]["scaling"] == "strong" and also[1]["config"]["with_transpose"]["value"] > 0
             ret["names"] = names
