@@ -135,6 +135,10 @@ int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
  * nrow, ...}).  All parts together are exactly fs_spmv / fs_spmv_t. */
 int fs_spmv_part_rows(fs_matrix_t A, int transposed, int nparts, int *rows /* nparts + 1 */);
 int fs_spmv_part(fs_matrix_t A, int transposed, double *y, const double *x, int part, int nparts, fs_stream_t stream);
+/* the same for k row-major columns (fs_spmm / fs_spmm_t in parts: the block-CG iteration): the one-sweep kernel of k = 2, 4 is cut
+ * like the single-vector pair, every other plan does everything with part 0; k = 1 is fs_spmv_part */
+int fs_spmm_part_rows(fs_matrix_t A, int transposed, int k, int nparts, int *rows /* nparts + 1 */);
+int fs_spmm_part(fs_matrix_t A, int transposed, double *Y, const double *X, int k, int part, int nparts, fs_stream_t stream);
 /* dst[dst_off[i] + j] = src[src_off[i] + j] for j < count[i], i < nseg, in one launch; table_dev = int64[3 * nseg] in HBM:
  * dst_off[nseg], src_off[nseg], count[nseg]; max_count = the largest count (sizes the grid).  Unpacks the padded receive
  * buffer of an all-gather of unequal y shards. */

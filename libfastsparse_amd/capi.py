@@ -22,7 +22,7 @@ DEVICE_API = [
     "fs_version", "fs_last_error", "fs_device_count", "fs_set_device", "fs_set_option", "fs_get_option",
     "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
     "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel", "fs_matrix_candidate_ms",
-    "fs_matrix_prepare", "fs_matrix_spmm_plan", "fs_matrix_device_bytes", "fs_spmv_part", "fs_spmv_part_rows", "fs_copy_segments",
+    "fs_matrix_prepare", "fs_matrix_spmm_plan", "fs_matrix_device_bytes", "fs_spmv_part", "fs_spmv_part_rows", "fs_spmm_part", "fs_spmm_part_rows", "fs_copy_segments",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
     "fs_spmv", "fs_spmv_t", "fs_spmv_host", "fs_spmv_t_host", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
     "fs_cbcsr_create", "fs_cbcsr_destroy", "fs_cbcsr_spmv", "fs_invalidate", "fs_release_all", "fs_cache_entries",
@@ -102,6 +102,8 @@ def lib():
     L.fs_matrix_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fs_spmv_part_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.fs_spmv_part.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]
+    L.fs_spmm_part_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.fs_spmm_part.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.fs_copy_segments.argtypes = [C.c_int, vp, C.c_int64, vp, vp, vp]
     L.fs_matrix_nrow.argtypes = [vp]
     L.fs_matrix_ncol.argtypes = [vp]
@@ -255,14 +257,17 @@ class Matrix:
         f = lib().fs_spmv_t if transposed else lib().fs_spmv
         check(f(self.h, _ptr(y), _ptr(x), stream), "fs_spmv")
 
-    def part_rows(self, nparts, transposed=False):
-        """row cuts of the product in `nparts` parts: rows [r[p], r[p+1]) are final after part p (fs_spmv_part_rows)"""
+    def part_rows(self, nparts, transposed=False, k=1):
+        """row cuts of the product (k columns) in `nparts` parts: rows [r[p], r[p+1]) are final after part p"""
         out = (C.c_int * (nparts + 1))()
-        check(lib().fs_spmv_part_rows(self.h, int(transposed), nparts, out), "fs_spmv_part_rows")
+        check(lib().fs_spmm_part_rows(self.h, int(transposed), k, nparts, out), "fs_spmm_part_rows")
         return [int(v) for v in out]
 
     def spmv_part(self, y, x, part, nparts, stream=None, transposed=False):
         check(lib().fs_spmv_part(self.h, int(transposed), _ptr(y), _ptr(x), part, nparts, stream), "fs_spmv_part")
+
+    def spmm_part(self, Y, X, k, part, nparts, stream=None, transposed=False):
+        check(lib().fs_spmm_part(self.h, int(transposed), _ptr(Y), _ptr(X), k, part, nparts, stream), "fs_spmm_part")
 
     def spmv_host(self, y, x, transposed=False):
         """y, x: contiguous float64 numpy arrays in host memory (fs_spmv_host: copies overlapped with the kernels)"""

@@ -332,6 +332,36 @@ int fs_spmv_part(fs_matrix_t A, int transposed, double *y, const double *x, int 
   return fs::launch_spmv_part(transposed ? A->at : A->a, y, x, part, nparts, (hipStream_t)stream);
 }
 
+int fs_spmm_part_rows(fs_matrix_t A, int transposed, int k, int nparts, int *rows)
+{
+  if (!A || !rows || k < 1 || nparts < 1 || nparts > 64) { set_error("fs_spmm_part_rows: bad argument"); return FS_ERR_ARG; }
+  if (k == 1) return fs_spmv_part_rows(A, transposed, nparts, rows);
+  if (transposed && !A->has_t) { set_error("fs_spmm_part_rows: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  fs::DeviceCsr &a = transposed ? A->at : A->a;
+  const int *r = nullptr;
+  if (k == 2 || k == 4) {
+    if (int rc = fs::spmm_part_bounds(a, k, nparts, &r, nullptr, nullptr)) return rc;
+    for (int p = 0; p <= nparts; ++p) rows[p] = r[p];
+  } else {
+    rows[0] = 0;
+    for (int p = 1; p <= nparts; ++p) rows[p] = a.nrow;
+  }
+  return FS_OK;
+}
+
+int fs_spmm_part(fs_matrix_t A, int transposed, double *Y, const double *X, int k, int part, int nparts, fs_stream_t stream)
+{
+  if (k == 1) return fs_spmv_part(A, transposed, Y, X, part, nparts, stream);
+  FS_RANGE("fs_spmm_part");
+  if (int rc = check_mul(A, Y, X, "fs_spmm_part")) return rc;
+  if (k < 1 || nparts < 1 || nparts > 64 || part < 0 || part >= nparts) { set_error("fs_spmm_part: bad argument"); return FS_ERR_ARG; }
+  if (transposed && !A->has_t) { set_error("fs_spmm_part: call fs_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(A->lock);
+  A->last_stream = (hipStream_t)stream; A->last_async = true;
+  return fs::launch_spmm_part(transposed ? A->at : A->a, Y, X, k, part, nparts, (hipStream_t)stream);
+}
+
 int fs_copy_segments(int nseg, const int64_t *table_dev, int64_t max_count, const double *src, double *dst, fs_stream_t stream)
 {
   if (nseg < 0 || (nseg > 0 && (!table_dev || !src || !dst))) { set_error("fs_copy_segments: bad argument"); return FS_ERR_ARG; }

@@ -54,6 +54,8 @@ struct DeviceCsr {
   int part_n = 0, part_kind = 0;
   bool part_cut = false;
   std::vector<int> part_rows, part_units;
+  struct PartCuts { int n = 0, kind = 0; bool cut = false; std::vector<int> rows, units; };
+  PartCuts partk[2];           // the same for the k-column sweeps: [0] k = 2, [1] k = 4
 };
 
 // L2-tiled copy of a CSR for the column-band kernel (see DESIGN.md "spmv_tiled_kernel").
@@ -286,6 +288,8 @@ int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s)
 int spmv_choice(const DeviceCsr &A, const Options &o);   // 7 two-pass, 8 LDS-staged, 6 L2-tiled, 2 lanes per row, 1 chunk-streaming
 int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out);
 int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int nparts, hipStream_t s);
+int spmm_part_bounds(DeviceCsr &A, int k, int nparts, const int **rows_out, const int **units_out, int *plan_out);
+int launch_spmm_part(DeviceCsr &A, double *Y, const double *X, int k, int part, int nparts, hipStream_t s);
 int launch_copy_segments(int nseg, const int64_t *tab_dev, int64_t max_count, const double *src, double *dst, hipStream_t s);
 int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
 // y_host = A x_host: copies and kernels overlapped where the kept copy allows it (two-pass copy without cut rows)
@@ -308,7 +312,8 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
                       int ys = 1, int c0 = 0, int c1 = -1);                  // T.ldsx selects the LDS-staged kernel
 int build_binned(DeviceCsr &A, hipStream_t s);      // no-op unless options/heuristic ask for it
 int build_binned_k(DeviceCsr &A, int kw, hipStream_t s);   // the k-column copy (kw = 2 or 4) into A.binned2 / A.binned4
-int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys);
+int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys, int p0 = 0,
+                       int p1 = -1, int row0 = 0, int row1 = 0);
 int choose_copy(DeviceCsr &A, hipStream_t s);       // times the candidates and keeps the fastest copy
 int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs = 1, int ys = 1, int p0 = 0,
                        int p1 = -1, int row0 = 0, int row1 = 0);   // p1 >= 0: pass 2 for panels p0 .. p1 only (pass 1 with p0 == 0)

@@ -1473,9 +1473,11 @@ __global__ __launch_bounds__(kBinBlock) void spmm_expand_kernel(
 
 template <int K>
 __global__ __launch_bounds__(kBinBlock) void spmm_reduce_kernel(
-    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ Y, int ys)
+    const unsigned *__restrict__ bin_ptr_all, const int *__restrict__ panel_row_all, const uint16_t *__restrict__ lrow,
+    const double *__restrict__ prod, double *__restrict__ Y, int ys, int pbase)
 {
+  const unsigned *__restrict__ bin_ptr = bin_ptr_all + pbase;          // this launch covers the panels pbase .. pbase + gridDim.x
+  const int *__restrict__ panel_row = panel_row_all + pbase;
   constexpr int GE = kBinGroup / K;
   constexpr int EPL = 8 / K;             // entries per lane and step: 64 bytes of products
   __shared__ double ytile[kBinRowsMax];  // [rows of the panel][K]
@@ -1529,9 +1531,10 @@ __global__ __launch_bounds__(kBinBlock) void spmm_reduce_kernel(
 // Y[r, 0:K] = sum of the virtual rows of row r, in storage order (yv holds K doubles per virtual row)
 template <int K>
 __global__ __launch_bounds__(kBlock) void tiled_combine_k_kernel(int nrow, const int *__restrict__ vfirst,
-                                                                const double *__restrict__ yv, double *__restrict__ Y, int ys)
+                                                                const double *__restrict__ yv, double *__restrict__ Y, int ys,
+                                                                int row0 = 0)
 {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)row0 * K + (int64_t)blockIdx.x * kBlock + threadIdx.x;   // rows row0 .. nrow of this launch
   const int64_t r = i / K;
   const int j = (int)(i % K);
   if (r >= nrow) return;
@@ -1732,6 +1735,41 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
 // spmv_part_bounds gives the row cuts rows[0 .. nparts] (rows [rows[p], rows[p+1]) are final after part p) and the unit
 // cuts (panels / workgroups) for a given nparts; cached per handle.
 // ------------------------------------------------------------------------------------------
+// cuts of a two-pass copy (single-vector or k-column): pass 2 by whole generations of resident workgroups, rows by the panels'
+// first rows (with cut rows: the rows whose every piece lies below the cut).  *cut = false: too few panels to cut.
+static int binned_part_cuts(const DeviceCsr &A, BinnedCsr &N, int nparts, std::vector<int> &rows, std::vector<int> &units, bool *cut)
+{
+  *cut = false;
+  const int slots = N.slots > 0 ? N.slots : 256;
+  if (N.nwg1 <= 0 || nparts <= 1 || N.P <= slots) return FS_OK;
+  if (!N.h_panel_row) {
+    int *hp = (int *)malloc(sizeof(int) * ((size_t)N.P + 1));
+    if (!hp) { set_error("out of host memory"); return FS_ERR_HIP; }
+    const hipError_t e = hipMemcpy(hp, N.panel_row, sizeof(int) * ((size_t)N.P + 1), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(hp); return hip_fail(e, "hipMemcpy(panel_row)", __FILE__, __LINE__); }
+    N.h_panel_row = hp;
+  }
+  std::vector<int> vfirst;
+  if (N.split) {
+    vfirst.resize((size_t)A.nrow + 1);
+    FS_HIP(hipMemcpy(vfirst.data(), N.vfirst, sizeof(int) * vfirst.size(), hipMemcpyDeviceToHost));
+  }
+  // one pass-2 workgroup per CU (its y slice fills LDS) and launches of one stream run one after the other: a part is a
+  // whole number of generations of resident workgroups -- 4 parts of 192 panels on 256 CUs would take 4 generations where
+  // the undivided pass takes 3 (config 2: 768 panels)
+  const int gens = (N.P + slots - 1) / slots;
+  const int c = nparts < gens ? nparts : gens;
+  for (int p = 0; p <= nparts; ++p) {
+    const int64_t w = p >= c ? N.P : (int64_t)slots * ((int64_t)gens * p / c);
+    units[(size_t)p] = (int)(w < N.P ? w : N.P);
+    const int vcut = N.h_panel_row[units[(size_t)p]];
+    rows[(size_t)p] = !N.split ? vcut : p == nparts ? A.nrow :
+                      (int)(std::upper_bound(vfirst.begin(), vfirst.end(), vcut) - vfirst.begin()) - 1;
+  }
+  *cut = true;
+  return FS_OK;
+}
+
 int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out)
 {
   const Options &o = options();
@@ -1743,35 +1781,8 @@ int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int *
   std::vector<int> rows((size_t)nparts + 1, A.nrow), units((size_t)nparts + 1, 0);
   rows[0] = 0;
   bool cut = false;
-  if (kind == 7 && A.binned->nwg1 > 0 && nparts > 1 && A.binned->P > (A.binned->slots > 0 ? A.binned->slots : 256)) {
-    BinnedCsr &N = *A.binned;
-    if (!N.h_panel_row) {
-      int *hp = (int *)malloc(sizeof(int) * ((size_t)N.P + 1));
-      if (!hp) { set_error("out of host memory"); return FS_ERR_HIP; }
-      const hipError_t e = hipMemcpy(hp, N.panel_row, sizeof(int) * ((size_t)N.P + 1), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) { free(hp); return hip_fail(e, "hipMemcpy(panel_row)", __FILE__, __LINE__); }
-      N.h_panel_row = hp;
-    }
-    std::vector<int> vfirst;
-    if (N.split) {
-      vfirst.resize((size_t)A.nrow + 1);
-      FS_HIP(hipMemcpy(vfirst.data(), N.vfirst, sizeof(int) * vfirst.size(), hipMemcpyDeviceToHost));
-    }
-    // one pass-2 workgroup per CU (its y slice fills LDS) and launches of one stream run one after the other: a part is a
-    // whole number of generations of resident workgroups -- 4 parts of 192 panels on 256 CUs would take 4 generations where
-    // the undivided pass takes 3 (config 2: 768 panels)
-    const int slots = N.slots > 0 ? N.slots : 256;
-    const int gens = (N.P + slots - 1) / slots;
-    const int c = nparts < gens ? nparts : gens;
-    for (int p = 0; p <= nparts; ++p) {
-      const int64_t w = p >= c ? N.P : (int64_t)slots * ((int64_t)gens * p / c);
-      units[(size_t)p] = (int)(w < N.P ? w : N.P);
-      const int vcut = N.h_panel_row[units[(size_t)p]];
-      // cut rows: the rows whose every piece lies below the virtual row vcut
-      rows[(size_t)p] = !N.split ? vcut : p == nparts ? A.nrow :
-                        (int)(std::upper_bound(vfirst.begin(), vfirst.end(), vcut) - vfirst.begin()) - 1;
-    }
-    cut = true;
+  if (kind == 7) {
+    if (int rc = binned_part_cuts(A, *A.binned, nparts, rows, units, &cut)) return rc;
   } else if ((kind == 8 || kind == 6) && nparts > 1) {
     TiledCsr &M = kind == 8 ? *A.tiledx : *A.tiled;
     if (!M.split && !(M.ldsx && M.shared)) {
@@ -1802,7 +1813,11 @@ int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int *
       }
     }
   }
-  if (!cut) units.assign((size_t)nparts + 1, 0);    // everything with part 0: rows = {0, nrow, nrow, ...}
+  if (!cut) {                                        // everything with part 0: rows = {0, nrow, nrow, ...}
+    units.assign((size_t)nparts + 1, 0);
+    rows.assign((size_t)nparts + 1, A.nrow);
+    rows[0] = 0;
+  }
   A.part_n = nparts; A.part_kind = kind; A.part_cut = cut;
   A.part_rows.swap(rows); A.part_units.swap(units);
   *rows_out = A.part_rows.data(); if (units_out) *units_out = A.part_units.data();
@@ -1821,12 +1836,15 @@ int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int npa
 }
 
 // one sweep of a k-column two-pass copy: Y[:, 0:kw] = A X[:, 0:kw]; X / Y rows are xs / ys doubles apart
-int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys)
+// p0 .. p1 / row0 .. row1: as launch_spmv_binned (p1 < 0: the whole sweep)
+int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys, int p0,
+                       int p1, int row0, int row1)
 {
   const int K = N.kw;
   double *out = N.split ? N.yv : Y;
   const int os = N.split ? K : ys;
-  const int nwg1 = (options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1;
+  if (p1 < 0) { p0 = 0; p1 = N.P; row0 = 0; row1 = A.nrow; }
+  const int nwg1 = (p0 != 0) ? 0 : ((options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1);
 #define FS_XP(V, KK)                                                                                                  \
   hipLaunchKernelGGL((spmm_expand_kernel<V, KK, 4>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol, \
                      N.vals, N.gdst, X, xs, N.prod)
@@ -1836,17 +1854,19 @@ int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const 
     FS_HIP(hipGetLastError());
   }
 #undef FS_XP
-  if (K == 2)
-    hipLaunchKernelGGL(spmm_reduce_kernel<2>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
-  else
-    hipLaunchKernelGGL(spmm_reduce_kernel<4>, dim3(N.P), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os);
-  FS_HIP(hipGetLastError());
-  if (N.split) {
-    const unsigned grid = (unsigned)(((int64_t)A.nrow * K + kBlock - 1) / kBlock);
+  if (p1 > p0) {
     if (K == 2)
-      hipLaunchKernelGGL(tiled_combine_k_kernel<2>, dim3(grid), dim3(kBlock), 0, s, A.nrow, N.vfirst, N.yv, Y, ys);
+      hipLaunchKernelGGL(spmm_reduce_kernel<2>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
     else
-      hipLaunchKernelGGL(tiled_combine_k_kernel<4>, dim3(grid), dim3(kBlock), 0, s, A.nrow, N.vfirst, N.yv, Y, ys);
+      hipLaunchKernelGGL(spmm_reduce_kernel<4>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
+    FS_HIP(hipGetLastError());
+  }
+  if (N.split && row1 > row0) {
+    const unsigned grid = (unsigned)(((int64_t)(row1 - row0) * K + kBlock - 1) / kBlock);
+    if (K == 2)
+      hipLaunchKernelGGL(tiled_combine_k_kernel<2>, dim3(grid), dim3(kBlock), 0, s, row1, N.vfirst, N.yv, Y, ys, row0);
+    else
+      hipLaunchKernelGGL(tiled_combine_k_kernel<4>, dim3(grid), dim3(kBlock), 0, s, row1, N.vfirst, N.yv, Y, ys, row0);
     FS_HIP(hipGetLastError());
   }
   return FS_OK;
@@ -2381,6 +2401,45 @@ int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
   if (A.nrow == 0) return FS_OK;
   return launch_spmm_plan(A, spmm_plan(A, k, nullptr), Y, X, k, s);
+}
+
+// The k-column product in parts: only the one-sweep plan (k = 2, 4 on the k-column two-pass copy) is cut, like the single-vector
+// pair; every other plan does everything with part 0.  The cuts are cached per handle and k.
+int spmm_part_bounds(DeviceCsr &A, int k, int nparts, const int **rows_out, const int **units_out, int *plan_out)
+{
+  const int plan = spmm_plan(A, k, nullptr);
+  if (plan_out) *plan_out = plan;
+  DeviceCsr::PartCuts &C = A.partk[k == 4 ? 1 : 0];
+  const bool sweep = plan == kPlanBinnedK && (k == 2 || k == 4);
+  if (C.n == nparts && C.kind == (sweep ? k : -k) && !C.rows.empty()) {
+    *rows_out = C.rows.data(); if (units_out) *units_out = C.units.data();
+    return FS_OK;
+  }
+  std::vector<int> rows((size_t)nparts + 1, A.nrow), units((size_t)nparts + 1, 0);
+  rows[0] = 0;
+  bool cut = false;
+  if (sweep)
+    if (int rc = binned_part_cuts(A, k == 4 ? *A.binned4 : *A.binned2, nparts, rows, units, &cut)) return rc;
+  if (!cut) {
+    units.assign((size_t)nparts + 1, 0);
+    rows.assign((size_t)nparts + 1, A.nrow);
+    rows[0] = 0;
+  }
+  C.n = nparts; C.kind = sweep ? k : -k; C.cut = cut;
+  C.rows.swap(rows); C.units.swap(units);
+  *rows_out = C.rows.data(); if (units_out) *units_out = C.units.data();
+  return FS_OK;
+}
+
+int launch_spmm_part(DeviceCsr &A, double *Y, const double *X, int k, int part, int nparts, hipStream_t s)
+{
+  if (A.nrow == 0) return FS_OK;
+  if (k != 2 && k != 4) return part == 0 ? launch_spmm(A, Y, X, k, s) : FS_OK;    // (k = 3 is two sweeps: not cut)
+  const int *rows = nullptr, *units = nullptr;
+  int plan = 0;
+  if (int rc = spmm_part_bounds(A, k, nparts, &rows, &units, &plan)) return rc;
+  if (!A.partk[k == 4 ? 1 : 0].cut) return part == 0 ? launch_spmm_plan(A, plan, Y, X, k, s) : FS_OK;
+  return launch_spmm_binned(A, k == 4 ? *A.binned4 : *A.binned2, Y, X, s, k, k, units[part], units[part + 1], rows[part], rows[part + 1]);
 }
 
 namespace {

@@ -124,19 +124,22 @@ class EvenParts:
 
 
 class HipParts:
-    """local product in parts on the HIP C-ABI (fs_spmv_part: pass 2 of the two-pass pair in ranges of panels, the
-    tiled kernels in generations of workgroups); `matrix` is a capi.Matrix"""
+    """local product in parts on the HIP C-ABI (fs_spmv_part / fs_spmm_part: pass 2 of the two-pass pair in ranges of
+    panels, the tiled kernels in generations of workgroups); `matrix` is a capi.Matrix, k the number of row-major columns"""
 
-    def __init__(self, matrix, transposed=False, stream_fn=None):
+    def __init__(self, matrix, transposed=False, stream_fn=None, k=1):
         from . import capi
-        self.m, self.t, self.capi, self.stream_fn = matrix, transposed, capi, stream_fn
+        self.m, self.t, self.capi, self.stream_fn, self.k = matrix, transposed, capi, stream_fn, k
 
     def rows(self, nparts):
-        return self.m.part_rows(nparts, transposed=self.t)
+        return self.m.part_rows(nparts, transposed=self.t, k=self.k)
 
     def run(self, y_local, x_full, part, nparts):
         st = self.stream_fn() if self.stream_fn else self.capi.current_stream()
-        self.m.spmv_part(y_local, x_full, part, nparts, st, transposed=self.t)
+        if self.k == 1:
+            self.m.spmv_part(y_local, x_full, part, nparts, st, transposed=self.t)
+        else:       # k row-major columns (fs_spmm_part: the k = 2 / 4 sweep is cut like the single-vector pair)
+            self.m.spmm_part(y_local, x_full, self.k, part, nparts, st, transposed=self.t)
 
 
 class ShardedOperator:

@@ -83,7 +83,7 @@ def _worker(rank, world, port, ret):
             def t_partial(zf, ul):
                 (A.spmv(zf, ul, st(), transposed=True) if k == 1 else A.spmm(zf, ul, k, st(), transposed=True))
 
-            parts = fsd.HipParts(A) if k == 1 else None           # products in parts exist for single vectors
+            parts = fsd.HipParts(A, k=k)                          # k = 2: the two-column sweep in parts (fs_spmm_part)
             op_a = fsd.ShardedOperator(a_local, rb, parts=parts, k=k, copy_segments=prov.copy_segments)
             X = np.ascontiguousarray(np.stack([((np.arange(F) * (3 + j)) % 17 - 8).astype(np.float64) for j in range(k)], 1))
             ref = O.csr_mul_n(N, rp, cc, None, X, k) if k > 1 else O.csr_mul(N, rp, cc, None, X[:, 0])

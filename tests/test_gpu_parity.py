@@ -1165,6 +1165,40 @@ def test_longest_rows_outside_the_two_pass_copy(hip, valued, geometry):
             capi.set_option(k_, v_)
 
 
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_k_column_product_in_parts(hip, k):
+    """fs_spmm_part / fs_spmm_part_rows: the one-sweep kernel of k = 2, 4 finishes its rows by generations of pass-2 panels
+    (the block-CG iteration's exchange rides on that); k = 3 (two sweeps) and unprepared handles do everything with part 0.
+    Pattern-only, integer X: every part's rows and the whole against the oracle, bit for bit."""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(50 + k)
+    nrow, ncol, per = 3_000_000, 500_001, 3
+    rp = (np.arange(nrow + 1, dtype=np.int64) * per).astype(np.int32)
+    cc = rng.integers(0, ncol, nrow * per).astype(np.int32)
+    st = capi.current_stream()
+    capi.set_option("binning", 2)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None)
+        X = np.ascontiguousarray(np.stack([S.x_int(7 + j, ncol) for j in range(k)], 1))
+        ref = O.csr_mul_n(nrow, rp, cc, None, X, k)
+        Xd = torch.from_numpy(X).cuda()
+        for prepared in (False, True):
+            if prepared:
+                A.prepare(k, st)
+            rows = A.part_rows(3, k=k)
+            assert rows[0] == 0 and rows[-1] == nrow and all(a <= b for a, b in zip(rows, rows[1:])), rows
+            cutk = prepared and k in (2, 4)
+            assert (sum(b > a for a, b in zip(rows, rows[1:])) >= 2) == cutk, (k, prepared, rows)
+            Y = torch.full((nrow, k), -7.0, dtype=torch.float64, device="cuda")
+            for part in range(3):
+                A.spmm_part(Y, Xd, k, part, 3, st)
+                assert np.array_equal(Y.cpu().numpy()[:rows[part + 1]], ref[:rows[part + 1]]), (k, prepared, part)
+            assert np.array_equal(Y.cpu().numpy(), ref)
+    finally:
+        capi.set_option("binning", 1)
+
+
 def test_copy_segments_unpacks_a_padded_gather(hip):
     """fs_copy_segments: the one-launch unpack of the padded receive buffer of an all-gather of unequal shards"""
     import torch
