@@ -1401,8 +1401,16 @@ def main():
         else:
             dist.init_process_group(backend)
     prov = HipProvider(dev)
+    if world > 1 and not os.environ.get("FS_BENCH_WATCHDOG"):
+        # a collective that never returns (first contact with RCCL on more than one GPU) must not end in silence: after the
+        # budget every rank dumps its Python stacks to stderr and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("FS_BENCH_BUDGET_S", "480")), repeat=False, exit=True)
     if args.workload in ("all", "c2"):
         rec = run_c2(args, prov, world, rank, nccl, strong=args.strong)
+        if world > 1 and not os.environ.get("FS_BENCH_WATCHDOG"):
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()      # the headline exists: from here on the budget watchdog prints it
         if args.workload == "all":
             also, state = [], {}
             budget = float(os.environ.get("FS_BENCH_BUDGET_S", "480")) - (time.perf_counter() - t_start)
