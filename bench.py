@@ -574,9 +574,9 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     else:
         bytes_t = csr_bytes(nnz_local, ncol, n_local)   # same entries, nrow and ncol swap roles
 
-    op_a = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments)
+    op_a = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments, exchange=getattr(args, "exchange", "allgather"))
     if z_scheme == "gather":
-        op_t = fsd.ShardedOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb, parts=prov.parts(At), copy_segments=prov.copy_segments)
+        op_t = fsd.ShardedOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb, parts=prov.parts(At), copy_segments=prov.copy_segments, exchange=getattr(args, "exchange", "allgather"))
     elif z_scheme == "reduce":
         op_t = fsd.TransposedShardedOperator(lambda zf, ul: prov.spmv(A, zf, ul, transposed=True), bounds)
     else:
@@ -750,6 +750,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     if world > 1:
         rec["config"].update({
             "exchange": {"y": "all-gather of the y shards, started part by part inside the product (%d parts)" % nparts,
+                         "how": getattr(args, "exchange", "allgather"),
                          "z_scheme": z_scheme, "z_scheme_fallback_reason": z_err,
                          "bytes_received_per_rank_per_step": {
                              "y_all_gather": 8.0 * (n_global - n_local),
@@ -1018,7 +1019,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
 
     x = prov.sin_vector(ncol, 7.0, 0.3)
     if world > 1:
-        op = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments)
+        op = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments, exchange=getattr(args, "exchange", "allgather"))
         y = prov.empty(n_global)
     else:
         op, y = None, prov.empty(n_local)
@@ -1038,7 +1039,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
             if hasattr(prov, "trim"):
                 prov.trim()
             opt = fsd.TransposedGatherOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb)
-            opt.parts, opt.copy_segments = prov.parts(At), prov.copy_segments
+            opt.parts, opt.copy_segments, opt.exchange = prov.parts(At), prov.copy_segments, getattr(args, "exchange", "allgather")
             u = prov.sin_vector(n_global, 11.0, -0.2)
             z = prov.empty(ncol)
             bytes_t = csr_bytes(int(At.nnz), cb[rank + 1] - cb[rank], n_global)
@@ -1232,8 +1233,8 @@ def run_cg_dist(args, prov, world, rank, nccl):
     At = in_turns(lambda: prov.coo(cb[rank + 1] - cb[rank], n_global, tr.to(torch.int32), tc.to(torch.int32), None), prov, world, rank, nccl)
     del tr, tc
     A = in_turns(lambda: prov.csr(n_local, ncol, rp, cc, None), prov, world, rank, nccl)
-    op_a = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments)
-    op_t = fsd.ShardedOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb, copy_segments=prov.copy_segments)
+    op_a = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments, exchange=getattr(args, "exchange", "allgather"))
+    op_t = fsd.ShardedOperator(lambda zl, uf: prov.spmv(At, zl, uf), cb, copy_segments=prov.copy_segments, exchange=getattr(args, "exchange", "allgather"))
     cg = fsd.ShardedCG(op_a, op_t, scheme="gather", nparts=max(1, args.parts))
     b = prov.sin_vector(ncol, 19.0, 0.4)
     x, it = cg.solve(b, 5.0, 1e-8)                         # warm
@@ -1354,6 +1355,9 @@ def main():
                     help="c2, N > 1: strong scaling -- the ONE config-2 matrix (--rows rows in all) cut over the ranks (default: weak "
                          "scaling, --rows rows per rank)")
     ap.add_argument("--parts", type=int, default=4, help="N > 1: parts of a local product; the all-gather of part p runs under part p+1")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "direct"],
+                    help="N > 1: how a part's rows travel: one padded all-gather per part (default) or direct point-to-point sends to "
+                         "every peer (no padding, no unpack) -- to be A/B'ed on a machine with more than one GPU")
     ap.add_argument("--z-scheme", default="gather", choices=["gather", "reduce"],
                     help="c2, N > 1: z = A'u by row shards of A' + all-gather (default) or local A_r'u_r + all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")

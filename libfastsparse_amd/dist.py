@@ -76,6 +76,11 @@ def all_to_all(out, inp, out_split=None, in_split=None, group=None):
         dist.all_to_all_single(out, inp, out_split, in_split, group=group)
 
 
+def _peer(r, group):
+    """global rank of rank r of `group` (point-to-point calls take global ranks)"""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 def even_row_partition(nrow, world):
     """contiguous row ranges of (almost) equal size: bounds[r] .. bounds[r+1]"""
     base, rem = divmod(nrow, world)
@@ -154,12 +159,18 @@ class ShardedOperator:
     `k`: doubles per row (k right-hand sides, row-major).
     """
 
-    def __init__(self, local_spmv, bounds, group=None, parts=None, k=1, copy_segments=None):
+    def __init__(self, local_spmv, bounds, group=None, parts=None, k=1, copy_segments=None, exchange="allgather"):
         self.local_spmv = local_spmv
         self.bounds = list(bounds)
         self.group = group
         self.parts = parts
         self.k = k
+        # how apply_overlapped ships the rows of a part: "allgather" (one all_gather_into_tensor per part on a padded buffer,
+        # unpacked by one fs_copy_segments launch) or "direct" (SURVEY.md 5: "each GPU pushes its shard on all 7 links": one
+        # batch of point-to-point sends / receives per part, every rank's rows straight into their place in y, no padding and
+        # no unpack).  Which is faster over xGMI is for a machine with more than one GPU to tell (bench.py --exchange).
+        assert exchange in ("allgather", "direct")
+        self.exchange = exchange
         self.copy_segments = copy_segments or copy_segments_torch
         self._plan = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -252,7 +263,7 @@ class ShardedOperator:
                     dst.append((self.bounds[r] + cuts[r][p]) * k)
                     src.append(off[p] + r * maxc[p] * k)
                     cnt.append(c * k)
-        plan = {"mine": mine, "maxc": maxc, "off": off, "dst": dst, "src": src, "cnt": cnt,
+        plan = {"mine": mine, "cuts": cuts, "maxc": maxc, "off": off, "dst": dst, "src": src, "cnt": cnt,
                 "pad": torch.empty(max(off[-1], 1), dtype=like.dtype, device=like.device)}
         self._plan[key] = plan
         return plan
@@ -266,6 +277,27 @@ class ShardedOperator:
         plan = self._part_plan(nparts, y_full)
         k, n_local = self.k, self.hi - self.lo
         works = []
+        if self.exchange == "direct" and not _host_collective(y_full, self.group):
+            # the local product writes straight into this rank's rows of y_full; after part p every peer is sent those rows and
+            # this rank posts the receives of the peers' part-p rows (cuts exchanged by _part_plan) into their place in y_full
+            mine_full = y_full[self.lo * k:self.hi * k]
+            cuts = plan["cuts"]
+            for p in range(nparts):
+                self.parts.run(mine_full, x_full, p, nparts)
+                ops = []
+                a, b = cuts[self.rank][p], cuts[self.rank][p + 1]
+                for r in range(self.world):
+                    if r == self.rank:
+                        continue
+                    ra, rb = cuts[r][p], cuts[r][p + 1]
+                    if rb > ra:
+                        ops.append(dist.P2POp(dist.irecv, y_full[(self.bounds[r] + ra) * k:(self.bounds[r] + rb) * k], _peer(r, self.group),
+                                              group=self.group))
+                    if b > a:
+                        ops.append(dist.P2POp(dist.isend, mine_full[a * k:b * k], _peer(r, self.group), group=self.group))
+                if ops:
+                    works.extend(dist.batch_isend_irecv(ops))
+            return _Then(works, lambda: None)
         for p in range(nparts):
             self.parts.run(y_local[:n_local * k], x_full, p, nparts)
             c = plan["maxc"][p]

@@ -166,15 +166,18 @@ def _cg_worker(rank, world, port, ret):
                     z_full.copy_(torch.from_numpy(np.ascontiguousarray(Z).reshape(-1)))
 
                 op_a = fsd.ShardedOperator(a_local, rb, parts=fsd.EvenParts(a_local, hi - lo), k=k)
-                # (1) the exchange inside the product: 1, 3 and 5 parts give the product with the whole matrix, bit for bit
+                op_d = fsd.ShardedOperator(a_local, rb, parts=fsd.EvenParts(a_local, hi - lo), k=k, exchange="direct")
+                # (1) the exchange inside the product: 1, 3 and 5 parts give the product with the whole matrix, bit for bit --
+                # by padded all-gathers and by direct point-to-point sends of every part's rows
                 X = np.ascontiguousarray(np.stack([S.x_int(5 + j, F) for j in range(k)], 1)).reshape(-1)
                 ref = (O.csr_mul_n(N, a_rp, a_cc, None, X.reshape(F, k), k) if k > 1 else O.csr_mul(N, a_rp, a_cc, None, X)).reshape(-1)
-                for nparts in (1, 3, 5):
-                    y = torch.full((N * k,), -1.0, dtype=torch.float64)
-                    op_a.apply_overlapped(y, torch.from_numpy(X), nparts)
-                    if not np.array_equal(y.numpy(), ref):
-                        ok = False
-                        why.append((name, k, "overlapped", nparts))
+                for op_x, how in ((op_a, "allgather"), (op_d, "direct")):
+                    for nparts in (1, 3, 5):
+                        y = torch.full((N * k,), -1.0, dtype=torch.float64)
+                        op_x.apply_overlapped(y, torch.from_numpy(X), nparts)
+                        if not np.array_equal(y.numpy(), ref):
+                            ok = False
+                            why.append((name, k, "overlapped", how, nparts))
                 # (2) the solvers
                 B = np.ascontiguousarray(np.stack([np.sin(0.37 * np.arange(F) + 1.0 + j) for j in range(k)], 1)).reshape(-1)
                 xref, itref = O.cg_normal(N, F, rows, cols, B.reshape(F, k) if k > 1 else B, 0.5, 1e-8, two=(k == 2))
