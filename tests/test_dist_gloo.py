@@ -359,7 +359,7 @@ def _c2_worker(rank, world, port, z_scheme, ret):
         n, per = 2500, 16
         args = argparse.Namespace(rows=n, per_row=per, c5_rows=9000, steps=2, warmup=1, transpose=False, strong=False, parts=3,
                                   z_scheme=z_scheme, no_cpu_baseline=True, no_reproducible_cost=True, cpu_sample_rows=0,
-                                  spmm_kernel=0)
+                                  spmm_kernel=0, exchange="direct" if z_scheme == "reduce" else "allgather")   # both ways of shipping a part
         out = {}
         rec = bench.run_c2(args, prov, world, rank, False, out=out)
         # weak scaling: the global matrix is (world * n) x n with the same generator row by row; y and z must be the oracle's
