@@ -101,6 +101,8 @@ struct fs_dist_s {
   std::vector<hipStream_t> comm_stream;  // communication stream per rank
   bool use_rccl = false;
   std::vector<ncclComm_t> comm;
+  std::mutex lock;                    // the streams and communicators serve one product at a time (a communicator must not be
+                                      // used from two host threads at once): taken behind the matrix's own lock
 };
 
 // one direction of a distributed matrix: row shards of M (A, or A'), input replicated, output gathered
@@ -566,6 +568,7 @@ int fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host)
 {
   if (!M || !y_host || !x_host) { fs::set_error("fs_dist_spmv: NULL argument"); return FS_ERR_ARG; }
   std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
   if (int rc = upload_all(M, M->x, x_host, (size_t)M->ncol)) return rc;
   if (int rc = dist_product(M->D, M->a, M->x, M->y)) return rc;
@@ -578,6 +581,7 @@ int fs_dist_spmv_t(fs_dist_matrix_t M, double *z_host, const double *u_host)
   if (!M || !z_host || !u_host) { fs::set_error("fs_dist_spmv_t: NULL argument"); return FS_ERR_ARG; }
   if (!M->t.built) { fs::set_error("fs_dist_spmv_t: call fs_dist_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
   if (int rc = upload_all(M, M->y, u_host, (size_t)M->nrow)) return rc;   // u lives where y does: A then A' chains without a copy
   if (int rc = dist_product(M->D, M->t, M->y, M->z)) return rc;
@@ -592,6 +596,7 @@ int fs_dist_spmv_resident(fs_dist_matrix_t M)
 {
   if (!M) { fs::set_error("fs_dist_spmv_resident: NULL handle"); return FS_ERR_ARG; }
   std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
   if (int rc = dist_product(M->D, M->a, M->x, M->y)) return rc;
   return dist_sync(M->D);
@@ -602,6 +607,7 @@ int fs_dist_spmv_t_resident(fs_dist_matrix_t M)
   if (!M) { fs::set_error("fs_dist_spmv_t_resident: NULL handle"); return FS_ERR_ARG; }
   if (!M->t.built) { fs::set_error("fs_dist_spmv_t_resident: call fs_dist_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
   if (int rc = dist_product(M->D, M->t, M->y, M->z)) return rc;
   return dist_sync(M->D);
@@ -627,6 +633,7 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
   if (!M || !x_host || !b_host) { fs::set_error("fs_dist_cg: NULL argument"); return FS_ERR_ARG; }
   if (!M->t.built) { fs::set_error("fs_dist_cg: call fs_dist_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
   fs_dist_t D = M->D;
   const int n = D->n, F = M->ncol;
