@@ -247,12 +247,19 @@ class HipProvider:
         self.torch.cuda.empty_cache()
 
 
+def _multi(world):
+    """more than one rank -- or FS_BENCH_FORCE_MULTI=1: the N > 1 code path with ONE rank, which is how the one-GPU box can run
+    it on RCCL (RCCL refuses two ranks on one card): init_process_group("nccl"), the device-side collectives of the timing and
+    of the exchanges, every sub-record of the N > 1 plan.  Use it with FS_DIST_FORCE_COLLECTIVES=1 and reduced sizes."""
+    return world > 1 or os.environ.get("FS_BENCH_FORCE_MULTI", "0") == "1"
+
+
 def in_turns(fn, prov, world, rank, nccl):
     """fn() on every rank -- one rank after the other when the ranks SHARE one GPU (the gloo rehearsal): the radix sorts of the
     format builders and of torch wait for other workgroups of their own grid (decoupled look-back), and several processes
     time-sliced on one card were seen to starve each other there for ever (GPU 100 % busy, no memory traffic).  One process
     per GPU, the real thing, has the card to itself."""
-    if nccl or world == 1 or getattr(prov, "name", "") != "hip":
+    if nccl or not _multi(world) or getattr(prov, "name", "") != "hip":
         return fn()
     import torch.distributed as dist
     out = None
@@ -273,7 +280,7 @@ def timed_steps(prov, step, drain, steps, warmup, world, backend_is_nccl):
         step(None)
     drain()
     prov.synchronize()
-    if world > 1:
+    if _multi(world):
         dist.barrier()
     evs = [[prov.event() for _ in range(4)] for _ in range(steps)]
     e0, e1 = prov.event(), prov.event()
@@ -285,11 +292,11 @@ def timed_steps(prov, step, drain, steps, warmup, world, backend_is_nccl):
     drain()
     e1.record()
     prov.synchronize()
-    if world > 1:
+    if _multi(world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     region_ms = prov.elapsed_ms(e0, e1)
-    if world > 1:
+    if _multi(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=prov.dev if backend_is_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -532,7 +539,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     dev = prov.dev
     per = args.per_row
     ncol = args.rows                    # column space stays config 2's at every N
-    if strong and world > 1:            # strong scaling: the one 10 M-row matrix cut into equal row shards
+    if strong and _multi(world):            # strong scaling: the one 10 M-row matrix cut into equal row shards
         n_global = args.rows
         sb = fsd.even_row_partition(n_global, world)
         lo, n_local = sb[rank], sb[rank + 1] - sb[rank]
@@ -540,9 +547,9 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         n_local = args.rows
         n_global = n_local * world
         lo = rank * n_local
-    cdev = dev if (nccl and world > 1) else "cpu"
+    cdev = dev if (nccl and _multi(world)) else "cpu"
     nparts = max(1, args.parts)
-    z_scheme = "local" if world == 1 else args.z_scheme
+    z_scheme = "local" if not _multi(world) else args.z_scheme
     z_err = None
 
     # ---- this rank's shard: rows lo .. lo+n_local of the n_global x 10M matrix ---------------------------------
@@ -550,7 +557,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     bounds = fsd.even_row_partition(n_global, world)
     cb = fsd.even_row_partition(ncol, world)
     At = None
-    if world > 1 and z_scheme == "gather":
+    if _multi(world) and z_scheme == "gather":
         # z = A' u as "row shards of A' + all-gather": this rank owns rows cb[rank] .. cb[rank+1] of A' (= those columns of
         # A), built once by an all-to-all of the entries; moves F doubles per product where the all-reduce moves 2 F
         try:
@@ -560,7 +567,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
             del tr, tc, tv
         except Exception as ex:          # never ran on more than one GPU before the driver's run: keep the number, say why
             z_scheme, z_err, At = "reduce", repr(ex), None
-        if world > 1:                    # every rank takes the same scheme
+        if _multi(world):                    # every rank takes the same scheme
             flag = torch.tensor([1.0 if z_scheme == "gather" else 0.0], dtype=torch.float64, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag.item()) == 0.0 and z_scheme == "gather":
@@ -591,7 +598,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         """N = 1: A x, A' u.  N > 1, the iterating consumer's order (cg.h:15-16): [A x in parts, the all-gather of the finished
         rows under the later parts], y complete; [A' u likewise], z complete.  ev[0..1] / ev[2..3] bracket this rank's kernels
         of the two products on the launch stream (the exchanges run on RCCL's stream)."""
-        if world == 1:
+        if not _multi(world):
             prov.spmv(A, y, x)
             prov.spmv(A, z, u, transposed=True)
             return
@@ -623,21 +630,21 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
 
     elapsed, evs, region_ms = timed_steps(prov, step, lambda: None, args.steps, args.warmup, world, nccl)
     launches = 2 * args.steps
-    if world == 1:
+    if not _multi(world):
         avg_ms = region_ms / launches                # ONE event pair around the K steps
     else:
         avg_ms = sum(prov.elapsed_ms(e[0], e[1]) + prov.elapsed_ms(e[2], e[3]) for e in evs) / launches
     bytes_per_launch = (bytes_a + bytes_t) / 2.0
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     tb = torch.tensor([float(bytes_a + bytes_t)], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if _multi(world):
         dist.all_reduce(tb)             # shards may differ by a row under strong scaling
     total_bytes = float(tb.item()) * args.steps
     value = total_bytes / elapsed / 1e9
 
     # the two products apart (outside the timed region): A x and A' u, a few runs each
     split = {}
-    if world == 1:
+    if not _multi(world):
         e = [prov.event() for _ in range(3)]
         e[0].record()
         for _ in range(5):
@@ -652,7 +659,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         split = {"A_mul_B_ms": sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs),
                  "At_mul_B_ms": sum(prov.elapsed_ms(e[2], e[3]) for e in evs) / len(evs)}
     noex = None
-    if world > 1:   # the same loop without any exchange: what the exchanges cost on top of the local products
+    if _multi(world):   # the same loop without any exchange: what the exchanges cost on top of the local products
         noex, _, _ = timed_steps(prov, lambda ev=None: step(None, exchange=False), lambda: None, args.steps, 1, world, nccl)
 
     # self-check outside the timed region (no oracle here: that is the tests' job): the products the timed loop left in
@@ -660,7 +667,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     # the same gathered y / z
     self_check = {}
     try:
-        if world > 1:
+        if _multi(world):
             step(None)                                                # y, z of a complete step (the no-exchange loop ran last)
         y_ref = prov.empty(n_local)
         prov.spmv_strict(A, y_ref, x)
@@ -672,11 +679,11 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         else:
             z_ref = prov.empty(ncol)
             prov.spmv_strict(A, z_ref, u[lo:lo + n_local], transposed=True)
-            if world > 1:
+            if _multi(world):
                 fsd.all_reduce_sum(z_ref)                             # sum of the ranks' partial products
             dz = float((z - z_ref).abs().max())
         self_check["At_mul_B_max_abs_diff_vs_storage_order_kernel"] = dz
-        if world > 1:
+        if _multi(world):
             self_check["ranks_hold_identical_y_and_z"] = _same_on_all_ranks([float(y.sum()), float(z.sum())], cdev)
         self_check["ok"] = bool(self_check["A_mul_B_max_abs_diff_vs_storage_order_kernel"] <= 1e-11 and
                                 dz <= 1e-11 * max(1, world if z_scheme == "reduce" else 8) and
@@ -690,7 +697,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     # what fixed-order sums would cost: the same matrix created under "reproducible" keeps a kernel whose
     # additions have a fixed order (the two-pass kernels add a row's terms of one band with LDS atomics in arrival order)
     repro = None
-    if world == 1 and hasattr(prov, "capi") and not args.no_reproducible_cost:
+    if not _multi(world) and hasattr(prov, "capi") and not args.no_reproducible_cost:
         try:
             prov.capi.set_option("reproducible", 1)
             try:
@@ -718,7 +725,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     kname = prov.kernel_name(A)
     kname_t = prov.kernel_name(At) if z_scheme == "gather" else prov.kernel_name(A, True)
     F8 = 8.0 * ncol
-    if world == 1:
+    if not _multi(world):
         what = "BASELINE config 2: CSR %d x %d, %d nnz/row uniform, fp64, step = A_mul_B + At_mul_B" % (n_global, ncol, per)
     else:
         what = ("%s: CSR %d x %d, %d rows/GPU, %d nnz/row, step = (A_mul_B in %d parts with the all-gather of y inside the product) "
@@ -726,11 +733,11 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
                                          "config-2 shards, weak scaling by rows", n_global, ncol, n_local, per, nparts,
                                          "row shards of A' + all-gather of z inside the product" if z_scheme == "gather" else
                                          "local A_r' u_r + all-reduce of z"))
-    traffic = _traffic((kname, kname_t), "c2", n_local, per) if world == 1 else None
+    traffic = _traffic((kname, kname_t), "c2", n_local, per) if not _multi(world) else None
     rec = {
         "metric": METRIC, "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong" if (strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong" if (strong and _multi(world)) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": what,
                    "rows_per_gpu": n_local, "nnz_per_gpu": nnz_local, "parallelism": "rows x%d" % world,
                    "pct_of_hbm_peak": 100.0 * value / (HBM_PEAK_GBS * world),
@@ -747,7 +754,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
-    if world > 1:
+    if _multi(world):
         rec["config"].update({
             "exchange": {"y": "all-gather of the y shards, started part by part inside the product (%d parts)" % nparts,
                          "how": getattr(args, "exchange", "allgather"),
@@ -758,7 +765,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
                              "z_all_reduce_ring": 2.0 * F8 * (world - 1) / world}},
             "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
             "rccl_status": "first contact: no multi-GPU machine was available to the builder; numbers above are the driver's"})
-    if world == 1 and not args.no_cpu_baseline and hasattr(prov, "capi"):
+    if not _multi(world) and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
             rec["cpu_baseline"] = cpu_baseline_c2(n_local, ncol, per)
         except Exception as ex:  # the baseline is a reported extra; its failure must not hide the GPU number
@@ -1004,10 +1011,10 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     from libfastsparse_amd import dist as fsd
     n_global = args.c5_rows
     ncol = n_global
-    parts = world if world > 1 else 8
-    mine = rank if world > 1 else min(3, parts - 1)     # N = 1: the shard rank 3 of 8 owns
+    parts = world if _multi(world) else 8
+    mine = rank if _multi(world) else min(3, parts - 1)     # N = 1: the shard rank 3 of 8 owns
     nparts = max(1, args.parts)
-    cdev = prov.dev if (nccl and world > 1) else "cpu"
+    cdev = prov.dev if (nccl and _multi(world)) else "cpu"
     bounds, cum_nnz, total_nnz = c5_partition(prov, n_global, parts)
     lo, hi = bounds[mine], bounds[mine + 1]
     rp, cc, vv, nnz = c5_shard(prov, lo, hi, ncol)
@@ -1018,7 +1025,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         prov.trim()
 
     x = prov.sin_vector(ncol, 7.0, 0.3)
-    if world > 1:
+    if _multi(world):
         op = fsd.ShardedOperator(lambda yl, xf: prov.spmv(A, yl, xf), bounds, parts=prov.parts(A), copy_segments=prov.copy_segments, exchange=getattr(args, "exchange", "allgather"))
         y = prov.empty(n_global)
     else:
@@ -1029,7 +1036,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     opt = At = None
     t_err = None
     bytes_t = 0
-    if world > 1 and args.transpose:
+    if _multi(world) and args.transpose:
         try:
             cb = fsd.even_row_partition(ncol, world)
             tr, tc, tv = fsd.build_transposed_shard(rp, cc, vv, lo, cb)
@@ -1051,11 +1058,11 @@ def run_c5(args, prov, world, rank, nccl, out=None):
             opt, t_err = None, "another rank could not build its shard of A'"
 
     def step(ev=None, exchange=True, transpose=False):
-        if world == 1:
+        if not _multi(world):
             ev = None                  # one GPU: ONE event pair around the K steps (timed_steps)
         if ev is not None:
             ev[0].record()
-        if world == 1:
+        if not _multi(world):
             prov.spmv(A, y, x)
         elif exchange:
             hy = op.apply_overlapped_async(y, x, nparts)
@@ -1063,7 +1070,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
             op.local(y, x)
         if ev is not None:
             ev[1].record()
-        if world > 1 and exchange:
+        if _multi(world) and exchange:
             hy.wait()
         if transpose:
             if ev is not None:
@@ -1078,18 +1085,18 @@ def run_c5(args, prov, world, rank, nccl, out=None):
                 hz.wait()
 
     elapsed, evs, region_ms = timed_steps(prov, step, lambda: None, args.steps, args.warmup, world, nccl)
-    local_ms = region_ms / args.steps if world == 1 else sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs)
+    local_ms = region_ms / args.steps if not _multi(world) else sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs)
 
     def all_ranks(v):
         t = torch.tensor([float(v)], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if _multi(world):
             dist.all_reduce(t)
         return float(t.item())
 
     bytes_all = all_ranks(bytes_local)
     value = bytes_all * args.steps / elapsed / 1e9
     noex = with_t = None
-    if world > 1:   # the same loop without any exchange: what the all-gather costs on top of the local products
+    if _multi(world):   # the same loop without any exchange: what the all-gather costs on top of the local products
         noex, _, _ = timed_steps(prov, lambda ev=None: step(None, exchange=False), lambda: None, args.steps, 1, world, nccl)
     if opt is not None:
         el_t, evs_t, _ = timed_steps(prov, lambda ev=None: step(ev, transpose=True), lambda: None, args.steps, 1, world, nccl)
@@ -1104,15 +1111,15 @@ def run_c5(args, prov, world, rank, nccl, out=None):
 
     sc = {}
     try:
-        if world > 1:
+        if _multi(world):
             step(None, transpose=opt is not None)     # complete vectors (a no-exchange loop ran last)
         if out is not None:
             out["y"], out["z"], out["bounds"] = y, (z if opt is not None else None), bounds
-        if world > 1:
+        if _multi(world):
             sc["ranks_hold_identical_y"] = _same_on_all_ranks([float(y.sum())], cdev)
         y_ref = prov.empty(n_local)
         prov.spmv_strict(A, y_ref, x)
-        mine_y = y[lo:hi] if world > 1 else y
+        mine_y = y[lo:hi] if _multi(world) else y
         lens = (rp[1:] - rp[:-1]).to(torch.float64).clamp(min=1.0)
         sc["rows_within_1e-12_x_row_length_of_storage_order_kernel"] = bool(((mine_y - y_ref).abs() <= 1e-12 * lens).all())
         sc["ok"] = all(v for v in sc.values())
@@ -1128,7 +1135,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE config 5: CSR %d x %d power-law (mean %.1f nnz/row, clipped at %d), rows cut by "
                                 "non-zeros over %d GPUs, x replicated, step = local SpMV in %d parts with the all-gather of y "
-                                "inside the product" % (n_global, ncol, total_nnz / n_global, C5_MAXLEN, world, nparts)) if world > 1 else
+                                "inside the product" % (n_global, ncol, total_nnz / n_global, C5_MAXLEN, world, nparts)) if _multi(world) else
                                ("ONE shard of BASELINE config 5 (CSR %d x %d power-law, %d non-zeros in all): the rows rank %d of "
                                 "%d owns under the nnz-balanced cut; one GPU cannot hold the matrix in a struct CSR "
                                 "(2^31-1 non-zeros)" % (n_global, ncol, total_nnz, mine, parts)),
@@ -1139,12 +1146,12 @@ def run_c5(args, prov, world, rank, nccl, out=None):
                    "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
                    "with_transpose": with_t, "transpose_error": t_err, "kernel": kname,
                    "builder_timed_ms": prov.candidate_ms(A), "self_check": sc},
-        "roofline": _roofline(_klabel(kname), achieved, _traffic((kname,), "c5", n_local, 0) if world == 1 else None, bytes_local,
+        "roofline": _roofline(_klabel(kname), achieved, _traffic((kname,), "c5", n_local, 0) if not _multi(world) else None, bytes_local,
                               local_ms, args.steps, "profiles/traffic_c5_%s.json" % kname.replace("-", "_")),
     }
-    if world > 1:
+    if _multi(world):
         rec["config"]["rccl_status"] = "first contact: no multi-GPU machine was available to the builder"
-    if world == 1 and not args.no_cpu_baseline and hasattr(prov, "capi"):
+    if not _multi(world) and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
             rec["cpu_baseline"] = cpu_baseline_c5(lo, ncol, sample_rows=args.cpu_sample_rows or 1_000_000)
         except Exception as ex:
@@ -1288,14 +1295,14 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     state = {} if state is None else state
     sub = copy.copy(args)
     sub.cpu_sample_rows = args.cpu_sample_rows or 0
-    plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {}), ("cg", run_cg, {})] if world == 1 else \
+    plan = [("c3", run_c3, {}), ("c4", run_c4, {}), ("c5", run_c5, {}), ("cg", run_cg, {})] if not _multi(world) else \
            [("c2-strong", run_c2, {"strong": True}), ("c5", run_c5, {}), ("cg", run_cg_dist, {})]
     for name, fn, kw in plan:
         prov.release()
         state["current"] = name
         t0 = time.perf_counter()
         a = copy.copy(sub)
-        if world == 1:       # bounded samples for the CPU baselines of the sub-records: the default run stays within minutes
+        if not _multi(world):       # bounded samples for the CPU baselines of the sub-records: the default run stays within minutes
             a.cpu_sample_rows = args.cpu_sample_rows or {"c3": 1_000_000, "c4": 200_000, "c5": 500_000}.get(name, 0)
         else:
             a.transpose = True
@@ -1304,7 +1311,7 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
             err = None
         except BaseException as ex:   # incl. SystemExit of a workload's own argument checks
             rec, err = None, repr(ex)
-        if world > 1:        # a rank that failed must not leave the others waiting in the next workload's collectives
+        if _multi(world):        # a rank that failed must not leave the others waiting in the next workload's collectives
             bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=prov.dev if nccl else "cpu")
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if float(bad.item()) and not err:
@@ -1314,7 +1321,7 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
                 rec = {"workload": name, "error": err}
             rec["wall_s_incl_build"] = time.perf_counter() - t0
             recs.append(rec)
-        if err and world > 1:
+        if err and _multi(world):
             break            # collectives may be out of step after a failure: stop here
     state["current"] = None
     prov.release()
@@ -1398,21 +1405,24 @@ def main():
     dev_index = local_rank if nccl else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if _multi(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:      # FS_BENCH_FORCE_MULTI without a launcher: a one-rank group of its own
+            os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if nccl:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
     prov = HipProvider(dev)
-    if world > 1 and not os.environ.get("FS_BENCH_WATCHDOG"):
+    if _multi(world) and not os.environ.get("FS_BENCH_WATCHDOG"):
         # a collective that never returns (first contact with RCCL on more than one GPU) must not end in silence: after the
         # budget every rank dumps its Python stacks to stderr and exits
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ.get("FS_BENCH_BUDGET_S", "480")), repeat=False, exit=True)
     if args.workload in ("all", "c2"):
         rec = run_c2(args, prov, world, rank, nccl, strong=args.strong)
-        if world > 1 and not os.environ.get("FS_BENCH_WATCHDOG"):
+        if _multi(world) and not os.environ.get("FS_BENCH_WATCHDOG"):
             import faulthandler
             faulthandler.cancel_dump_traceback_later()      # the headline exists: from here on the budget watchdog prints it
         if args.workload == "all":
@@ -1429,7 +1439,7 @@ def main():
         rec = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload](args, prov, world, rank, nccl)
     if rank == 0 and rec is not None:
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if _multi(world):
         dist.destroy_process_group()
 
 

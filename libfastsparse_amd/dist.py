@@ -10,8 +10,17 @@ entries (`exchange_transpose_entries`), so both directions are "local SpMV + all
 Nothing here computes: `local_spmv(y_local, x_full)` is injected -- the HIP C-ABI in the product
 (`hip_local_spmv`), the oracle in the gloo tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _single(world):
+    """one rank and nothing to exchange -- unless FS_DIST_FORCE_COLLECTIVES=1 asks for the multi-rank code path anyway (a
+    one-rank RCCL group on the one-GPU box: the collectives, their stream ordering and the unpack all run; the counterpart
+    of FS_DIST_FORCE_RCCL in the native path)"""
+    return world == 1 and os.environ.get("FS_DIST_FORCE_COLLECTIVES", "0") != "1"
 
 
 def _host_collective(t, group):
@@ -202,7 +211,7 @@ class ShardedOperator:
     def local(self, y_full, x_full):
         """local product only; returns the tensor `gather` has to be called with"""
         n_local = self.hi - self.lo
-        if self.world == 1:
+        if _single(self.world):
             self.local_spmv(y_full, x_full)
             return y_full
         y_local = self._buffers(y_full)
@@ -211,7 +220,7 @@ class ShardedOperator:
 
     def gather(self, y_full, y_local):
         """the exchange step: all-gather of the y shards (no-op on one rank)"""
-        if self.world == 1:
+        if _single(self.world):
             return y_full
         n_local = self.hi - self.lo
         if self.equal:
@@ -231,7 +240,7 @@ class ShardedOperator:
         Equal shards: one all-gather straight into y_full.  Unequal shards (the nnz-balanced cut of a power-law
         matrix, BASELINE config 5): one all-gather of max-sized shards into a padded buffer, unpacked by `world`
         slice copies when the handle is waited for -- the transfer itself overlaps whatever is launched in between."""
-        if self.world == 1:
+        if _single(self.world):
             return _Done()
         if self.equal:
             return all_gather_into_async(y_full, y_local[:(self.hi - self.lo) * self.k], self.group)
@@ -271,7 +280,7 @@ class ShardedOperator:
     def apply_overlapped_async(self, y_full, x_full, nparts=4):
         """local product in `nparts` parts; the all-gather of part p's rows is started as soon as part p is enqueued and
         runs under parts p + 1 ...; returns a handle whose wait() leaves y_full complete on the current stream"""
-        if self.world == 1 or self.parts is None or nparts <= 1:
+        if _single(self.world) or self.parts is None or nparts <= 1:
             return self.gather_async(y_full, self.local(y_full, x_full))
         y_local = self._buffers(y_full)
         plan = self._part_plan(nparts, y_full)
@@ -338,12 +347,12 @@ class TransposedShardedOperator:
 
     def reduce(self, z_full):
         """the exchange step: sum of the partial results over the ranks (no-op on one rank)"""
-        if self.world > 1:
+        if not _single(self.world):
             all_reduce_sum(z_full, self.group)
         return z_full
 
     def reduce_async(self, z_full):
-        return all_reduce_sum_async(z_full, self.group) if self.world > 1 else _Done()
+        return _Done() if _single(self.world) else all_reduce_sum_async(z_full, self.group)
 
     def apply(self, z_full, u_full):
         self.apply_local(z_full, u_full)
@@ -403,7 +412,7 @@ def exchange_transpose_entries(rows_global, cols_global, vals, col_bounds, group
     else:
         dest, order, send_counts = local_part()
     lo = col_bounds[rank]
-    if world == 1:
+    if _single(world):
         return (cols_global[order] - lo), rows_global[order], (None if vals is None else vals[order])
     recv_counts = torch.empty_like(send_counts)
     all_to_all(recv_counts, send_counts, group=group)
@@ -446,7 +455,7 @@ class ShardedCG:
 
     def _sum(self, t):
         """sum over the ranks of a few partial dots"""
-        if self.world > 1:
+        if not _single(self.world):
             all_reduce_sum(t, self.group)
         return t
 
@@ -499,7 +508,7 @@ class ShardedCG:
         max_iter = F if max_iter is None else max_iter
         while it < max_iter:
             # p on every rank (gather: the slices are all-gathered; reduce: it is replicated already)
-            if gather and self.world > 1:
+            if gather and not _single(self.world):
                 pl = op_t._buffers(p_full)
                 pl[:n * k] = p
                 op_t.gather(p_full, pl)
@@ -511,7 +520,7 @@ class ShardedCG:
             else:
                 t_local = op_a.local(y_full, p_full)                     # rows of this rank only: nothing of length N moves
                 nl = op_a.hi - op_a.lo
-                op_t.local_tspmv(q, t_local[:nl * k] if op_a.world > 1 else y_full)
+                op_t.local_tspmv(q, y_full if _single(op_a.world) else t_local[:nl * k])
                 op_t.reduce(q)
             q.add_(p, alpha=lam)
             if k == 1:
@@ -539,7 +548,7 @@ class ShardedCG:
             it += 1
         if k == 2:
             x = (x.view(n, 2) * norms).reshape(-1)
-        if gather and self.world > 1:
+        if gather and not _single(self.world):
             x_full = torch.empty(F * k, dtype=dt, device=dev)
             xl = op_t._buffers(x_full)
             xl[:n * k] = x

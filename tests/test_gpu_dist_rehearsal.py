@@ -24,12 +24,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":       # ONE rank (RCCL refuses two ranks on one card): the multi-rank code path is forced instead
+        os.environ["FS_DIST_FORCE_COLLECTIVES"] = "1"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import bench
         from libfastsparse_amd import capi
@@ -103,6 +107,24 @@ def _worker(rank, world, port, ret):
                 if not (abs(it - itref) <= max(2, itref // 20) and err <= 1e-7 * max(1.0, float(np.max(np.abs(xref))))):
                     ok = False
                     why.append((k, scheme, it, itref, err))
+        if backend == "nccl":
+            # the remaining collectives of the path on device tensors: the all-reduce of z partials (scheme "reduce" of config 2),
+            # the all-to-all that builds the row shard of A', the plain asynchronous gather
+            u = torch.from_numpy(np.cos(0.11 * np.arange(N))).to(dev)
+            zt = torch.empty(F, dtype=torch.float64, device=dev)
+            op_r = fsd.TransposedShardedOperator(lambda zf, ul: A.spmv(zf, ul, st(), transposed=True), rb)
+            op_r.apply_local(zt, u)
+            op_r.reduce_async(zt).wait()
+            zref = np.asarray(O.coo_tmul(F, rows, cc, None, u.cpu().numpy()))
+            zg = torch.empty(F, dtype=torch.float64, device=dev)
+            fsd.ShardedOperator(lambda zl, uf: At.spmv(zl, uf, st()), cb).apply(zg, u)
+            if not torch.allclose(zt, zg, rtol=0, atol=1e-9) or not np.allclose(zt.cpu().numpy(), zref, rtol=0, atol=1e-9):
+                ok = False
+                why.append(("all-reduce of z", float((zt - zg).abs().max())))
+            r_at, c_at, _ = fsd.build_transposed_shard(l_rp.to(torch.int64), l_cc, None, lo, cb)
+            if not (torch.equal(r_at.to(torch.int32), t_rows) and torch.equal(c_at.to(torch.int32), t_cols)):
+                ok = False
+                why.append(("all-to-all transpose",))
         ret[rank] = (ok, why)
     finally:
         dist.destroy_process_group()
@@ -117,3 +139,40 @@ def test_two_gloo_ranks_on_one_gpu_overlapped_exchange_and_cg_on_the_hip_kernels
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert len(ret) == world and all(v[0] for v in ret.values()), dict(ret)
+
+
+@pytest.mark.gpu
+def test_one_rccl_rank_runs_the_multi_rank_code_path_on_device_tensors():
+    """RCCL itself under the same code: a one-rank "nccl" group with FS_DIST_FORCE_COLLECTIVES=1, so that the asynchronous
+    all-gathers of the parts (on RCCL's stream, ordered against the product's stream by the work handles), the unpack, the
+    all-reduces of the dots and of z and the all-to-all of the transpose build all run on device tensors.  What one rank cannot
+    show is the transport between GPUs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(1, _free_port(), ret, "nccl"), nprocs=1, join=True)
+    assert len(ret) == 1 and all(v[0] for v in ret.values()), dict(ret)
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_multi_rank_plan_on_one_rccl_rank():
+    """`bench.py` with FS_BENCH_FORCE_MULTI=1: the N > 1 plan (config 2 weak + strong, config 5 across the ranks, the row-sharded
+    CG) on a ONE-rank "nccl" group -- init_process_group with device_id, the device-side timing all-reduce and barrier, the
+    all-gathers inside the products, every sub-record's self-check.  Reduced sizes; full size: profiles/r03_bench_n_gt_1_plan_on_one_rccl_rank.json"""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, FS_BENCH_FORCE_MULTI="1", FS_DIST_FORCE_COLLECTIVES="1", FS_BENCH_WATCHDOG="300")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--rows", "2000000", "--c5-rows", "3000000"], env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    recs = [rec] + rec["also"]
+    assert len(recs) >= 4, [r["config"]["workload"][:40] for r in recs]
+    for r in recs:
+        assert r["config"]["self_check"]["ok"], r["config"]
+    assert "all-gather" in rec["config"]["exchange"]["y"]
