@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfastsparse_hip.so")
+# FS_LIB_PATH: an experiment build of the same library (tools/build_variants.py: ablation / instrumented kernels), never a fallback
+LIB_PATH = os.environ.get("FS_LIB_PATH") or os.path.join(HERE, "libfastsparse_hip.so")
 # FS_HOST_ONLY_LIB=<path>: a library holding ONLY the host half (fs_host.c, fs_sort.c: constructors, loaders, sorters) -- the
 # sanitizer build tests/test_host_sanitizers.py runs the host tests against; no device entry point is declared on it
 HOST_ONLY_LIB = os.environ.get("FS_HOST_ONLY_LIB")

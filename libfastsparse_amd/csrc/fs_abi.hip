@@ -147,6 +147,7 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "long_min_len")) { fs::options().long_min_len = value; return FS_OK; }
   if (!strcmp(name, "long_geometry")) { fs::options().long_geometry = value; return FS_OK; }
   if (!strcmp(name, "spmm_kernel")) { fs::options().spmm_kernel = value; return FS_OK; }
+  if (!strcmp(name, "spmm_wide")) { fs::options().spmm_wide = value; return FS_OK; }
   if (!strcmp(name, "ata_kernel")) { fs::options().ata_kernel = value; return FS_OK; }
   if (!strcmp(name, "device_build")) { fs::options().device_build = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
@@ -166,6 +167,7 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "ldsx")) return fs::options().ldsx;
   if (name && !strcmp(name, "reproducible")) return fs::options().reproducible;
   if (name && !strcmp(name, "spmm_kernel")) return fs::options().spmm_kernel;
+  if (name && !strcmp(name, "spmm_wide")) return fs::options().spmm_wide;
   if (name && !strcmp(name, "ata_kernel")) return fs::options().ata_kernel;
   if (name && !strcmp(name, "device_build")) return fs::options().device_build;
   return FS_ERR_ARG;
@@ -384,11 +386,17 @@ int fs_debug_long_rows(fs_matrix_t A, int transposed, int64_t *out2)
 
 int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
 {
-  if (!A || !A->a.tiled || !A->a.tiled->built) { set_error("no tiled copy"); return FS_ERR_ARG; }
-  const fs::TiledCsr &T = *A->a.tiled;
+  const bool hx = A && A->a.tiledx && A->a.tiledx->built;     // the LDS-staged copy when that is the one built
+  if (!A || !(hx || (A->a.tiled && A->a.tiled->built))) { set_error("no tiled copy"); return FS_ERR_ARG; }
+  const fs::TiledCsr &T = hx ? *A->a.tiledx : *A->a.tiled;
   out6[0] = T.R; out6[1] = T.W; out6[2] = T.P; out6[3] = T.J; out6[4] = T.nitems; out6[5] = T.lcol_bits;
   return FS_OK;
 }
+
+#if defined(FS_DMA_TRACE) && FS_DMA_TRACE
+// instrumented builds only (-DFS_DMA_TRACE=1|2, tools/dma_phase_trace.py): clock sums of wave 0 of every workgroup of the DMA kernel
+int fs_debug_dma_trace(unsigned long long *out8, int reset) { return fs::debug_dma_trace(out8, reset); }
+#endif
 
 int fs_debug_tiled_trace(fs_matrix_t A, double *y, const double *x, long long *times_host, int *xcc_host,
                          int *items_host, int *item_ptr_host)

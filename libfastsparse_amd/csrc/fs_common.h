@@ -274,6 +274,7 @@ struct Options {
   int device_build = -1; // format constructors (new_csr, new_bcsr, new_cbcsr, new_bsbm, new_bsdm): -1 = FS_DEVICE_BUILD or 1;
                          // 0 host loops, 1 on the device from 4 M entries, 2 on the device whenever one is visible
   int ata_kernel = 0;    // fs_ata_mul: 0 / 1 two products (A, then the cached A'), 2 the fused single kernel (no copy of A')
+  int spmm_wide = 0;     // row SpMM kernel with two columns per lane and 16-byte loads: 0 auto (even k from 4 to 14, 16-byte aligned X / Y), 1 wherever legal, -1 never
   int spmm_kernel = 0;   // multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep (k = 2..4), 3 one
                          // single-vector sweep per column, 4 the MFMA row kernel (experiment, see spmm_mfma_kernel)
 };
@@ -281,6 +282,7 @@ Options &options();
 
 // ---- launchers implemented in fs_kernels.hip --------------------------------------------
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
+int debug_dma_trace(unsigned long long *out8, int reset);   // defined in -DFS_DMA_TRACE builds only
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // never builds, never waits: see prepare_spmm
 int prepare_spmm(DeviceCsr &A, int k, hipStream_t s);   // k-column copy, scratch, measured choice: synchronous, idempotent
 int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare);   // which kernel launch_spmm runs for this k (kPlan* in fs_kernels.hip)

@@ -916,7 +916,13 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     R = (int)(((int64_t)nvrow + slots * g - 1) / (slots * g));
     if (R < 256) R = nvrow < 256 ? nvrow : 256;
     // few rows: full-height panels (dense tiles), cut into chunks below so that every CU still has work
-    if (ldsx && (int64_t)nvrow < (int64_t)slots * rows_max / 2) R = rows_max;
+    // (as equal as the row count allows: a remainder panel of a few hundred rows still sweeps every band -- 1 M rows under a limit
+    // of 14 272 rows left one of 960 rows whose single chunk of 4 883 nearly empty phases took as long as everything else
+    // together: config 3 transposed 0.75 -> 1.10 ms, profiles/r03_c3_kernel_variants_and_panel_cliff.jsonl)
+    if (ldsx && (int64_t)nvrow < (int64_t)slots * rows_max / 2) {
+      const int np = (int)(((int64_t)nvrow + rows_max - 1) / rows_max);
+      R = (int)(((int64_t)nvrow + np - 1) / (np > 0 ? np : 1));
+    }
   }
   if (R > rows_max) R = rows_max;
   std::vector<int> panel_row;
@@ -1071,14 +1077,16 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     // CUs take as long as 512) with entry counts as equal as the panels allow; a panel gets its share, at least one,
     // cut at item boundaries.  Measured on config 3 transposed (66 panels): 1 / 2 / 4 / 8 chunks per CU 3.7 / 3.7 /
     // 2.3 / 1.9 ms with rounded shares.
+    // (a chunk costs its PHASES: a work item takes about the same time whatever it holds, so panels are given chunks, and
+    // chunks are cut, by numbers of work items)
     const int64_t total = (P >= slots) ? P : 8 * (int64_t)slots;
     std::vector<int64_t> nnz_p((size_t)P, 0);
     std::vector<int> k_p((size_t)P, 1);
     std::vector<std::pair<double, int>> frac;
     int64_t given = 0;
     for (int p = 0; p < P; ++p) {
-      for (int i = item_ptr[p]; i < item_ptr[p + 1]; ++i) nnz_p[p] += items[i].y;
-      const double share = (double)nnz_p[p] * (double)total / (double)A.nnz;
+      nnz_p[p] = item_ptr[p + 1] - item_ptr[p];
+      const double share = (double)nnz_p[p] * (double)total / (double)(items.empty() ? 1 : items.size());
       const int cap = item_ptr[p + 1] - item_ptr[p] > 0 ? item_ptr[p + 1] - item_ptr[p] : 1;
       int k = (int)share;
       if (k < 1) k = 1;
@@ -1103,7 +1111,7 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
       for (int c = 0; c < k; ++c) {
         const int first = i;
         const int64_t goal = nnz_p[p] * (c + 1) / k;
-        while (i < i1 && (done < goal || c == k - 1)) done += items[i++].y;
+        while (i < i1 && (done < goal || c == k - 1)) { ++i; ++done; }
         chunks.push_back(Chunk{p | flag, first, i, c});
       }
     }

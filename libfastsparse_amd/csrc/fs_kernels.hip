@@ -648,6 +648,15 @@ __device__ __forceinline__ void ldsx_load2_entries(const int4 d, int t, const un
   // on an odd end reads one entry of the next item (or of the slack behind the array), masked too
   const int64_t e = (int64_t)d.x + (2 * t < d.y ? 2 * t : 0);
   // (the pair types carry the alignment of ONE element: spelled out here, a template would deduce the plain vector type)
+#if defined(FS_DMA_ABL) && FS_DMA_ABL == 5
+  // ablation (timing only, results wrong): HALF the entry bytes with the same number of loads -- what a 16-bit entry would move
+  if (!VALUED) {
+    const unsigned *p1 = pk + (e >> 1);
+    const unsigned one = NT ? __builtin_nontemporal_load(p1) : *p1;
+    w[0] = one; w[1] = one;
+    return;
+  }
+#endif
   const v2u_a4 *pp = reinterpret_cast<const v2u_a4 *>(pk + e);
   const v2u_a4 pw = NT ? __builtin_nontemporal_load(pp) : *pp;
   w[0] = pw.x; w[1] = pw.y;
@@ -843,6 +852,76 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(int nrow, int k, const int
 }
 
 // ------------------------------------------------------------------------------------------
+// The same product with 16-byte loads: a lane owns TWO neighbouring output columns, a row is served by 2^LG >= k/2 lanes, up
+// to sixteen X rows are in flight per lane.  tools/probe_rowgather (profiles/r03_probe_rowgather.jsonl) is why: from a table
+// far larger than the caches HBM hands out 128-byte lines at 53 G lines/s whatever part of the line is used (160 M rows of 16,
+// 32 or 64 bytes: 3.0 ms each), and for rows of 128 / 256 bytes dwordx4 loads with 16 rows in flight reach 6.2 / 5.6 TB/s where
+// dwordx2 loads with 8 in flight reach 5.4 / 4.9.  Every column still adds its terms in storage order (bit-identical to
+// spmm_kernel).  Needs an even k and 16-byte aligned X and Y.
+// ------------------------------------------------------------------------------------------
+template <bool VALUED, int LG>
+__global__ __launch_bounds__(kBlock) void spmm_wide_kernel(int nrow, int k, const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ cols,
+                                                          const double *__restrict__ vals,
+                                                          const double *__restrict__ X, double *__restrict__ Y)
+{
+  constexpr int KP = 1 << LG;                    // lanes per row = column PAIRS handled together
+  constexpr int EPL = LG < 4 ? (16 >> LG) : 1;   // entries per lane and step: a step always covers >= 16 entries
+  constexpr int EB = KP * EPL;
+  constexpr int gpb = kBlock >> LG;
+  const int j = threadIdx.x & (KP - 1);
+  const int64_t row = (int64_t)blockIdx.x * gpb + (threadIdx.x >> LG);
+  if (row >= nrow) return;
+  const int a = row_ptr[row], b = row_ptr[row + 1];
+  const int kh = k >> 1;
+  const double2 *__restrict__ X2 = reinterpret_cast<const double2 *>(X);
+  double2 *__restrict__ Y2 = reinterpret_cast<double2 *>(Y);
+  for (int j0 = 0; j0 < kh; j0 += KP) {
+    const int pr = j0 + j;
+    const bool act = pr < kh;
+    const int prc = act ? pr : kh - 1;           // lanes past the last pair read a valid address and store nothing
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int64_t base = a; base < b; base += EB) {
+      int myc[EPL];
+      double myv[EPL];
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) {            // unconditional loads from clamped positions, as in spmm_kernel
+        const int64_t e = base + q * KP + j;
+        const int64_t ec = e < b ? e : b - 1;
+        myc[q] = cols[ec];
+        if (VALUED) myv[q] = vals[ec];
+      }
+      const int n = (b - base < EB) ? (int)(b - base) : EB;
+#define FS_WIDE_GROUP(U)                                                                           \
+  {                                                                                                \
+    double2 xv[U];                                                                                 \
+    double wv[U];                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
+      const int i = i0 + u;                                                                        \
+      const int cc = __shfl(myc[(i / KP) % EPL], i & (KP - 1), KP);                                \
+      if (VALUED) wv[u] = __shfl(myv[(i / KP) % EPL], i & (KP - 1), KP);                           \
+      xv[u] = X2[(int64_t)cc * kh + prc];                                                          \
+    }                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                  \
+      if (i0 + u < n) {                                                                            \
+        acc0 += VALUED ? xv[u].x * wv[u] : xv[u].x;                                                \
+        acc1 += VALUED ? xv[u].y * wv[u] : xv[u].y;                                                \
+      }                                                                                            \
+  }
+#pragma unroll
+      for (int i0 = 0; i0 < EB; i0 += 16) {
+        if (i0 < n) {
+          if (n - i0 > 8) FS_WIDE_GROUP(16)
+          else FS_WIDE_GROUP(8)
+        }
+      }
+#undef FS_WIDE_GROUP
+    }
+    if (act) Y2[row * kh + pr] = make_double2(acc0, acc1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Y = A X on the matrix cores: the experiment BASELINE.json's north_star asks for ("MFMA only to the dense panel
 // accumulate"), kept as an opt-in kernel (option spmm_kernel = 4) so that its counters can be put next to the row
 // kernel's.  One wave per CSR row.  v_mfma_f64_16x16x4_f64 computes D(16x16) += A(16x4) B(4x16) with ONE f64 of A and
@@ -962,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int n
 #define FS_DMA_ADDS_LAST 1
 #endif
 #ifndef FS_DMA_ABL
-#define FS_DMA_ABL 0   // ablation builds (timing only, results wrong): 1 no slice DMA, 3 no adds, 4 no gathers
+#define FS_DMA_ABL 0   // ablation builds (timing only, results wrong): 1 no slice DMA, 3 no adds, 4 no gathers, 5 half the entry bytes, 6 neither gathers nor adds, 7 = 6 without the slice DMA
 #endif
 constexpr int kLdsxDmaSets = FS_DMA_SETS;
 #define FS_WAIT_IMM(VM, LGKM) (((VM) & 0xF) | (0x7 << 4) | (((LGKM) & 0xF) << 8) | (((VM) >> 4) << 14))
@@ -970,6 +1049,19 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
+
+#ifndef FS_DMA_TRACE
+#define FS_DMA_TRACE 0   // instrumented builds (tools/dma_phase_trace.py): wave 0 of every workgroup times the segments of its phases
+#endif
+#if FS_DMA_TRACE
+__device__ unsigned long long g_dma_trace[8];
+__device__ __forceinline__ unsigned long long dma_clock()
+{
+  unsigned long long c;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : : "memory");
+  return c;
+}
+#endif
 
 template <bool VALUED, bool NT, int NSETS>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
@@ -1016,6 +1108,9 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
   const unsigned ybase = lds_addr(ytile);
   const unsigned xbase[3] = {lds_addr(xs0), lds_addr(xs1), lds_addr(xs2)};
   __syncthreads();
+#if FS_DMA_TRACE
+  unsigned long long tr_a = 0, tr_bc = 0, tr_d = 0, tr_n = 0, tr_0 = dma_clock();
+#endif
   for (int it = first; it < it1; it += NSETS) {
 #pragma unroll
     for (int ph = 0; ph < NSETS; ++ph) {
@@ -1029,13 +1124,13 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const unsigned a = xbase[(ph + 1) % 3] + ((w[s1][q] & cmask) << 3);                // item IT+1: gathered now
-        if (FS_DMA_ABL != 4) asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
+        if (FS_DMA_ABL != 4 && FS_DMA_ABL != 6 && FS_DMA_ABL != 7) asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
         else gnew[q] = 1.0;
       }
       {
         const int c0 = dS.z * W + 2 * t;
         const int cc = c0 + 1 < ncol ? c0 : ncol - 2;            // ncol is even and >= 2 here
-        if (FS_DMA_ABL != 1)
+        if (FS_DMA_ABL != 1 && FS_DMA_ABL != 7)
           __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(x + cc),
                                            (void __attribute__((address_space(3))) *)(bfree + wave_cols), 16, 0, 0);
       }
@@ -1051,36 +1146,86 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
       asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));
       __builtin_amdgcn_sched_barrier(0);
 #endif
+#if FS_DMA_TRACE
+      unsigned long long tr_1 = 0;
+      if (t < 64) { tr_1 = dma_clock(); tr_a += tr_1 - tr_0; }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         if (2 * t + q < dset[s0].y) {
           double pr = gcur[q];
           if (VALUED) pr *= v[s0][q];
           const unsigned a = ybase + ((w[s0][q] >> lcol_bits) << 3);
-          if (FS_DMA_ABL != 3) asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
+          if (FS_DMA_ABL != 3 && FS_DMA_ABL != 6 && FS_DMA_ABL != 7) asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
+          else asm volatile("" : : "v"(a), "v"(pr));     // (the ablation keeps the entries it no longer uses alive: their loads must stay)
         }
       }
       // (the entries after the adds: requested right behind the DMA, 0.70 -> 0.74 ms -- memory instructions issued in a
       // burst queue up in front of the address unit)
       ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(VALUED ? 5 : 3, FS_DMA_ADDS_LAST ? 15 : 0));
+#if defined(FS_DMA_EXTRA_SALU)      // issue-slot probe: that many more scalar (and, FS_DMA_EXTRA_VALU, vector) instructions per phase
+      {
+        int dummy_s = IT;
+#pragma unroll
+        for (int e = 0; e < FS_DMA_EXTRA_SALU; ++e) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy_s));
+#if defined(FS_DMA_EXTRA_VALU)
+        int dummy_v = t;
+#pragma unroll
+        for (int e = 0; e < FS_DMA_EXTRA_VALU; ++e) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy_v));
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#if FS_DMA_TRACE == 2      // the clock BEFORE the wait for the slice: what the issue of the adds and entries (and the adds' drain) takes
+      unsigned long long tr_3 = 0;
+      if (t < 64) { tr_3 = dma_clock(); tr_bc += tr_3 - tr_1; }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // (ablation 7, no DMA in the queue: the entries of item IT+2 are home, NSETS - 3 phases of entry loads stay in flight)
+      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(FS_DMA_ABL == 7 ? (VALUED ? 2 : 1) * (NSETS - 3) : (VALUED ? 5 : 3), FS_DMA_ADDS_LAST ? 15 : 0));
 #if !FS_DMA_ADDS_LAST
       asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));   // see above
 #endif
+#if FS_DMA_TRACE == 1
+      unsigned long long tr_3 = 0;
+      if (t < 64) { tr_3 = dma_clock(); tr_bc += tr_3 - tr_1; }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       __builtin_amdgcn_s_barrier();
+#if FS_DMA_TRACE
+      if (t < 64) { tr_0 = dma_clock(); tr_d += tr_0 - tr_3; tr_n += 1; }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       gcur[0] = gnew[0]; gcur[1] = gnew[1];
     }
   }
   __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));
   __syncthreads();
+#if FS_DMA_TRACE
+  if (t == 0) {
+    atomicAdd(&g_dma_trace[0], tr_a); atomicAdd(&g_dma_trace[1], tr_bc); atomicAdd(&g_dma_trace[2], tr_d);
+    atomicAdd(&g_dma_trace[3], tr_n); atomicAdd(&g_dma_trace[4], 1ull);
+  }
+#endif
   if (shared) {
     for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
   } else {
     for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
   }
 }
+
+#if FS_DMA_TRACE
+int debug_dma_trace(unsigned long long *out8, int reset)
+{
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  FS_HIP(hipDeviceSynchronize());
+  if (out8) FS_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dma_trace), sizeof(z)));
+  if (reset) FS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dma_trace), z, sizeof(z)));
+  return FS_OK;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // y = A x in two streaming passes (BinnedCsr in fs_common.h).  Same callers as the kernels above.
@@ -2327,6 +2472,30 @@ static int spmm_scratch_ready(DeviceCsr &A, int k, int64_t *ldx_out, int64_t *ld
 
 static int launch_spmm_row(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
+  // two columns per lane and 16-byte loads where the layout allows it and it measured faster (config 4's matrix, k = 4 / 6 / 8 /
+  // 12: 3.39 / 3.88 / 3.32 / 5.00 ms -> 3.30 / 3.76 / 3.19 / 4.83; k = 16 / 32 / 64: 3.65 / 7.94 / 16.15 -> 3.71 / 7.93 / 16.20:
+  // there both sit at the HBM rate for the lines they pull, profiles/r03_spmm_wide_ab.jsonl); option spmm_wide: 1 wherever
+  // legal, -1 never
+  const int wide = options().spmm_wide;
+  if (wide >= 0 && (k & 1) == 0 && (wide > 0 || (k >= 4 && k <= 14)) && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0) {
+    const int kh = k >> 1;
+    const int lg = ceil_log2(kh > 64 ? 64 : kh);
+    const int gpb = kBlock >> lg;
+    const unsigned grid = (unsigned)(((int64_t)A.nrow + gpb - 1) / gpb);
+#define FS_SPMMW(V, L) \
+  hipLaunchKernelGGL((spmm_wide_kernel<V, L>), dim3(grid), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y)
+#define FS_SPMMW_LG(V)                                                                                  \
+  switch (lg) {                                                                                         \
+    case 0: FS_SPMMW(V, 0); break; case 1: FS_SPMMW(V, 1); break; case 2: FS_SPMMW(V, 2); break;        \
+    case 3: FS_SPMMW(V, 3); break; case 4: FS_SPMMW(V, 4); break; case 5: FS_SPMMW(V, 5); break;        \
+    default: FS_SPMMW(V, 6); break;                                                                     \
+  }
+    if (A.vals) { FS_SPMMW_LG(true) } else { FS_SPMMW_LG(false) }
+#undef FS_SPMMW_LG
+#undef FS_SPMMW
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+  }
   const int lg = ceil_log2(k > 64 ? 64 : k);
   const int gpb = kBlock >> lg;
   const unsigned grid = (unsigned)(((int64_t)A.nrow + gpb - 1) / gpb);

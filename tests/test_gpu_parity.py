@@ -954,6 +954,79 @@ def test_spmm_matrix_core_experiment(hip, k):
         capi.set_option("spmm_kernel", 0)
 
 
+def test_lds_staged_panels_are_cut_to_equal_heights(hip):
+    """Few rows, many columns (the shape of config 3 transposed): the LDS-staged copy takes full-height panels and cuts them
+    into chunks.  Every panel sweeps every band whatever it holds, so a remainder panel of a few hundred rows costs as many
+    phases as a full one (round 3: 1 M rows under a limit of 14 272 left one of 960 rows and the product took 1.10 ms instead
+    of 0.75): panels must be as equal as the row count allows.  2 x 14 336 + 300 rows -> three panels of 9 658 / 9 658 / 9 656
+    rows, not 14 336 / 14 336 / 300.  Product against the oracle, bit for bit on integer x."""
+    import ctypes as C
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(99)
+    nrow, ncol, per = 2 * 14336 + 300, 300_000, 200
+    rp = (np.arange(nrow + 1, dtype=np.int64) * per).astype(np.int32)
+    cc = rng.integers(0, ncol, nrow * per).astype(np.int32)
+    for k, v in (("ldsx", 2), ("tiling", 0), ("binning", 0)):
+        capi.set_option(k, v)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, None)
+    finally:
+        for k, v in (("ldsx", 1), ("tiling", 1), ("binning", 1)):
+            capi.set_option(k, v)
+    assert A.kernel_name() == "lds-staged"
+    L = capi.lib()
+    L.fs_debug_tiled_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    g = (C.c_int * 6)()
+    assert L.fs_debug_tiled_geometry(A.h, g) == 0
+    R, P = int(g[0]), int(g[2])
+    assert P == 3 and R == -(-nrow // 3), (R, P)
+    x = S.x_int(12, ncol)
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    A.spmv(y, torch.from_numpy(x).cuda(), capi.current_stream())
+    assert np.array_equal(y.cpu().numpy(), O.csr_mul(nrow, rp, cc, None, x))
+
+
+@pytest.mark.parametrize("k", [2, 4, 6, 8, 12, 16, 32, 40, 130])
+def test_spmm_row_kernel_with_16_byte_loads_has_the_bits_of_the_row_loop(hip, k):
+    """spmm_wide_kernel (two columns per lane, dwordx4 loads, up to sixteen X rows in flight; the default for even k from 4 to
+    14 with 16-byte aligned X and Y, forced here by spmm_wide = 1): every column adds in storage order, so VALUED products with
+    real X must equal the oracle's row loop (csr.h:441-465) bit for bit; rows of 0 .. 39 entries, one of 1234 (several steps of
+    the entry loop), k / 2 not a power of two, k > 128 (more than one pass over the columns); and an X that is only 8-byte
+    aligned must fall back to the one-column kernel with the same bits"""
+    import torch
+    from libfastsparse_amd import capi
+    rng = np.random.default_rng(11 * k)
+    nrow, ncol = 30_000, 20_000
+    lens = rng.integers(0, 40, nrow)
+    lens[5] = 1234
+    lens[rng.uniform(size=nrow) < 0.05] = 0
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    st = capi.current_stream()
+    capi.set_option("spmm_kernel", 1)
+    capi.set_option("spmm_wide", 1)
+    try:
+        for vv in (rng.uniform(-1, 1, nnz), None):
+            X = S.X_sin(ncol, k)
+            A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)
+            ref = O.csr_mul_n(nrow, rp, cc, vv, X, k)
+            Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
+            assert np.array_equal(Y.cpu().numpy(), ref)
+            buf = torch.zeros(ncol * k + 1, dtype=torch.float64, device="cuda")      # X at an odd multiple of 8 bytes
+            buf[1:] = torch.from_numpy(X).cuda().reshape(-1)
+            Y.fill_(-1.0)
+            A.spmm(Y, buf[1:], k, st)
+            assert np.array_equal(Y.cpu().numpy(), ref)
+    finally:
+        capi.set_option("spmm_kernel", 0)
+        capi.set_option("spmm_wide", 0)
+
+
 def _csr_struct(hip, nrow, ncol, rp, cc, vv):
     return hip.CSR(nrow, ncol, len(cc), hip._ip(rp), hip._ip(cc), hip._dp(vv))
 

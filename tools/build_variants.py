@@ -1,0 +1,40 @@
+"""Experiment builds of the library next to the product build: fs_kernels.hip (and fs_abi.hip, for the debug exports) compiled with
+extra -D flags, linked with the product build's other objects into libfastsparse_amd/build/variants/libfs_<name>.so; a tool then runs
+with FS_LIB_PATH=<that file>.  Several variants fit into ONE gpurun call, i.e. are timed on the same box.
+    python tools/build_variants.py name=-DFS_DMA_ABL=3 other="-DFS_DMA_ABL=4 -DFS_DMA_SETS=9" ..."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from libfastsparse_amd import _build  # noqa: E402
+
+
+def one(spec):
+    name, flags = spec.split("=", 1)
+    out_dir = os.path.join(_build.OBJ, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + _build.CSRC]
+    objs = []
+    for src in _build.HIP_SOURCES:
+        if src in ("fs_kernels.hip", "fs_abi.hip"):
+            o = os.path.join(out_dir, "%s_%s.o" % (name, src))
+            subprocess.check_call([_build._hipcc(), "--offload-arch=" + _build.ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                                   "-Wall", "-Wno-unused-result"] + flags.split() + inc + ["-c", os.path.join(_build.CSRC, src), "-o", o])
+        else:
+            o = os.path.join(_build.OBJ, src + ".o")
+        objs.append(o)
+    objs += [os.path.join(_build.OBJ, src + ".o") for src in _build.C_SOURCES]
+    lib = os.path.join(out_dir, "libfs_%s.so" % name)
+    subprocess.check_call([_build._hipcc(), "--offload-arch=" + _build.ARCH, "-shared", "-fPIC"] + objs +
+                          ["-o", lib, "-lm", "-ldl", "-pthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return lib
+
+
+if __name__ == "__main__":
+    _build.build()
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        for lib in ex.map(one, sys.argv[1:]):
+            print(lib)
