@@ -1,9 +1,14 @@
 // fs_cg.hip -- the consumers of the A_mul_B path, device resident:
 // conjugate gradients on (A'A + lambda I) with one right-hand side (bsbm_cg, cg.h:25-82) and with two
 // row-major right-hand sides (bsbm_cg2, cg.h:85-187).  Every vector lives in HBM for the whole solve; per
-// iteration two products (fs_spmv / fs_spmm on A and A') and three fused vector kernels run, and one or two
-// 8..24-byte reductions travel to the host, which does the scalar / 2x2 algebra (solve2sym, linalg.h:77-88)
-// exactly as the reference does.
+// iteration two products (fs_spmv / fs_spmm on A and A') and three fused vector kernels run.  The scalars of the
+// iteration (alpha, beta, r.r; for two right-hand sides the 2x2 algebra of solve2sym, linalg.h:77-88) are computed
+// ON THE DEVICE by the one-workgroup kernel that finishes each reduction, with the reference's formulas, and stay
+// there: nothing in an iteration waits for the host.  The host only has to learn WHEN to stop enqueuing: the
+// "done" flag of iteration i is copied to pinned memory behind it and looked at while iteration i + 1 runs; the
+// vector kernels of iterations enqueued past the end see the flag and do nothing (their products are wasted
+// work: at most two iterations' worth).  Round 2 fetched every reduction to the host: two stream
+// synchronisations per iteration, 0.1-0.2 ms of idle GPU in a 1.5 ms iteration.
 //
 // Reductions are two-stage with a fixed shape (1024 workgroup partials, then one workgroup), so results are
 // reproducible run to run; they are NOT the CPU's single left-to-right sums, so iterates agree with the
@@ -187,7 +192,12 @@ __global__ __launch_bounds__(kRedThreads) void cg2_scale_kernel(int n, double n0
   }
 }
 
-static void solve2sym_host(double *X, const double *A, const double *RHS)  // linalg.h:77-88
+// ---- the same steps with their scalars in device memory (fs_cg / fs_cg2) ---------------------------------
+// state of one solve, doubles.  One right-hand side: rsq_old, alpha, beta, stop; two: RtR[3], Alpha[4], Psi[4], tolsq
+enum { kStDone = 0, kStIter = 1, kStRsq = 2, kStAlpha = 3, kStBeta = 4, kStStop = 5,
+       kSt2RtR = 2, kSt2Alpha = 5, kSt2Psi = 9, kSt2Tolsq = 13, kStDoubles = 16 };
+
+__device__ __forceinline__ void solve2sym_dev(double *X, const double *A, const double *RHS)  // linalg.h:77-88
 {
   const double dinv = 1.0 / (A[0] * A[1] - A[2] * A[2]);
   const double i0 = dinv * A[1], i1 = dinv * A[0], i2 = -dinv * A[2];
@@ -195,6 +205,138 @@ static void solve2sym_host(double *X, const double *A, const double *RHS)  // li
   X[1] = i2 * RHS[0] + i1 * RHS[1];
   X[2] = i0 * RHS[2] + i2 * RHS[3];
   X[3] = i2 * RHS[2] + i1 * RHS[3];
+}
+
+// the one workgroup that finishes a reduction, then does the iteration's scalar step (cg.h:59-76, 143-172):
+//   MODE 0  b.b: rsq_old, stop = tol sqrt(b.b), done = 0, iter = 0           (tol in `arg`)
+//   MODE 1  p.q: alpha = rsq_old / p.q
+//   MODE 2  r.r: converged -> done; else beta = rsq_new / rsq_old, rsq_old = rsq_new, ++iter
+//   MODE 3  P'KP: Alpha = solve2sym(P'KP, R'R)
+//   MODE 4  R'R new: both <= tol^2 -> done; else Psi = solve2sym(R'R, R'R new), R'R = R'R new, ++iter
+template <int NV, int MODE>
+__global__ __launch_bounds__(kRedThreads) void final_step_kernel(const double *__restrict__ part, int nblocks,
+                                                                double *__restrict__ red, double *__restrict__ st, double arg)
+{
+  if (MODE != 0 && st[kStDone] != 0.0) return;
+  double v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kRedThreads) v[j] += part[b * NV + j];
+  }
+  block_sum<NV>(v, red);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (MODE == 0) {
+    st[kStRsq] = red[0]; st[kStStop] = arg * sqrt(red[0]); st[kStDone] = 0.0; st[kStIter] = 0.0;
+  } else if (MODE == 1) {
+    st[kStAlpha] = st[kStRsq] / red[0];
+  } else if (MODE == 2) {
+    const double rsq_new = red[0];
+    if (sqrt(rsq_new) <= st[kStStop]) st[kStDone] = 1.0;
+    else { st[kStBeta] = rsq_new / st[kStRsq]; st[kStRsq] = rsq_new; st[kStIter] += 1.0; }
+  } else if (MODE == 3) {
+    const double rhs[4] = {st[kSt2RtR], st[kSt2RtR + 2], st[kSt2RtR + 2], st[kSt2RtR + 1]};
+    double a[4];
+    solve2sym_dev(a, red, rhs);
+    st[kSt2Alpha] = a[0]; st[kSt2Alpha + 1] = a[1]; st[kSt2Alpha + 2] = a[2]; st[kSt2Alpha + 3] = a[3];
+  } else {
+    const double n0 = red[0], n1 = red[1], n2 = red[2], tolsq = st[kSt2Tolsq];
+    if (n0 <= tolsq && n1 <= tolsq) st[kStDone] = 1.0;
+    else {
+      const double old[3] = {st[kSt2RtR], st[kSt2RtR + 1], st[kSt2RtR + 2]};
+      const double rhs[4] = {n0, n2, n2, n1};
+      double ps[4];
+      solve2sym_dev(ps, old, rhs);
+      st[kSt2Psi] = ps[0]; st[kSt2Psi + 1] = ps[1]; st[kSt2Psi + 2] = ps[2]; st[kSt2Psi + 3] = ps[3];
+      st[kSt2RtR] = n0; st[kSt2RtR + 1] = n1; st[kSt2RtR + 2] = n2;
+      st[kStIter] += 1.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg_shift_dot_dev_kernel(int n, double lambda, double *__restrict__ q,
+                                                                      const double *__restrict__ p, double *__restrict__ part,
+                                                                      const double *__restrict__ st)
+{
+  if (st[kStDone] != 0.0) return;
+  double v[1] = {0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pi = p[i];
+    const double qi = q[i] + lambda * pi;
+    q[i] = qi;
+    v[0] += qi * pi;
+  }
+  block_sum<1>(v, part);
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg_update_dev_kernel(int n, double *__restrict__ x, double *__restrict__ r,
+                                                                   const double *__restrict__ p, const double *__restrict__ q,
+                                                                   double *__restrict__ part, const double *__restrict__ st)
+{
+  if (st[kStDone] != 0.0) return;
+  const double alpha = st[kStAlpha];
+  double v[1] = {0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    v[0] += ri * ri;
+  }
+  block_sum<1>(v, part);
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg_direction_dev_kernel(int n, double *__restrict__ p, const double *__restrict__ r,
+                                                                      const double *__restrict__ st)
+{
+  if (st[kStDone] != 0.0) return;
+  const double beta = st[kStBeta];
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) p[i] = r[i] + beta * p[i];
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg2_shift_dot_dev_kernel(int n, double lambda, double *__restrict__ Q,
+                                                                       const double *__restrict__ P, double *__restrict__ part,
+                                                                       const double *__restrict__ st)
+{
+  if (st[kStDone] != 0.0) return;
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pa = P[2 * i], pb = P[2 * i + 1];
+    const double qa = Q[2 * i] + lambda * pa, qb = Q[2 * i + 1] + lambda * pb;
+    Q[2 * i] = qa; Q[2 * i + 1] = qb;
+    v[0] += pa * qa; v[1] += pb * qb; v[2] += pa * qb;
+  }
+  block_sum<3>(v, part);
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg2_update_dev_kernel(int n, double *__restrict__ X, double *__restrict__ R,
+                                                                    const double *__restrict__ P, const double *__restrict__ Q,
+                                                                    double *__restrict__ part, const double *__restrict__ st)
+{
+  if (st[kStDone] != 0.0) return;
+  const double a0 = st[kSt2Alpha], a1 = st[kSt2Alpha + 1], a2 = st[kSt2Alpha + 2], a3 = st[kSt2Alpha + 3];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pa = P[2 * i], pb = P[2 * i + 1], qa = Q[2 * i], qb = Q[2 * i + 1];
+    X[2 * i] += a0 * pa + a1 * pb;
+    X[2 * i + 1] += a2 * pa + a3 * pb;
+    const double ra = R[2 * i] - (a0 * qa + a1 * qb), rb = R[2 * i + 1] - (a2 * qa + a3 * qb);
+    R[2 * i] = ra; R[2 * i + 1] = rb;
+    v[0] += ra * ra; v[1] += rb * rb; v[2] += ra * rb;
+  }
+  block_sum<3>(v, part);
+}
+
+__global__ __launch_bounds__(kRedThreads) void cg2_direction_dev_kernel(int n, double *__restrict__ P, const double *__restrict__ R,
+                                                                       const double *__restrict__ st)
+{
+  if (st[kStDone] != 0.0) return;
+  const double s0 = st[kSt2Psi], s1 = st[kSt2Psi + 1], s2 = st[kSt2Psi + 2], s3 = st[kSt2Psi + 3];
+  for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < n; i += gridDim.x * kRedThreads) {
+    const double pa = P[2 * i], pb = P[2 * i + 1];
+    P[2 * i] = R[2 * i] + s0 * pa + s1 * pb;
+    P[2 * i + 1] = R[2 * i + 1] + s2 * pa + s3 * pb;
+  }
 }
 
 struct Workspace {
@@ -207,6 +349,38 @@ struct Workspace {
     return (double *)p;
   }
   ~Workspace() { for (void *p : bufs) (void)hipFree(p); }
+};
+
+// the host's view of a running solve: {done, iterations} of the two most recent iterations, in pinned memory
+struct Flags {
+  double *h = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int init()
+  {
+    FS_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4));
+    h[0] = h[1] = h[2] = h[3] = 0.0;
+    FS_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    FS_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    return FS_OK;
+  }
+  ~Flags()
+  {
+    if (h) (void)hipHostFree(h);
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+  }
+  // behind iteration `iter`: its flags on their way to the host; then look at the flags of iteration iter - 1 (they arrive
+  // while this iteration runs).  *stop: that iteration had converged -- nothing further needs to be enqueued
+  int after_iteration(int iter, const double *st, hipStream_t s, bool *stop)
+  {
+    FS_HIP(hipMemcpyAsync(h + 2 * (iter & 1), st + kStDone, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+    FS_HIP(hipEventRecord(ev[iter & 1], s));
+    *stop = false;
+    if (iter >= 1) {
+      FS_HIP(hipEventSynchronize(ev[(iter - 1) & 1]));
+      *stop = h[2 * ((iter - 1) & 1)] != 0.0;
+    }
+    return FS_OK;
+  }
 };
 
 // ---- the vector steps of CG as launchers, for callers that bring their own products (fs_dist_cg: the same steps on every
@@ -282,28 +456,30 @@ int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lamb
   Workspace ws;
   double *r = ws.get(F), *p = ws.get(F), *q = ws.get(F), *tmp = ws.get(N), *part = ws.get(kRedBlocks * 3), *red = ws.get(4);
   if (!r || !p || !q || !tmp || !part || !red) { set_error("fs_cg: out of device memory"); return FS_ERR_HIP; }
-  const dim3 g(kRedBlocks), blk(kRedThreads);
-  double h[1];
+  double *st = ws.get(kStDoubles);
+  Flags fl;
+  if (!st) { set_error("fs_cg: out of device memory"); return FS_ERR_HIP; }
+  if (int rc = fl.init()) return rc;
+  const dim3 g(kRedBlocks), blk(kRedThreads), one(1);
   hipLaunchKernelGGL(cg_init_kernel, g, blk, 0, s, F, b, x, r, p, part);
-  if (int rc = reduce_to_host<1>(part, red, h, s)) return rc;
-  double rsq_old = h[0];
-  const double stop = tol * sqrt(rsq_old);
-  int iter;
-  for (iter = 0; iter < F; iter++) {
+  hipLaunchKernelGGL((final_step_kernel<1, 0>), one, blk, 0, s, part, kRedBlocks, red, st, tol);
+  for (int iter = 0; iter < F; iter++) {
     if (int rc = fs_spmv(A, tmp, p, stream)) return rc;
     if (int rc = fs_spmv(At, q, tmp, stream)) return rc;
-    hipLaunchKernelGGL(cg_shift_dot_kernel, g, blk, 0, s, F, lambda, q, p, part);
-    if (int rc = reduce_to_host<1>(part, red, h, s)) return rc;
-    const double alpha = rsq_old / h[0];
-    hipLaunchKernelGGL(cg_update_kernel, g, blk, 0, s, F, alpha, x, r, p, q, part);
-    if (int rc = reduce_to_host<1>(part, red, h, s)) return rc;
-    const double rsq_new = h[0];
-    if (sqrt(rsq_new) <= stop) break;
-    hipLaunchKernelGGL(cg_direction_kernel, g, blk, 0, s, F, rsq_new / rsq_old, p, r);
-    rsq_old = rsq_new;
+    hipLaunchKernelGGL(cg_shift_dot_dev_kernel, g, blk, 0, s, F, lambda, q, p, part, st);
+    hipLaunchKernelGGL((final_step_kernel<1, 1>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // alpha
+    hipLaunchKernelGGL(cg_update_dev_kernel, g, blk, 0, s, F, x, r, p, q, part, st);
+    hipLaunchKernelGGL((final_step_kernel<1, 2>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // converged? beta
+    hipLaunchKernelGGL(cg_direction_dev_kernel, g, blk, 0, s, F, p, r, st);
+    FS_HIP(hipGetLastError());
+    bool stop = false;
+    if (int rc = fl.after_iteration(iter, st, s, &stop)) return rc;
+    if (stop) break;
   }
+  double fin[2] = {0.0, 0.0};
+  FS_HIP(hipMemcpyAsync(fin, st + kStDone, sizeof(fin), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
-  if (out_iter) *out_iter = iter;
+  if (out_iter) *out_iter = (int)fin[1];
   return FS_OK;
 }
 
@@ -330,28 +506,37 @@ int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lam
   if (int rc = reduce_to_host<3>(part, red, h, s)) return rc;
   norms[0] = sqrt(h[0]); norms[1] = sqrt(h[1]);
   hipLaunchKernelGGL(cg2_init_kernel, g, blk, 0, s, F, 1.0 / norms[0], 1.0 / norms[1], B, X, R, P, part);
-  double RtR[3], RtR2[3], PtKP[3], Alpha[4], Psi[4];
+  double RtR[3];
   if (int rc = reduce_to_host<3>(part, red, RtR, s)) return rc;
-  int iter;
-  for (iter = 0; iter < F; iter++) {
+  // from here on the scalars live on the device (see the head of this file)
+  double *st = ws.get(kStDoubles);
+  Flags fl;
+  if (!st) { set_error("fs_cg2: out of device memory"); return FS_ERR_HIP; }
+  if (int rc = fl.init()) return rc;
+  double st0[kStDoubles] = {0.0};
+  st0[kSt2RtR] = RtR[0]; st0[kSt2RtR + 1] = RtR[1]; st0[kSt2RtR + 2] = RtR[2]; st0[kSt2Tolsq] = tolsq;
+  FS_HIP(hipMemcpyAsync(st, st0, sizeof(st0), hipMemcpyHostToDevice, s));
+  FS_HIP(hipStreamSynchronize(s));            // (st0 is on this stack frame)
+  const dim3 one(1);
+  for (int iter = 0; iter < F; iter++) {
     if (int rc = fs_spmm(A, tmp, P, 2, stream)) return rc;
     if (int rc = fs_spmm(At, Q, tmp, 2, stream)) return rc;
-    hipLaunchKernelGGL(cg2_shift_dot_kernel, g, blk, 0, s, F, lambda, Q, P, part);
-    if (int rc = reduce_to_host<3>(part, red, PtKP, s)) return rc;
-    const double rhs[4] = {RtR[0], RtR[2], RtR[2], RtR[1]};
-    solve2sym_host(Alpha, PtKP, rhs);
-    hipLaunchKernelGGL(cg2_update_kernel, g, blk, 0, s, F, Alpha[0], Alpha[1], Alpha[2], Alpha[3], X, R, P, Q, part);
-    if (int rc = reduce_to_host<3>(part, red, RtR2, s)) return rc;
-    if (RtR2[0] <= tolsq && RtR2[1] <= tolsq) break;
-    const double rhs_psi[4] = {RtR2[0], RtR2[2], RtR2[2], RtR2[1]};
-    solve2sym_host(Psi, RtR, rhs_psi);
-    hipLaunchKernelGGL(cg2_direction_kernel, g, blk, 0, s, F, Psi[0], Psi[1], Psi[2], Psi[3], P, R);
-    RtR[0] = RtR2[0]; RtR[1] = RtR2[1]; RtR[2] = RtR2[2];
+    hipLaunchKernelGGL(cg2_shift_dot_dev_kernel, g, blk, 0, s, F, lambda, Q, P, part, st);
+    hipLaunchKernelGGL((final_step_kernel<3, 3>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // Alpha
+    hipLaunchKernelGGL(cg2_update_dev_kernel, g, blk, 0, s, F, X, R, P, Q, part, st);
+    hipLaunchKernelGGL((final_step_kernel<3, 4>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // converged? Psi
+    hipLaunchKernelGGL(cg2_direction_dev_kernel, g, blk, 0, s, F, P, R, st);
+    FS_HIP(hipGetLastError());
+    bool stop = false;
+    if (int rc = fl.after_iteration(iter, st, s, &stop)) return rc;
+    if (stop) break;
   }
   hipLaunchKernelGGL(cg2_scale_kernel, g, blk, 0, s, F, norms[0], norms[1], X);
   FS_HIP(hipGetLastError());
+  double fin[2] = {0.0, 0.0};
+  FS_HIP(hipMemcpyAsync(fin, st + kStDone, sizeof(fin), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
-  if (out_iter) *out_iter = iter;
+  if (out_iter) *out_iter = (int)fin[1];
   return FS_OK;
 }
 
