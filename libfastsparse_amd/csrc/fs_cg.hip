@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kRedThreads) void cg2_scale_kernel(int n, double n0
 
 // ---- the same steps with their scalars in device memory (fs_cg / fs_cg2) ---------------------------------
 // state of one solve, doubles.  One right-hand side: rsq_old, alpha, beta, stop; two: RtR[3], Alpha[4], Psi[4], tolsq
-enum { kStDone = 0, kStIter = 1, kStRsq = 2, kStAlpha = 3, kStBeta = 4, kStStop = 5,
-       kSt2RtR = 2, kSt2Alpha = 5, kSt2Psi = 9, kSt2Tolsq = 13, kStDoubles = 16 };
+enum { kStDone = kCgStateDone, kStIter = kCgStateIter, kStRsq = 2, kStAlpha = 3, kStBeta = 4, kStStop = 5,
+       kSt2RtR = 2, kSt2Alpha = 5, kSt2Psi = 9, kSt2Tolsq = 13, kStDoubles = kCgStateDoubles };
 
 __device__ __forceinline__ void solve2sym_dev(double *X, const double *A, const double *RHS)  // linalg.h:77-88
 {
@@ -351,68 +351,56 @@ struct Workspace {
   ~Workspace() { for (void *p : bufs) (void)hipFree(p); }
 };
 
-// the host's view of a running solve: {done, iterations} of the two most recent iterations, in pinned memory
-struct Flags {
-  double *h = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  int init()
-  {
-    FS_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4));
-    h[0] = h[1] = h[2] = h[3] = 0.0;
-    FS_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    FS_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    return FS_OK;
-  }
-  ~Flags()
-  {
-    if (h) (void)hipHostFree(h);
-    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-  }
-  // behind iteration `iter`: its flags on their way to the host; then look at the flags of iteration iter - 1 (they arrive
-  // while this iteration runs).  *stop: that iteration had converged -- nothing further needs to be enqueued
-  int after_iteration(int iter, const double *st, hipStream_t s, bool *stop)
-  {
-    FS_HIP(hipMemcpyAsync(h + 2 * (iter & 1), st + kStDone, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
-    FS_HIP(hipEventRecord(ev[iter & 1], s));
-    *stop = false;
-    if (iter >= 1) {
-      FS_HIP(hipEventSynchronize(ev[(iter - 1) & 1]));
-      *stop = h[2 * ((iter - 1) & 1)] != 0.0;
-    }
-    return FS_OK;
-  }
-};
-
-// ---- the vector steps of CG as launchers, for callers that bring their own products (fs_dist_cg: the same steps on every
-// device of a row-sharded matrix).  part: kCgPartDoubles doubles of scratch, red: 1 double; each leaves its reduced value in red[0].
-int cg_step_init(int n, const double *b, double *x, double *r, double *p, double *part, double *red, hipStream_t s)
+// ---- the vector steps of CG as launchers, for callers that bring their own products (fs_dist_cg: the same steps, replicated,
+// on every device of a row-sharded matrix -- same kernels on the same data, so every device takes the same decisions).
+// part: kCgPartDoubles doubles of scratch, red: 4 doubles, st: kCgStateDoubles doubles (st[kCgStateDone], st[kCgStateIter]).
+int cg_dev_init(int n, const double *b, double *x, double *r, double *p, double *part, double *red, double *st, double tol,
+                hipStream_t s)
 {
   hipLaunchKernelGGL(cg_init_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, b, x, r, p, part);
-  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red);
+  hipLaunchKernelGGL((final_step_kernel<1, 0>), dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red, st, tol);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
-int cg_step_shift_dot(int n, double lambda, double *q, const double *p, double *part, double *red, hipStream_t s)
+// behind q = A'(A p): q += lambda p, alpha, x and r, the convergence test and beta, the new p -- all on the device
+int cg_dev_steps(int n, double lambda, double *x, double *r, double *p, double *q, double *part, double *red, double *st,
+                 hipStream_t s)
 {
-  hipLaunchKernelGGL(cg_shift_dot_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, lambda, q, p, part);
-  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red);
+  const dim3 g(kRedBlocks), blk(kRedThreads), one(1);
+  hipLaunchKernelGGL(cg_shift_dot_dev_kernel, g, blk, 0, s, n, lambda, q, p, part, st);
+  hipLaunchKernelGGL((final_step_kernel<1, 1>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // alpha
+  hipLaunchKernelGGL(cg_update_dev_kernel, g, blk, 0, s, n, x, r, p, q, part, st);
+  hipLaunchKernelGGL((final_step_kernel<1, 2>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // converged? beta
+  hipLaunchKernelGGL(cg_direction_dev_kernel, g, blk, 0, s, n, p, r, st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
-int cg_step_update(int n, double alpha, double *x, double *r, const double *p, const double *q, double *part, double *red, hipStream_t s)
+int CgFlags::init()
 {
-  hipLaunchKernelGGL(cg_update_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, alpha, x, r, p, q, part);
-  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red);
-  FS_HIP(hipGetLastError());
+  FS_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4));
+  h[0] = h[1] = h[2] = h[3] = 0.0;
+  FS_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  FS_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
   return FS_OK;
 }
 
-int cg_step_direction(int n, double beta, double *p, const double *r, hipStream_t s)
+CgFlags::~CgFlags()
 {
-  hipLaunchKernelGGL(cg_direction_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, beta, p, r);
-  FS_HIP(hipGetLastError());
+  if (h) (void)hipHostFree(h);
+  for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+}
+
+int CgFlags::after_iteration(int iter, const double *st, hipStream_t s, bool *stop)
+{
+  FS_HIP(hipMemcpyAsync(h + 2 * (iter & 1), st + kCgStateDone, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+  FS_HIP(hipEventRecord(ev[iter & 1], s));
+  *stop = false;
+  if (iter >= 1) {
+    FS_HIP(hipEventSynchronize(ev[(iter - 1) & 1]));
+    *stop = h[2 * ((iter - 1) & 1)] != 0.0;
+  }
   return FS_OK;
 }
 
@@ -457,21 +445,14 @@ int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lamb
   double *r = ws.get(F), *p = ws.get(F), *q = ws.get(F), *tmp = ws.get(N), *part = ws.get(kRedBlocks * 3), *red = ws.get(4);
   if (!r || !p || !q || !tmp || !part || !red) { set_error("fs_cg: out of device memory"); return FS_ERR_HIP; }
   double *st = ws.get(kStDoubles);
-  Flags fl;
+  CgFlags fl;
   if (!st) { set_error("fs_cg: out of device memory"); return FS_ERR_HIP; }
   if (int rc = fl.init()) return rc;
-  const dim3 g(kRedBlocks), blk(kRedThreads), one(1);
-  hipLaunchKernelGGL(cg_init_kernel, g, blk, 0, s, F, b, x, r, p, part);
-  hipLaunchKernelGGL((final_step_kernel<1, 0>), one, blk, 0, s, part, kRedBlocks, red, st, tol);
+  if (int rc = cg_dev_init(F, b, x, r, p, part, red, st, tol, s)) return rc;
   for (int iter = 0; iter < F; iter++) {
     if (int rc = fs_spmv(A, tmp, p, stream)) return rc;
     if (int rc = fs_spmv(At, q, tmp, stream)) return rc;
-    hipLaunchKernelGGL(cg_shift_dot_dev_kernel, g, blk, 0, s, F, lambda, q, p, part, st);
-    hipLaunchKernelGGL((final_step_kernel<1, 1>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // alpha
-    hipLaunchKernelGGL(cg_update_dev_kernel, g, blk, 0, s, F, x, r, p, q, part, st);
-    hipLaunchKernelGGL((final_step_kernel<1, 2>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // converged? beta
-    hipLaunchKernelGGL(cg_direction_dev_kernel, g, blk, 0, s, F, p, r, st);
-    FS_HIP(hipGetLastError());
+    if (int rc = cg_dev_steps(F, lambda, x, r, p, q, part, red, st, s)) return rc;
     bool stop = false;
     if (int rc = fl.after_iteration(iter, st, s, &stop)) return rc;
     if (stop) break;
@@ -510,7 +491,7 @@ int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lam
   if (int rc = reduce_to_host<3>(part, red, RtR, s)) return rc;
   // from here on the scalars live on the device (see the head of this file)
   double *st = ws.get(kStDoubles);
-  Flags fl;
+  CgFlags fl;
   if (!st) { set_error("fs_cg2: out of device memory"); return FS_ERR_HIP; }
   if (int rc = fl.init()) return rc;
   double st0[kStDoubles] = {0.0};

@@ -300,11 +300,21 @@ int last_host_path();
 
 // ---- the vector steps of CG (fs_cg.hip) for callers with their own products; every step leaves its dot / norm in red[0]
 constexpr int kCgPartDoubles = 3 * 1024;
-int cg_step_init(int n, const double *b, double *x, double *r, double *p, double *part, double *red, hipStream_t s);       // x = 0, r = p = b; b.b
-int cg_step_shift_dot(int n, double lambda, double *q, const double *p, double *part, double *red, hipStream_t s);          // q += lambda p; q.p
-int cg_step_update(int n, double alpha, double *x, double *r, const double *p, const double *q, double *part, double *red,
-                   hipStream_t s);                                                                                            // x += a p, r -= a q; r.r
-int cg_step_direction(int n, double beta, double *p, const double *r, hipStream_t s);                                        // p = r + beta p
+constexpr int kCgStateDoubles = 16, kCgStateDone = 0, kCgStateIter = 1;   // device state of a solve: st[done], st[iterations], scalars
+int cg_dev_init(int n, const double *b, double *x, double *r, double *p, double *part, double *red, double *st, double tol,
+                hipStream_t s);                                                // x = 0, r = p = b; b.b, the stopping threshold
+int cg_dev_steps(int n, double lambda, double *x, double *r, double *p, double *q, double *part, double *red, double *st,
+                 hipStream_t s);                                               // everything of an iteration behind q = A'(A p)
+// the host's view of a running solve: {done, iterations} of the two most recent iterations, in pinned memory
+struct CgFlags {
+  double *h = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int init();
+  ~CgFlags();
+  // behind iteration `iter`: its flags on their way to the host; then a look at the flags of iteration iter - 1 (they arrive
+  // while this iteration runs).  *stop: that iteration had converged -- nothing further needs to be enqueued
+  int after_iteration(int iter, const double *st, hipStream_t s, bool *stop);
+};
 
 // ---- format work implemented in fs_format.hip --------------------------------------------
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled = true);

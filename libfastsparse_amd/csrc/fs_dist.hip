@@ -639,17 +639,17 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
   const int n = D->n, F = M->ncol;
   struct Work {
     fs_dist_t D;
-    std::vector<double *> sol, r, b, part, red;
+    std::vector<double *> sol, r, b, part, red, st;
     ~Work()
     {
       for (size_t d = 0; d < sol.size(); ++d) {
         (void)hipSetDevice(D->dev[d]);
-        for (double *p : {sol[d], r[d], b[d], part[d], red[d]})
+        for (double *p : {sol[d], r[d], b[d], part[d], red[d], st[d]})
           if (p) (void)hipFree(p);
       }
     }
   } W{D, std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr),
-      std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr)};
+      std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr)};
   for (int d = 0; d < n; ++d) {
     FS_HIP(hipSetDevice(D->dev[d]));
     FS_HIP(hipMalloc(&W.sol[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
@@ -657,46 +657,37 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
     FS_HIP(hipMalloc(&W.b[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
     FS_HIP(hipMalloc(&W.part[(size_t)d], sizeof(double) * fs::kCgPartDoubles));
     FS_HIP(hipMalloc(&W.red[(size_t)d], sizeof(double) * 4));
+    FS_HIP(hipMalloc(&W.st[(size_t)d], sizeof(double) * fs::kCgStateDoubles));
   }
   if (int rc = upload_all(M, W.b, b_host, (size_t)F)) return rc;
-  auto reduced = [&](double *out) -> int {     // the value every device just reduced, from device 0
-    FS_HIP(hipSetDevice(D->dev[0]));
-    FS_HIP(hipMemcpyAsync(out, W.red[0], sizeof(double), hipMemcpyDeviceToHost, D->stream[0]));
-    FS_HIP(hipStreamSynchronize(D->stream[0]));
-    return FS_OK;
-  };
+  // the scalars of the iteration stay on every device (the same kernels on the same data: every device decides alike); the
+  // host watches device 0's done flag one iteration behind (see fs_cg.hip)
+  fs::CgFlags fl;
+  FS_HIP(hipSetDevice(D->dev[0]));
+  if (int rc = fl.init()) return rc;
   for (int d = 0; d < n; ++d) {
     FS_HIP(hipSetDevice(D->dev[d]));
-    if (int rc = fs::cg_step_init(F, W.b[(size_t)d], W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d], D->stream[d])) return rc;
+    if (int rc = fs::cg_dev_init(F, W.b[(size_t)d], W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d],
+                                 W.st[(size_t)d], tol, D->stream[d])) return rc;
   }
-  double rsq_old = 0.0;
-  if (int rc = reduced(&rsq_old)) return rc;
-  const double stop = tol * sqrt(rsq_old);
-  int iter;
-  for (iter = 0; iter < F; iter++) {
+  for (int iter = 0; iter < F; iter++) {
     if (int rc = dist_product(D, M->a, M->x, M->y)) return rc;      // y = A p
     if (int rc = dist_product(D, M->t, M->y, M->z)) return rc;      // q = A' y
     for (int d = 0; d < n; ++d) {
       FS_HIP(hipSetDevice(D->dev[d]));
-      if (int rc = fs::cg_step_shift_dot(F, lambda, M->z[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d], D->stream[d])) return rc;
+      if (int rc = fs::cg_dev_steps(F, lambda, W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], M->z[(size_t)d], W.part[(size_t)d],
+                                    W.red[(size_t)d], W.st[(size_t)d], D->stream[d])) return rc;
     }
-    double pq = 0.0;
-    if (int rc = reduced(&pq)) return rc;
-    const double alpha = rsq_old / pq;
-    for (int d = 0; d < n; ++d) {
-      FS_HIP(hipSetDevice(D->dev[d]));
-      if (int rc = fs::cg_step_update(F, alpha, W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], M->z[(size_t)d], W.part[(size_t)d], W.red[(size_t)d],
-                                      D->stream[d])) return rc;
-    }
-    double rsq_new = 0.0;
-    if (int rc = reduced(&rsq_new)) return rc;
-    if (sqrt(rsq_new) <= stop) break;
-    for (int d = 0; d < n; ++d) {
-      FS_HIP(hipSetDevice(D->dev[d]));
-      if (int rc = fs::cg_step_direction(F, rsq_new / rsq_old, M->x[(size_t)d], W.r[(size_t)d], D->stream[d])) return rc;
-    }
-    rsq_old = rsq_new;
+    bool stop = false;
+    FS_HIP(hipSetDevice(D->dev[0]));
+    if (int rc = fl.after_iteration(iter, W.st[0], D->stream[0], &stop)) return rc;
+    if (stop) break;
   }
+  double fin[2] = {0.0, 0.0};
+  FS_HIP(hipSetDevice(D->dev[0]));
+  FS_HIP(hipMemcpyAsync(fin, W.st[0] + fs::kCgStateDone, sizeof(fin), hipMemcpyDeviceToHost, D->stream[0]));
+  FS_HIP(hipStreamSynchronize(D->stream[0]));
+  const int iter = (int)fin[1];
   if (int rc = download_from(M, 0, x_host, W.sol[0], (size_t)F)) return rc;
   if (int rc = dist_sync(D)) return rc;
   if (out_iter) *out_iter = iter;
