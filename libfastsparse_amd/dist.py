@@ -500,8 +500,14 @@ class ShardedCG:
         def red(t):
             return [float(v) for v in (self._sum(t) if gather else t).cpu()]
 
-        rr = red(self._dots(r, r, n))
-        stop = tol * (rr[0] ** 0.5) if k == 1 else tol * tol
+        if k == 1:
+            rr_t = self._dots(r, r, n)
+            rr_t = self._sum(rr_t) if gather else rr_t
+            stop_t = tol * rr_t.sqrt()
+            rr = None
+        else:
+            rr = red(self._dots(r, r, n))
+        stop = tol * tol
         q = torch.empty(n * k, dtype=dt, device=dev)
         q_gather_buf = None
         it = 0
@@ -524,13 +530,21 @@ class ShardedCG:
                 op_t.reduce(q)
             q.add_(p, alpha=lam)
             if k == 1:
-                alpha = rr[0] / red(self._dots(p, q, n))[0]
-                x.add_(p, alpha=alpha)
-                r.add_(q, alpha=-alpha)
-                rr2 = red(self._dots(r, r, n))
-                if rr2[0] ** 0.5 <= stop:
+                # the scalars stay where the vectors are (device tensors with RCCL): alpha and beta are never fetched, the
+                # one host round trip of an iteration is the convergence test
+                pq = self._dots(p, q, n)
+                pq = self._sum(pq) if gather else pq
+                alpha = rr_t / pq
+                x.addcmul_(p, alpha)
+                r.addcmul_(q, -alpha)
+                rr2_t = self._dots(r, r, n)
+                rr2_t = self._sum(rr2_t) if gather else rr2_t
+                if bool((rr2_t.sqrt() <= stop_t).item()):
                     break
-                p.mul_(rr2[0] / rr[0]).add_(r)
+                p.mul_(rr2_t / rr_t).add_(r)
+                rr_t = rr2_t
+                it += 1
+                continue
             else:
                 ptkp = red(self._dots(p, q, n))
                 al = self._solve2sym(ptkp, [rr[0], rr[2], rr[2], rr[1]])
