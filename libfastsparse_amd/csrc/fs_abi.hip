@@ -29,6 +29,9 @@ Options &options()
     if (const char *v = getenv("FS_TILE_COLS")) q.tile_cols = atoi(v);
     if (const char *v = getenv("FS_LONG_ROWS")) q.long_rows = atoi(v);
     if (const char *v = getenv("FS_LONG_GEOMETRY")) q.long_geometry = atoi(v);
+    if (const char *v = getenv("FS_REPRODUCIBLE")) q.reproducible = atoi(v);     // drop-in callers: fixed-order sums without a code change
+    if (const char *v = getenv("FS_STRICT_ORDER")) q.strict_order = atoi(v);     //                  the reference's own order of additions
+    if (const char *v = getenv("FS_SPMM_WIDE")) q.spmm_wide = atoi(v);
     return q;
   }();
   return o;
