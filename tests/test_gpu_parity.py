@@ -954,6 +954,45 @@ def test_spmm_matrix_core_experiment(hip, k):
         capi.set_option("spmm_kernel", 0)
 
 
+@pytest.mark.parametrize("shape", [(300_000, 300_000, 16, True), (400_000, 60_000, 64, False), (30_000, 30_000, 8, True)])
+def test_products_can_be_captured_in_a_hip_graph_and_replayed(hip, shape):
+    """fs_spmv / fs_spmv_t only launch (no allocation, no wait, no host-side state that a replay would miss), so a caller may
+    capture them on its stream into a HIP graph and replay it: y = A x, z = A' y captured once, replayed on fresh outputs,
+    against the eager products (same kernels, same order: bit-identical for the pattern-only case, to rounding of the atomic
+    order otherwise).  (tools/graph_probe.py times eager against replay: no gain on this runtime, 31 vs 35 us for a pair of
+    small products -- so the library itself does not use graphs.)"""
+    import torch
+    from libfastsparse_amd import capi
+    n, m, per, valued = shape
+    rp, cc, vv = capi.synth_uniform(n, m, per, 21, valued=valued)
+    A = capi.Matrix.from_csr(n, m, rp, cc, vv, borrow=True)
+    A.build_transpose(capi.current_stream())
+    x = ((torch.arange(m, device="cuda") % 13) - 6).to(torch.float64) if not valued else torch.sin(torch.arange(m, device="cuda", dtype=torch.float64))
+    y, z = torch.empty(n, device="cuda", dtype=torch.float64), torch.empty(m, device="cuda", dtype=torch.float64)
+    yref, zref = torch.empty_like(y), torch.empty_like(z)
+    A.spmv(yref, x, capi.current_stream())
+    A.spmv(zref, yref, capi.current_stream(), transposed=True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        A.spmv(y, x, capi.current_stream())
+        A.spmv(z, y, capi.current_stream(), transposed=True)
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            A.spmv(y, x, capi.current_stream())
+            A.spmv(z, y, capi.current_stream(), transposed=True)
+    for _ in range(2):
+        y.fill_(-1.0)
+        z.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        if valued:
+            assert torch.allclose(y, yref, rtol=0, atol=1e-11 * per) and torch.allclose(z, zref, rtol=1e-12, atol=1e-9)
+        else:
+            assert torch.equal(y, yref) and torch.equal(z, zref)
+
+
 def test_lds_staged_panels_are_cut_to_equal_heights(hip):
     """Few rows, many columns (the shape of config 3 transposed): the LDS-staged copy takes full-height panels and cuts them
     into chunks.  Every panel sweeps every band whatever it holds, so a remainder panel of a few hundred rows costs as many
