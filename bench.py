@@ -694,8 +694,9 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     if out is not None:
         out["y"], out["z"], out["bounds"], out["z_scheme"] = y, z, bounds, z_scheme
 
-    # what fixed-order sums would cost: the same matrix created under "reproducible" keeps a kernel whose
-    # additions have a fixed order (the two-pass kernels add a row's terms of one band with LDS atomics in arrival order)
+    # what fixed-order sums cost: the same matrix created under "reproducible" keeps a kernel whose additions
+    # have a fixed order -- since round 3 the two-pass pair itself with a pass 2 that walks a panel's products in stream order, one
+    # wave per panel (the default pass 2 adds with sixteen waves in arrival order)
     repro = None
     if not _multi(world) and hasattr(prov, "capi") and not args.no_reproducible_cost:
         try:

@@ -1498,7 +1498,9 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   const int bcols = big ? kBinColsBig : kBinCols / kw;   // columns per band: kw * 8 bytes of X per column in LDS
   const int rmax = big ? kBinRowsBig : kBinRowsMax / kw; // rows per panel: kw * 8 bytes of Y per row in LDS
   const int ge = kBinGroup / kw;       // entries per group: a group of products is one 128-byte line
-  if (o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz == 0) return FS_OK;
+  // ("reproducible": the single-vector copy stays in the race -- its pass 2 then adds in stream order, one wave per panel; the
+  // k-column copies add in arrival order and are not built)
+  if (o.binning == 0 || (o.reproducible && kw != 1) || A.nrow == 0 || A.nnz == 0) return FS_OK;
   // (measured on 10 M x 10 M x 16: 0.75 ms against 1.06 ms tiled and 2.99 ms streaming; the two passes move
   // 20.5 bytes per entry at stream speed whatever the size of x, so the copy pays once the matrix is large
   // enough to fill the chip)
@@ -1656,7 +1658,8 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
 // The estimates in the builders only weed out hopeless candidates.  Between the survivors (and the chunk-streaming
 // kernel, which needs no copy) the choice is measured: every candidate runs the product on a zero vector -- same
 // addresses and traffic as any x -- and the fastest keeps its copy; the others are released.  (Callers who need
-// sums that are bit-identical from run to run set "reproducible", which takes the two-pass copy out of the race.)
+// sums that are bit-identical from run to run set "reproducible": the LDS-staged copy leaves the race and the two-pass copy is
+// timed with its ordered pass 2.)
 template <typename F>
 static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *median)
 {

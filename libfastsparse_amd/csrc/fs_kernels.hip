@@ -1398,6 +1398,64 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
   reduce_panel<NTLD>(ytile, pbase + blockIdx.x, bin_ptr, panel_row, lrow, prod, y, ys);
 }
 
+// pass 2 with a FIXED order of additions: ONE wave per panel walks the panel's products in stream order, 512 entries per step
+// (eight per lane, as above).  A wave's LDS instructions execute in program order, so every y slot receives its addends in the
+// order of the stream (band by band, inside a band in CSR order; lanes of one instruction that hit the same slot are
+// serialised by the LDS in a fixed order): the result is bit-identical run to run, which the sixteen-wave kernel above -- whose
+// waves add into the same slots concurrently -- is not.  One wave can do it because the pass is a stream: DEPTH steps of loads
+// (80 bytes per lane each) stay in flight in registers, and eight ds_add_f64 per 512 entries are far below what one wave may
+// issue.
+#ifndef FS_ORDERED_DEPTH
+#define FS_ORDERED_DEPTH 16   // steps of loads in flight (config 2: 4 / 6 / 8 / 12 / 16 / 20 -> +13 / +7 / +6 / +4.3 / +3.5 / +3 % over the 16-wave pass)
+#endif
+template <bool NTLD, int RM, int DEPTH>
+__global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
+    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
+    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
+{
+  __shared__ __attribute__((aligned(16))) double ytile[RM];
+  const int t = threadIdx.x;
+  const int panel = pbase + blockIdx.x;
+  const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
+  for (int i = 2 * t; i < nr; i += 128) *reinterpret_cast<v2d *>(&ytile[i]) = v2d{0.0, 0.0};   // (RM is even: a pair past nr stays inside)
+  const int64_t e0 = (int64_t)bin_ptr[panel] * kBinGroup, e1 = (int64_t)bin_ptr[panel + 1] * kBinGroup;
+#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FS_ADD8(A, P)                                                  \
+  FS_ADD(A.x & 0xffffu, P[0].x); FS_ADD(A.x >> 16, P[0].y);            \
+  FS_ADD(A.y & 0xffffu, P[1].x); FS_ADD(A.y >> 16, P[1].y);            \
+  FS_ADD(A.z & 0xffffu, P[2].x); FS_ADD(A.z >> 16, P[2].y);            \
+  FS_ADD(A.w & 0xffffu, P[3].x); FS_ADD(A.w >> 16, P[3].y);
+  constexpr int64_t kStep = 8 * 64;
+  v4u a[DEPTH];
+  v2d p[DEPTH][4];
+  // steps past the end re-read the segment's last eight entries (their adds are skipped): every load is unconditional
+  auto fetch = [&](int k, int64_t e) {
+    const int64_t ec = (e + 8 <= e1) ? e : (e1 - e0 >= 8 ? e1 - 8 : e0);
+    a[k] = stream_load<NTLD>((const v4u *)(lrow + ec));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ec + 2 * j));
+  };
+  if (e1 > e0) {
+    int64_t e = e0 + 8 * t;
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(k, e + (int64_t)k * kStep);
+    for (; e - 8 * t < e1; e += (int64_t)DEPTH * kStep) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        const int64_t ek = e + (int64_t)k * kStep;
+        const v4u ak = a[k];
+        v2d pk[4] = {p[k][0], p[k][1], p[k][2], p[k][3]};
+        fetch(k, ek + (int64_t)DEPTH * kStep);
+        if (ek + 8 <= e1) { FS_ADD8(ak, pk) }
+      }
+    }
+  }
+#undef FS_ADD8
+#undef FS_ADD
+  __syncthreads();
+  for (int i = t; i < nr; i += 64) y[(int64_t)(r0 + i) * ys] = ytile[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // The longest rows of a heavy-tailed matrix in ONE pass (LongRows, fs_common.h): persistent workgroups stream equal shares of
 // the (band, long row)-ordered entries; the band of x (128 KiB) AND one accumulator per long row (<= 24 KiB) sit in LDS.
@@ -1845,9 +1903,17 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   if (N.lr && p0 == 0)          // behind pass 1, in front of pass 2: HBM-bound like both
     if (int rc = launch_longrows(A, *N.lr, x, xs, s)) return rc;
   if (p1 > p0) {
-    if (N.bcols == kBinColsBig)
+    // "reproducible" (or bit 5 of bin_flags): one wave per panel, additions in stream order, bit-identical run to run
+    const bool ordered = options().reproducible || (options().bin_flags & 32);
+    if (N.bcols == kBinColsBig && ordered)
+      hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsBig, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
+                         N.panel_row, N.lrow, N.prod, out, os, p0);
+    else if (N.bcols == kBinColsBig)
       hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row,
                          N.lrow, N.prod, out, os, p0);
+    else if (ordered)
+      hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsMax, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
+                         N.panel_row, N.lrow, N.prod, out, os, p0);
     else if (options().bin_flags & 4)
       hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
                          out, os, p0);
@@ -2059,10 +2125,13 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
 
 // which kernel a single-vector product on A runs under the options o: 7 two-pass, 8 LDS-staged, 6 L2-tiled, 2 lanes per
 // row, 1 chunk-streaming.  The copy the format builder kept unless the caller asked for storage-order (strict_order) or
-// run-to-run identical (reproducible) sums, which the kernels that add in arrival order cannot give.
+// run-to-run identical (reproducible) sums, which the kernels that add in arrival order cannot give (LDS-staged; the k-column
+// sweeps; the long-row path).
 int spmv_choice(const DeviceCsr &A, const Options &o)
 {
-  if (A.binned && A.binned->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
+  // (the two-pass pair under "reproducible": its pass 2 then runs one wave per panel in stream order -- not with the long-row side
+  // path, whose waves add in arrival order)
+  if (A.binned && A.binned->built && !o.strict_order && (!o.reproducible || !A.binned->lr) && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
   if (A.tiledx && A.tiledx->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
   if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
   return o.spmv_kernel == 2 ? 2 : 1;

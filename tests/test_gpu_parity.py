@@ -634,8 +634,11 @@ def test_two_pass_on_thousands_of_bands(hip):
 
 
 def test_reproducible_option_and_tuning_switches(hip):
-    """`reproducible` keeps the format builder off the two-pass copy and repeated runs are then bit-identical;
-    the pass-1 unroll switches of the two-pass kernels change nothing but speed (pattern-only + integer x: exact)"""
+    """`reproducible`: the two-pass copy stays, its pass 2 then runs ONE wave per panel that adds in stream order
+    (spmv_reduce_ordered_kernel), and repeated runs are bit-identical (the sixteen-wave pass 2 adds in arrival order: its
+    bits may differ from run to run and from the ordered ones -- both within the rounding bar of the oracle); the option may be
+    switched on after the matrix was created; the pass-1 unroll switches of the two-pass kernels change nothing but speed
+    (pattern-only + integer x: exact)"""
     import torch
     from libfastsparse_amd import capi
     nrow, ncol, per = 600_000, 5_000_000, 16
@@ -644,13 +647,23 @@ def test_reproducible_option_and_tuning_switches(hip):
     y1 = torch.empty(nrow, dtype=torch.float64, device="cuda")
     y2 = torch.empty_like(y1)
     capi.set_option("reproducible", 1)
-    capi.set_option("binning", 2)          # even when asked for, the two-pass copy is not built under `reproducible`
+    capi.set_option("binning", 2)
     try:
         A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
-        assert A.kernel_name() in ("tiled", "stream")
+        assert A.kernel_name() == "two-pass"
         A.spmv(y1, x, capi.current_stream())
+        for _ in range(5):
+            y2.fill_(-1.0)
+            A.spmv(y2, x, capi.current_stream())
+            assert torch.equal(y1, y2)
+        rpn, ccn, vvn = rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy()
+        ref = O.csr_mul(nrow, rpn, ccn, vvn, S.x_sin(ncol))
+        sc = O.csr_abs_scale(nrow, rpn, ccn, vvn, S.x_sin(ncol))
+        assert np.all(np.abs(y1.cpu().numpy() - ref) <= TOL * np.maximum(sc, 1e-300))
+        # the same handle without the option: the sixteen-wave pass 2, same sums to rounding
+        capi.set_option("reproducible", 0)
         A.spmv(y2, x, capi.current_stream())
-        assert torch.equal(y1, y2)
+        assert np.all(np.abs(y2.cpu().numpy() - ref) <= TOL * np.maximum(sc, 1e-300))
         del A
     finally:
         capi.set_option("reproducible", 0)
@@ -665,12 +678,18 @@ def test_reproducible_option_and_tuning_switches(hip):
             capi.set_option("bin_flags", flags)
             P.spmv(y2, xi, capi.current_stream())
             assert torch.equal(y1, y2), flags
-        # with `reproducible` switched on later, an existing two-pass copy is bypassed (streaming kernel)
+        # `reproducible` switched on later: the existing two-pass copy stays in use, with the ordered pass 2
         capi.set_option("bin_flags", 0)
         capi.set_option("reproducible", 1)
-        assert P.kernel_name() == "stream"
+        assert P.kernel_name() == "two-pass"
         P.spmv(y2, xi, capi.current_stream())
         assert torch.equal(y1, y2)
+        # and in parts (pass 2 by ranges of panels)
+        if sum(b > a for a, b in zip(P.part_rows(3), P.part_rows(3)[1:])) >= 2:
+            y2.fill_(-1.0)
+            for part in range(3):
+                P.spmv_part(y2, xi, part, 3, capi.current_stream())
+            assert torch.equal(y1, y2)
     finally:
         capi.set_option("bin_flags", 0)
         capi.set_option("binning", 1)
