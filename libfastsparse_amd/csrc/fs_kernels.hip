@@ -1731,6 +1731,63 @@ __global__ __launch_bounds__(kBinBlock) void spmm_reduce_kernel(
   for (int i = t; i < nr * K; i += kBinBlock) Y[(int64_t)(r0 + i / K) * ys + (i % K)] = ytile[i];
 }
 
+// the same pass with a fixed order of additions: one wave per panel, stream order (see spmv_reduce_ordered_kernel)
+template <int K, int DEPTH>
+__global__ __launch_bounds__(64) void spmm_reduce_ordered_kernel(
+    const unsigned *__restrict__ bin_ptr_all, const int *__restrict__ panel_row_all, const uint16_t *__restrict__ lrow,
+    const double *__restrict__ prod, double *__restrict__ Y, int ys, int pbase)
+{
+  const unsigned *__restrict__ bin_ptr = bin_ptr_all + pbase;
+  const int *__restrict__ panel_row = panel_row_all + pbase;
+  constexpr int GE = kBinGroup / K;
+  constexpr int EPL = 8 / K;             // entries per lane and step: 64 bytes of products
+  __shared__ double ytile[kBinRowsMax];  // [rows of the panel][K]
+  const int t = threadIdx.x;
+  const int r0 = panel_row[blockIdx.x], nr = panel_row[blockIdx.x + 1] - r0;
+  for (int i = t; i < nr * K; i += 64) ytile[i] = 0.0;
+  const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * GE, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * GE;
+  typedef uint16_t rows_t __attribute__((ext_vector_type(EPL)));
+#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+  auto add8 = [&](const rows_t a, const v2d (&p)[4]) {
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+      const int base = (int)a[q] * K;
+#pragma unroll
+      for (int j = 0; j < K; j += 2) {
+        FS_ADD(base + j, p[(q * K + j) / 2].x);
+        FS_ADD(base + j + 1, p[(q * K + j) / 2].y);
+      }
+    }
+  };
+  constexpr int64_t kStep = (int64_t)EPL * 64;
+  rows_t a[DEPTH];
+  v2d p[DEPTH][4];
+  auto fetch = [&](int k, int64_t e) {   // steps past the end re-read the segment's last entries (their adds are skipped)
+    const int64_t ec = (e + EPL <= e1) ? e : (e1 - e0 >= EPL ? e1 - EPL : e0);
+    a[k] = *reinterpret_cast<const rows_t *>(lrow + ec);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[k][j] = *reinterpret_cast<const v2d *>(prod + ec * K + 2 * j);
+  };
+  if (e1 > e0) {
+    int64_t e = e0 + (int64_t)EPL * t;
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(k, e + (int64_t)k * kStep);
+    for (; e - EPL * t < e1; e += (int64_t)DEPTH * kStep) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        const int64_t ek = e + (int64_t)k * kStep;
+        const rows_t ak = a[k];
+        const v2d pk[4] = {p[k][0], p[k][1], p[k][2], p[k][3]};
+        fetch(k, ek + (int64_t)DEPTH * kStep);
+        if (ek + EPL <= e1) add8(ak, pk);
+      }
+    }
+  }
+#undef FS_ADD
+  __syncthreads();
+  for (int i = t; i < nr * K; i += 64) Y[(int64_t)(r0 + i / K) * ys + (i % K)] = ytile[i];
+}
+
 // Y[r, 0:K] = sum of the virtual rows of row r, in storage order (yv holds K doubles per virtual row)
 template <int K>
 __global__ __launch_bounds__(kBlock) void tiled_combine_k_kernel(int nrow, const int *__restrict__ vfirst,
@@ -2066,7 +2123,12 @@ int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const 
   }
 #undef FS_XP
   if (p1 > p0) {
-    if (K == 2)
+    const bool ordered = options().reproducible || (options().bin_flags & 32);   // one wave per panel, stream order
+    if (K == 2 && ordered)
+      hipLaunchKernelGGL((spmm_reduce_ordered_kernel<2, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
+    else if (ordered)
+      hipLaunchKernelGGL((spmm_reduce_ordered_kernel<4, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
+    else if (K == 2)
       hipLaunchKernelGGL(spmm_reduce_kernel<2>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
     else
       hipLaunchKernelGGL(spmm_reduce_kernel<4>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
@@ -2499,14 +2561,16 @@ int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
 {
   const Options &o = options();
   if (needs_prepare) *needs_prepare = 0;
-  const bool free_order = !o.strict_order && !o.reproducible;   // the two-pass and LDS-staged kernels add in arrival order
+  const bool free_order = !o.strict_order && !o.reproducible;   // the LDS-staged kernels add in arrival order
+  // the two-pass kernels: under "reproducible" their pass 2 runs one wave per panel in stream order -- not the long-row side path
+  const bool bin_order = !o.strict_order && (!o.reproducible || !(A.binned && A.binned->lr));
   const int want = o.spmm_kernel;
   const bool hb = A.binned && A.binned->built, hx = A.tiledx && A.tiledx->built, ht = A.tiled && A.tiled->built;
   const bool bin_ok = o.spmv_kernel == 0 || o.spmv_kernel == 7, ldsx_ok = o.spmv_kernel == 0 || o.spmv_kernel == 8;
   // (the k-column copy only where the format builder kept the two-pass copy for the single-vector product: that is the
   // class of matrices -- large x, thin tiles -- on which streaming products beats gathering; config 3's dense tiles stay
   // on the LDS-staged kernel, two sweeps of 0.9 ms against 36 bytes per entry here)
-  if (free_order && k >= 2 && k <= 4 && (want == 0 || want == 2) && o.binning != 0 && bin_ok && (hb || o.binning == 2 || want == 2)) {
+  if (bin_order && k >= 2 && k <= 4 && (want == 0 || want == 2) && o.binning != 0 && bin_ok && (hb || o.binning == 2 || want == 2)) {
     const BinnedCsr *slot = k == 4 ? A.binned4 : A.binned2;
     const bool tried = k == 4 ? A.tried4 : A.tried2;
     if (slot && slot->built && (k != 3 || hb)) return kPlanBinnedK;
@@ -2514,7 +2578,7 @@ int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
   }
   // column by column on the single-vector pair where that beats the row kernel, whose every X-row gather misses L2 (three
   // sweeps: 3.0 ms on config 2 against 3.8 ms for the row kernel; four: 4.0 against 3.5)
-  if (want != 1 && (k <= 3 || want == 3) && hb && free_order && bin_ok) return kPlanBinnedCols;
+  if (want != 1 && (k <= 3 || want == 3) && hb && bin_order && bin_ok) return kPlanBinnedCols;
   if (want != 1 && want != 4 && k >= 2 && k <= kLdsxSweepMaxK && hx && !hb && free_order && ldsx_ok) {
     if (want != 0 || k == 2) return kPlanLdsxColumns;          // k = 2: the sweeps won every measurement
     if (A.spmm_choice[k] == 0 && needs_prepare) *needs_prepare |= 2;

@@ -660,6 +660,21 @@ def test_reproducible_option_and_tuning_switches(hip):
         ref = O.csr_mul(nrow, rpn, ccn, vvn, S.x_sin(ncol))
         sc = O.csr_abs_scale(nrow, rpn, ccn, vvn, S.x_sin(ncol))
         assert np.all(np.abs(y1.cpu().numpy() - ref) <= TOL * np.maximum(sc, 1e-300))
+        # two and four right-hand sides: the k-column sweep stays too, its pass 2 ordered like the single-vector one
+        for k in (2, 4):
+            A.prepare(k, capi.current_stream())
+            assert A.spmm_plan(k) == "k-column two-pass", A.spmm_plan(k)
+            X = S.X_sin(ncol, k)
+            Y1 = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+            Y2 = torch.full((nrow, k), -2.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y1, torch.from_numpy(X).cuda(), k, capi.current_stream())
+            for _ in range(3):
+                A.spmm(Y2, torch.from_numpy(X).cuda(), k, capi.current_stream())
+                assert torch.equal(Y1, Y2), k
+            refk = O.csr_mul_n(nrow, rpn, ccn, vvn, X, k)
+            for j in range(k):
+                scj = O.csr_abs_scale(nrow, rpn, ccn, vvn, np.ascontiguousarray(X[:, j]))
+                assert np.all(np.abs(Y1.cpu().numpy()[:, j] - refk[:, j]) <= TOL * np.maximum(scj, 1e-300)), (k, j)
         # the same handle without the option: the sixteen-wave pass 2, same sums to rounding
         capi.set_option("reproducible", 0)
         A.spmv(y2, x, capi.current_stream())

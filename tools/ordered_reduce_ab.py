@@ -55,6 +55,15 @@ def main():
         rec["bit_identical_over_6_runs_" + name] = same
         outs[name] = y1
     capi.set_option("bin_flags", 0)
+    for k in (2, 4):                      # the k-column sweeps (block CG lives on k = 2)
+        A.prepare(k, st)
+        X = torch.sin(0.37 * torch.arange(m * k, device="cuda", dtype=torch.float64))
+        Y = torch.empty(n * k, device="cuda", dtype=torch.float64)
+        for name, flags in (("default_16_waves", 0), ("ordered_1_wave", 32)):
+            capi.set_option("bin_flags", flags)
+            rec["ms_spmm_k%d_%s" % (k, name)] = timed(lambda: A.spmm(Y, X, k, st), reps=10)
+        capi.set_option("bin_flags", 0)
+        del X, Y
     rec["max_abs_diff_ordered_vs_default"] = float((outs["ordered_1_wave"] - outs["default_16_waves"]).abs().max())
     print(json.dumps(rec), flush=True)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
