@@ -1396,6 +1396,9 @@ def main():
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run "
                              "--nproc-per-node %d) or drop the launcher and let bench.py start them" % (args.gpus, world, args.gpus))
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's peer mappings fail with
+    # "hipIpcGetMemHandle: invalid argument" (set before anything loads the HIP runtime; a launcher's own value wins)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("FS_BENCH_WATCHDOG"):     # seconds: every rank then dumps its Python stacks to stderr (a hung collective)
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["FS_BENCH_WATCHDOG"]), repeat=False)
