@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--cols", type=int, default=1_000_000)
     ap.add_argument("--per-row", type=int, default=64)
     ap.add_argument("--tiled-flags", type=int, default=0, help="8: the split-role kernel (DMA wave + entry waves)")
+    ap.add_argument("--force-ldsx", action="store_true", help="keep the LDS-staged copy whatever the builder's timing says (ablation builds)")
     ap.add_argument("--out", default="gpurun_out/dma_phase_trace.jsonl")
     a = ap.parse_args()
     L = capi.lib()
@@ -33,13 +34,16 @@ def main():
     st = capi.current_stream()
     capi.set_option("tiled_flags", a.tiled_flags)
     rp, cc, _ = capi.synth_uniform(a.rows, a.cols, a.per_row, 0x5EED0003, valued=False)
+    if a.force_ldsx:
+        for k, v in (("ldsx", 2), ("tiling", 0), ("binning", 0)):
+            capi.set_option(k, v)
     A = capi.Matrix.from_csr(a.rows, a.cols, rp, cc, None, borrow=True)
     x = torch.sin(0.3 * torch.arange(a.cols, device="cuda", dtype=torch.float64))
     y = torch.empty(a.rows, device="cuda", dtype=torch.float64)
     # the kernel under test against the default one of this build on integer-valued x (bit-identical whatever the order of the adds)
     xi = ((torch.arange(a.cols, device="cuda") % 17) - 8).to(torch.float64)
-    capi.set_option("tiled_flags", 0)
     yref = torch.empty_like(y)
+    capi.set_option("tiled_flags", 0)
     A.spmv(yref, xi, st)
     capi.set_option("tiled_flags", a.tiled_flags)
     A.spmv(y, xi, st)
