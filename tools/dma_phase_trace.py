@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--cols", type=int, default=1_000_000)
     ap.add_argument("--per-row", type=int, default=64)
     ap.add_argument("--tiled-flags", type=int, default=0, help="8: the split-role kernel (DMA wave + entry waves)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="panel height override (the four-buffer experiment needs <= 12288)")
     ap.add_argument("--force-ldsx", action="store_true", help="keep the LDS-staged copy whatever the builder's timing says (ablation builds)")
     ap.add_argument("--out", default="gpurun_out/dma_phase_trace.jsonl")
     a = ap.parse_args()
@@ -34,6 +35,7 @@ def main():
     st = capi.current_stream()
     capi.set_option("tiled_flags", a.tiled_flags)
     rp, cc, _ = capi.synth_uniform(a.rows, a.cols, a.per_row, 0x5EED0003, valued=False)
+    capi.set_option("tile_rows", a.tile_rows)
     if a.force_ldsx:
         for k, v in (("ldsx", 2), ("tiling", 0), ("binning", 0)):
             capi.set_option(k, v)
@@ -64,7 +66,7 @@ def main():
         L.fs_debug_dma_trace(out, 0)
     ta, tbc, td, n, wgs = (int(out[i]) for i in range(5))
     extra = [int(out[i]) for i in range(5, 8)]
-    rec = {"what": "dma_phase_trace", "build": os.path.basename(os.environ.get("FS_LIB_PATH", "product")), "tiled_flags": a.tiled_flags, "equals_default_kernel_on_integer_x": same, "kernel": A.kernel_name(),
+    rec = {"what": "dma_phase_trace", "build": os.path.basename(os.environ.get("FS_LIB_PATH", "product")), "tiled_flags": a.tiled_flags, "tile_rows": a.tile_rows, "equals_default_kernel_on_integer_x": same, "kernel": A.kernel_name(),
            "ms_per_product": e0.elapsed_time(e1) / reps, "instrumented": traced,
            "workgroups": wgs // reps, "phases_per_workgroup": n / max(wgs, 1),
            "clocks_per_phase": {"barrier_to_gathers_returned": ta / max(n, 1), "to_issue_done_or_slice_landed": tbc / max(n, 1),
