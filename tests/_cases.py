@@ -80,15 +80,21 @@ def all_cases():
     return out
 
 
-def run_case(be, case, tags=None, light=False):
-    """Push `case` through every hot-path entry point of backend `be`."""
+def run_case(be, case, tags=None, light=False, absolute=False):
+    """Push `case` through every hot-path entry point of backend `be`.
+
+    absolute=True runs the same products on |A| and |x| (no solver outputs): with the oracle backend that is
+    sum_j |a_ij||x_j| per output element, the scale of SURVEY N2's row-scaled bound."""
     c = case
     res = {}
     binary_vals = None
+    ab = (lambda a: None if a is None else np.abs(a)) if absolute else (lambda a: a)
+    cvals = ab(c.vals)
     for tag, x in c.xs.items():
         if tags and tag not in tags:
             continue
-        xt = c.xt(tag)
+        xt = ab(c.xt(tag))
+        x = ab(x)
         # --- pattern-only family: sparse.h / csr.h upper half / cbcsr.h ---
         res[f"A_mul_B/{tag}"] = be.coo_mul(c.nrow, c.ncol, c.rows, c.cols, binary_vals, x)
         res[f"At_mul_B/{tag}"] = be.coo_tmul(c.nrow, c.ncol, c.rows, c.cols, binary_vals, xt)
@@ -102,11 +108,11 @@ def run_case(be, case, tags=None, light=False):
             res[f"cbcsr_A_mul_B/cb{cbs}/{tag}"] = be.cbcsr_mul(c.nrow, c.ncol, c.rows, c.cols, cbs, x)
         # --- valued family: dsparse.h / csr.h lower half ---
         if c.vals is not None:
-            res[f"sdm_A_mul_B/{tag}"] = be.coo_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, x)
-            res[f"sdm_At_mul_B/{tag}"] = be.coo_tmul(c.nrow, c.ncol, c.rows, c.cols, c.vals, xt)
-            res[f"csr_A_mul_B/{tag}"] = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, x)
+            res[f"sdm_A_mul_B/{tag}"] = be.coo_mul(c.nrow, c.ncol, c.rows, c.cols, cvals, x)
+            res[f"sdm_At_mul_B/{tag}"] = be.coo_tmul(c.nrow, c.ncol, c.rows, c.cols, cvals, xt)
+            res[f"csr_A_mul_B/{tag}"] = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, cvals, x)
             for bs in c.block_sizes:
-                res[f"bsdm_A_mul_B/bs{bs}/{tag}"] = be.blocked_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, bs,
+                res[f"bsdm_A_mul_B/bs{bs}/{tag}"] = be.blocked_mul(c.nrow, c.ncol, c.rows, c.cols, cvals, bs,
                                                                    x, 1, "bsdm_A_mul_B")
     if light:
         return res
@@ -114,22 +120,22 @@ def run_case(be, case, tags=None, light=False):
     for name, k in BIN_SPMM + BIN_SPMM_VAR:
         if k > c.kmax:
             continue
-        X = S.X_sin(c.ncol, k)
+        X = ab(S.X_sin(c.ncol, k))
         res[f"{name}/k{k}"] = be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, None, X, k, name)
     bs = c.block_sizes[0]
     for name, k in [("bsbm_A_mul_B2", 2), ("bsbm_A_mul_B4", 4), ("bsbm_A_mul_Bn", 3)]:
-        X = S.X_sin(c.ncol, k)
+        X = ab(S.X_sin(c.ncol, k))
         res[f"{name}/bs{bs}"] = be.blocked_mul(c.nrow, c.ncol, c.rows, c.cols, None, bs, X, k, name)
     if c.vals is not None:
         for k in VAL_SPMM:
             if k > c.kmax:
                 continue
-            X = S.X_sin(c.ncol, k)
-            res[f"csr_A_mul_Bn/k{k}"] = be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, c.vals, X, k, "csr_A_mul_Bn")
+            X = ab(S.X_sin(c.ncol, k))
+            res[f"csr_A_mul_Bn/k{k}"] = be.csr_mul_n(c.nrow, c.ncol, c.rows, c.cols, cvals, X, k, "csr_A_mul_Bn")
     # --- the consumers of the path: CG on (A'A + lambda I), one and two right-hand sides ---
     # (F >= 16: on a 3-column matrix the second 2-column search block is rank deficient and the 2x2 solves of
     #  bsbm_cg2 divide by rounding noise -- in the reference too)
-    if 16 <= c.ncol <= 2100 and hasattr(be, "cg"):
+    if 16 <= c.ncol <= 2100 and hasattr(be, "cg") and not absolute:
         b1, b2 = cg_rhs(c.ncol)
         x, it = be.cg(c.nrow, c.ncol, c.rows, c.cols, b1, CG_LAMBDA, CG_TOL, False)
         res["bsbm_cg/x"], res["bsbm_cg/iter"] = x, np.array([float(it)])

@@ -33,10 +33,21 @@ def hip():
 VALUED = ("sdm_A_mul_B", "sdm_At_mul_B", "csr_A_mul_B", "csr_A_mul_Bn", "bsdm_A_mul_B")
 
 
+_SCALES = {}
+
+
+def _scales(name):
+    """sum_j |a_ij||x_j| of every output element of a case: the same products on |A|, |x| through the oracle (cached per case)"""
+    if name not in _SCALES:
+        _SCALES[name] = _cases.run_case(_cases.OracleBackend(), BY_NAME[name], absolute=True)
+    return _SCALES[name]
+
+
 def _check(out, gold, name, exact):
     """exact: every output bit for bit.  Otherwise: pattern-only products of integer-valued x bit for bit
-    (order-independent), everything else within TOL * max(1, |y|_inf) (a looser form of the
-    row-scaled bound only for rows whose terms cancel; the row-scaled form is used at full size)."""
+    (order-independent), everything else ROW-SCALED: |y - y_ref| <= TOL * sum_j |a_ij||x_j| per
+    element, the bound the full-size tests use (test_gpu_fullsize.py) -- an output whose terms are all zero must be exact."""
+    scales = None
     for k, v in out.items():
         g = gold[k.replace("/", "|")]
         assert v.shape == g.shape, (name, k)
@@ -52,8 +63,13 @@ def _check(out, gold, name, exact):
             assert np.array_equal(v.view(np.int64), g.view(np.int64)), \
                 f"{name}:{k} not bit-exact (max diff {np.max(np.abs(v - g))})"
         else:
-            bound = TOL * max(1.0, float(np.max(np.abs(g))))
-            assert np.max(np.abs(v - g)) <= bound, f"{name}:{k} off by {np.max(np.abs(v - g))} > {bound}"
+            if scales is None:
+                scales = _scales(name)
+            sc = scales[k]
+            assert sc.shape == g.shape, (name, k)
+            excess = np.abs(v - g) - TOL * sc
+            assert np.all(excess <= 0), \
+                f"{name}:{k} off by {np.max(np.abs(v - g))}, {np.max(excess)} beyond the row-scaled bound (worst scale {sc.flat[int(np.argmax(excess))]})"
 
 
 @pytest.mark.parametrize("backend", ["device", "dropin"])
@@ -1683,6 +1699,79 @@ def _dist_download(L, ptr, n):
     return out
 
 
+def _normal_residual(nrow, ncol, rp, cc, rows_all, lam, xs, b):
+    """||b - (A'A + lam I) xs|| / ||b|| with the ORACLE's products (cg.h:9-22): what a solve really left behind"""
+    q = O.coo_tmul(ncol, rows_all, cc, None, O.csr_mul(nrow, rp, cc, None, xs)) + lam * xs
+    return float(np.linalg.norm(b - q) / np.linalg.norm(b))
+
+
+def _dist_cg_checks(L, M, ranks, nrow, ncol, rp, cc, rows_all):
+    """fs_dist_cg (bsbm_cg, cg.h:25-82, across the ranks) against the oracle's solver.  Three separate questions, each with
+    its own numbers in the failure message (round 3 folded them into one assert and lost two of the three):
+
+    (a) an ILL-conditioned system (lambda = 3 under rows of 50 000 ones: ~1 100 iterations).  The iteration count of such a
+        solve depends on rounding (any other summation order moves it by several per cent; the reference's own fast-math build
+        differs from its strict build the same way), so it is only sanity-bounded; what is REQUIRED is what the caller gets:
+        the true relative residual, recomputed with the oracle's products, within 2 x tol -- the recursive residual the
+        solver tests (cg.h:69) drifts from the true one by far less at this conditioning -- and the solution within the
+        bound the two residuals imply, ||xs - xref|| <= (res_s + res_ref) ||b|| / lambda (A'A + lambda I >= lambda I);
+    (b) a WELL-conditioned system (lambda = 3e3: about 45 iterations): there the count must agree within one (the bar of the
+        reference goldens, _check above), same residual and solution bounds;
+    (c) fixed-order sums (option "reproducible"): two solves give the same count and the same bits."""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    bvec = np.sin(0.37 * np.arange(ncol) + 1.0)
+    bnorm = float(np.linalg.norm(bvec))
+
+    def solve(lam, tol):
+        xs = np.full(ncol, -1.0)
+        it = C.c_int(-1)
+        assert L.fs_dist_cg(M, xs.ctypes.data, bvec.ctypes.data, lam, tol, C.byref(it)) == 0, L.fs_last_error()
+        return xs, it.value
+
+    # (a)
+    lam, tol = 3.0, 1e-8
+    xs, it = solve(lam, tol)
+    xref, itref = O.cg_normal(nrow, ncol, rows_all, cc, bvec, lam, tol)
+    res_s = _normal_residual(nrow, ncol, rp, cc, rows_all, lam, xs, bvec)
+    res_ref = _normal_residual(nrow, ncol, rp, cc, rows_all, lam, xref, bvec)
+    err2 = float(np.linalg.norm(xs - xref))
+    errinf = float(np.max(np.abs(xs - xref)))
+    report = dict(ranks=ranks, iterations=it, oracle_iterations=itref, residual=res_s, oracle_residual=res_ref, err2=err2,
+                  errinf=errinf, err2_bound=(res_s + res_ref) * bnorm / lam, xmax=float(np.abs(xref).max()))
+    print("fs_dist_cg ill-conditioned:", report)
+    assert res_ref <= 2 * tol, report                       # (the oracle's own solve, for scale)
+    assert res_s <= 2 * tol, report
+    assert err2 <= 1.01 * (res_s + res_ref) * bnorm / lam, report
+    assert 0.5 * itref <= it <= 1.5 * itref + 2, report
+    # (b)
+    lam2, tol2 = 3.0e3, 1e-10
+    xs2, it2 = solve(lam2, tol2)
+    xref2, itref2 = O.cg_normal(nrow, ncol, rows_all, cc, bvec, lam2, tol2)
+    res2 = _normal_residual(nrow, ncol, rp, cc, rows_all, lam2, xs2, bvec)
+    res2_ref = _normal_residual(nrow, ncol, rp, cc, rows_all, lam2, xref2, bvec)
+    report2 = dict(ranks=ranks, iterations=it2, oracle_iterations=itref2, residual=res2, oracle_residual=res2_ref,
+                   err2=float(np.linalg.norm(xs2 - xref2)), err2_bound=(res2 + res2_ref) * bnorm / lam2,
+                   xmax=float(np.abs(xref2).max()))
+    print("fs_dist_cg well-conditioned:", report2)
+    assert abs(it2 - itref2) <= 1, report2
+    assert res2 <= 2 * tol2 and res2_ref <= 2 * tol2, report2
+    assert report2["err2"] <= 1.01 * report2["err2_bound"], report2
+    # (c)
+    capi.set_option("reproducible", 1)
+    try:
+        xa, ita = solve(lam, tol)
+        xb, itb = solve(lam, tol)
+    finally:
+        capi.set_option("reproducible", 0)
+    res_a = _normal_residual(nrow, ncol, rp, cc, rows_all, lam, xa, bvec)
+    report3 = dict(ranks=ranks, iterations=(ita, itb), residual=res_a, differing=int(np.count_nonzero(xa != xb)),
+                   maxdiff=float(np.max(np.abs(xa - xb))))
+    print("fs_dist_cg fixed-order:", report3)
+    assert ita == itb and np.array_equal(xa, xb), report3
+    assert res_a <= 2 * tol, report3
+
+
 @pytest.mark.parametrize("ranks", [1, 3])
 def test_native_multi_gpu_context_shards_by_nonzeros(hip, ranks):
     """fs_dist_* (one process, N devices, RCCL): on this one-GPU box the ranks are virtual (device 0 listed N times,
@@ -1757,14 +1846,8 @@ def test_native_multi_gpu_context_shards_by_nonzeros(hip, ranks):
                         assert L.fs_copy_to_device(L.fs_dist_x(M, r), xi.ctypes.data, 8 * ncol) == 0
             # bsbm_cg across the ranks, resident (pattern-only like the reference's BlockedSBM): against the oracle's solver
             if vals is None:
-                bvec = np.sin(0.37 * np.arange(ncol) + 1.0)
-                xs = np.full(ncol, -1.0)
-                it = C.c_int(-1)
-                assert L.fs_dist_cg(M, xs.ctypes.data, bvec.ctypes.data, 3.0, 1e-8, C.byref(it)) == 0, L.fs_last_error()
-                xref, itref = O.cg_normal(nrow, ncol, rows_all, cc, bvec, 3.0, 1e-8)
-                assert abs(it.value - itref) <= max(2, itref // 20) and np.max(np.abs(xs - xref)) <= 1e-7 * max(1.0, np.abs(xref).max()), \
-                    (it.value, itref)
-                for r in range(ranks):                       # x of the next products is whatever the caller puts there
+                _dist_cg_checks(L, M, ranks, nrow, ncol, rp, cc, rows_all)
+                for r in range(ranks):                       # fs_dist_cg uses x, y and z of the handle as its work vectors
                     assert L.fs_copy_to_device(L.fs_dist_x(M, r), x.ctypes.data, 8 * ncol) == 0
             # a kernel choice that moved after the plan was made (strict_order: the chunk-streaming kernel, one part) is followed
             capi.set_option("strict_order", 1)
