@@ -77,7 +77,10 @@ int  fs_set_device(int device);
  * "spmm_kernel" (multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep for k = 2..4, 3 one single-vector sweep
  * per column, 4 the v_mfma_f64_16x16x4_f64 experiment), "ata_kernel" (fs_ata_mul: 0 two products, 2 the fused single kernel),
  * "device_build" (format constructors: 0 host loops, 1 on the device from 4 M entries, 2 on the device always).
- * "tile_split": rows longer than this are cut into virtual rows in the tiled copy (0 = 256). */
+ * "tile_split": rows longer than this are cut into virtual rows in the tiled copy (0 = 256).
+ * "cg_fixed_order" (default 1; FS_CG_FIXED_ORDER): fs_cg / fs_cg2 / fs_dist_cg run their products with fixed-order sums, as under
+ * "reproducible", so that a solve is bit-identical from run to run like the reference's loops (cg.h:25-187); 0 = the default kernels.
+ * "dist_cg_scheme" (FS_DIST_CG_SCHEME): fs_dist_cg, 0 every device keeps whole vectors, 1 every device keeps its slice (see there). */
 int  fs_set_option(const char *name, int value);
 int  fs_get_option(const char *name);
 
@@ -214,16 +217,37 @@ fs_dist_t fs_dist_create(int ndev, const int *devices);
 void fs_dist_destroy(fs_dist_t D);
 int  fs_dist_ndev(fs_dist_t D);
 int  fs_dist_uses_rccl(fs_dist_t D);
+/* 1 once the context exchanges conservatively: ONE whole-shard all-gather behind the finished local product instead of one per
+ * part under the later parts.  Chosen with FS_DIST_PARTS=1, and taken for good when a group call of the overlapped mode returns an
+ * error (the product that met the error is finished conservatively).  The overlapped mode is UNVERIFIED on more than one GPU. */
+int  fs_dist_is_conservative(fs_dist_t D);
 /* host CSR arrays -> nnz-balanced row shards, one fs_matrix_t per device; vals == NULL: pattern-only */
 fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols,
                                     const double *vals);
+/* The matrix as per-rank shards -- no whole-matrix array anywhere, so the TOTAL may exceed 2^31 - 1 entries (every shard stays
+ * below it: int row_ptr, csr.h:358-366); BASELINE config 5 (3.2 G entries, 8 shards) enters this way.  Shard r = the next
+ * shard_rows[r] rows of A: a LOCAL row_ptr (shard_rows[r] + 1 ints from 0), GLOBAL column ids, optional values (vals == NULL or
+ * vals[r] == NULL for all r: pattern-only).  space = FS_HOST: host arrays; FS_DEVICE: shard r's arrays are on rank r's device
+ * (copied; the caller may free them).  The caller chooses the cuts (by non-zeros for power-law matrices). */
+fs_dist_matrix_t fs_dist_csr_create_from_shards(fs_dist_t D, int nrow, int ncol, const int *shard_rows /* ndev */,
+                                                const int64_t *shard_nnz /* ndev */, const int *const *row_ptr, const int *const *cols,
+                                                const double *const *vals, int space);
 void fs_dist_matrix_destroy(fs_dist_matrix_t M);
 /* row shards of A' (columns of A cut by non-zeros; every row of A' in ascending A-row order) from the SAME host arrays the
  * matrix was created from (the handle keeps no host copy); idempotent */
 int  fs_dist_matrix_build_transpose(fs_dist_matrix_t M, const int *row_ptr, const int *cols, const double *vals);
+/* the same shards of A' from the device-resident shards of A: per-rank column counts added up and cut on one device, a stable
+ * partition of every shard's entries by owner, device-to-device copies, a stable local sort -- no host array of the matrix
+ * (what a matrix created from shards needs; works for any).  Same bounds, same entry order as the host build.  Idempotent. */
+int  fs_dist_matrix_build_transpose_device(fs_dist_matrix_t M);
 int  fs_dist_matrix_has_transpose(fs_dist_matrix_t M);
-int  fs_dist_matrix_bounds(fs_dist_matrix_t M, int *bounds /* ndev + 1 */);
+int  fs_dist_matrix_bounds(fs_dist_matrix_t M, int *bounds /* ndev + 1: row cuts of A */);
+int  fs_dist_matrix_bounds_t(fs_dist_matrix_t M, int *bounds /* ndev + 1: row cuts of A' = column cuts of A */);
 int64_t fs_dist_matrix_shard_nnz(fs_dist_matrix_t M, int rank);
+int64_t fs_dist_matrix_nnz(fs_dist_matrix_t M);
+/* the handle of rank `rank`'s shard of A (transposed != 0: of A'), owned by M, on that rank's device: for inspection
+ * (fs_matrix_download, fs_matrix_spmv_kernel, fs_matrix_device_bytes) */
+fs_matrix_t fs_dist_matrix_shard(fs_dist_matrix_t M, int rank, int transposed);
 /* y[nrow] = A x[ncol] / z[ncol] = A' u[nrow] with HOST vectors: the input goes to every device over its own PCIe link
  * through a pinned staging buffer (chunks, the host copy of the next under the uploads of the last), the output comes back
  * from device 0 */
@@ -237,8 +261,13 @@ int  fs_dist_spmv_resident(fs_dist_matrix_t M);
 int  fs_dist_spmv_t_resident(fs_dist_matrix_t M);
 int  fs_dist_swap_xy(fs_dist_matrix_t M);
 /* (A'A + lambda I) x = b by conjugate gradients on the sharded matrix (bsbm_cg, cg.h:25-82, across the GPUs): everything
- * resident, two products with their all-gathers inside per iteration, the vector steps replicated on every device (identical
- * vectors everywhere: the dots need no exchange); b_host, x_host: ncol doubles; stops at ||r|| <= tol ||b|| */
+ * resident, the scalars of the iteration on the devices.  Option "dist_cg_scheme" 0: the vector steps replicated on every
+ * device (identical vectors everywhere, the dots need no exchange, both products carry their all-gather); 1: every device keeps
+ * its slice of the unknowns (vector work divided by the devices; the partial dots are all-gathered, 8 bytes per rank, and added in
+ * rank order; the new search direction is all-gathered).  Every device decides convergence for itself and the host compares
+ * the flags of all of them: a disagreement is an error return (FS_ERR_HIP), not a hang.  Products add in a fixed order unless
+ * option "cg_fixed_order" is 0.  b_host, x_host: ncol doubles; stops at ||r|| <= tol ||b||.
+ * CLOBBERS fs_dist_x / fs_dist_y / fs_dist_z (they are the solver's work vectors): upload x again before the next resident product. */
 int  fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double lambda, double tol, int *out_iter);
 double *fs_dist_x(fs_dist_matrix_t M, int rank);
 double *fs_dist_y(fs_dist_matrix_t M, int rank);

@@ -7,6 +7,7 @@
 namespace fs {
 
 static thread_local std::string g_err;
+thread_local int tl_fixed_order = 0;
 
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -32,6 +33,8 @@ Options &options()
     if (const char *v = getenv("FS_REPRODUCIBLE")) q.reproducible = atoi(v);     // drop-in callers: fixed-order sums without a code change
     if (const char *v = getenv("FS_STRICT_ORDER")) q.strict_order = atoi(v);     //                  the reference's own order of additions
     if (const char *v = getenv("FS_SPMM_WIDE")) q.spmm_wide = atoi(v);
+    if (const char *v = getenv("FS_CG_FIXED_ORDER")) q.cg_fixed_order = atoi(v);
+    if (const char *v = getenv("FS_DIST_CG_SCHEME")) q.dist_cg_scheme = atoi(v);
     return q;
   }();
   return o;
@@ -153,6 +156,8 @@ int fs_set_option(const char *name, int value)
   if (!strcmp(name, "spmm_wide")) { fs::options().spmm_wide = value; return FS_OK; }
   if (!strcmp(name, "ata_kernel")) { fs::options().ata_kernel = value; return FS_OK; }
   if (!strcmp(name, "device_build")) { fs::options().device_build = value; return FS_OK; }
+  if (!strcmp(name, "cg_fixed_order")) { fs::options().cg_fixed_order = value; return FS_OK; }
+  if (!strcmp(name, "dist_cg_scheme")) { fs::options().dist_cg_scheme = value; return FS_OK; }
   set_error(std::string("fs_set_option: unknown option ") + name);
   return FS_ERR_ARG;
 }
@@ -173,6 +178,8 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "spmm_wide")) return fs::options().spmm_wide;
   if (name && !strcmp(name, "ata_kernel")) return fs::options().ata_kernel;
   if (name && !strcmp(name, "device_build")) return fs::options().device_build;
+  if (name && !strcmp(name, "cg_fixed_order")) return fs::options().cg_fixed_order;
+  if (name && !strcmp(name, "dist_cg_scheme")) return fs::options().dist_cg_scheme;
   return FS_ERR_ARG;
 }
 
@@ -530,7 +537,7 @@ int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream
 {
   FS_RANGE("fs_ata_mul");
   if (int rc = check_mul(A, y, x, "fs_ata_mul")) return rc;
-  if (fs::options().ata_kernel == 2 && !fs::options().strict_order && !fs::options().reproducible) {
+  if (fs::options().ata_kernel == 2 && !fs::options().strict_order && !fs::reproducible_now()) {
     // the fused form (bcsr_AA_mul_B's own loop nest): one pass over A per phase, no copy of A'.  Measured slower than
     // the two products wherever A' fits: kept for callers short of HBM and as the measured answer to
     // SURVEY 8f-4.

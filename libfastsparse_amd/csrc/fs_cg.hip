@@ -377,6 +377,48 @@ int cg_dev_steps(int n, double lambda, double *x, double *r, double *p, double *
   return FS_OK;
 }
 
+int cg_dev_init_partial(int n, const double *b, double *x, double *r, double *p, double *part, double *red_out, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_init_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, b, x, r, p, part);
+  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red_out);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_dev_step_a(int n, double lambda, const double *p, double *q, double *part, double *red_out, const double *st, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_shift_dot_dev_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, lambda, q, p, part, st);
+  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red_out);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_dev_step_b(int n, double *x, double *r, const double *p, const double *q, double *part, double *red_out, const double *st,
+                  hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_update_dev_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, x, r, p, q, part, st);
+  hipLaunchKernelGGL(final_sum_kernel<1>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red_out);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_dev_step_c(int n, double *p, const double *r, const double *st, hipStream_t s)
+{
+  hipLaunchKernelGGL(cg_direction_dev_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, p, r, st);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg_dev_final(int mode, const double *partials, int count, double *red_out, double *st, double arg, hipStream_t s)
+{
+  const dim3 one(1), blk(kRedThreads);
+  if (mode == 0)      hipLaunchKernelGGL((final_step_kernel<1, 0>), one, blk, 0, s, partials, count, red_out, st, arg);
+  else if (mode == 1) hipLaunchKernelGGL((final_step_kernel<1, 1>), one, blk, 0, s, partials, count, red_out, st, arg);
+  else                hipLaunchKernelGGL((final_step_kernel<1, 2>), one, blk, 0, s, partials, count, red_out, st, arg);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int CgFlags::init()
 {
   FS_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4));
@@ -441,6 +483,7 @@ int fs_cg(fs_matrix_t A, fs_matrix_t At, double *x, const double *b, double lamb
   const int N = A->a.nrow, F = A->a.ncol;
   if (At->a.nrow != F || At->a.ncol != N) { set_error("fs_cg: At is not the transpose shape of A"); return FS_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
+  FixedOrderScope fixed(options().cg_fixed_order != 0);   // the products of a solve add in a fixed order: bit-identical run to run
   Workspace ws;
   double *r = ws.get(F), *p = ws.get(F), *q = ws.get(F), *tmp = ws.get(N), *part = ws.get(kRedBlocks * 3), *red = ws.get(4);
   if (!r || !p || !q || !tmp || !part || !red) { set_error("fs_cg: out of device memory"); return FS_ERR_HIP; }
@@ -472,6 +515,7 @@ int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lam
   if (!A || !At || !X || !B) { set_error("fs_cg2: NULL argument"); return FS_ERR_ARG; }
   const int N = A->a.nrow, F = A->a.ncol;
   if (At->a.nrow != F || At->a.ncol != N) { set_error("fs_cg2: At is not the transpose shape of A"); return FS_ERR_ARG; }
+  FixedOrderScope fixed(options().cg_fixed_order != 0);   // the products of a solve add in a fixed order: bit-identical run to run
   // the two-column copies of both matrices, before the first iteration (fs_spmm itself never builds)
   if (int rc = fs_matrix_prepare(A, 2, 0, stream)) return rc;
   if (int rc = fs_matrix_prepare(At, 2, 0, stream)) return rc;

@@ -101,6 +101,13 @@ struct TiledCsr {
   int *chunk_panel = nullptr;  // nchunks: panel of the chunk; bit 31 set when the panel has more than one chunk
   int *chunk_item = nullptr;   // 2 * nchunks: [first, one past the last) work item of every chunk
   bool shared = false;         // some panel has more than one chunk: products go through the zeroed scratch vector yv
+  // fixed-order sums on this copy (option "reproducible", the solvers): the builder keeps the entries of one row inside a work
+  // item with ONE wave (ldsx_reorder_kernel), whose LDS adds execute in program order; `orderable` = it managed to for every
+  // item.  Chunks sharing a panel then add their slices to HBM one after the other, in the order chunk_ord gives (a ticket per
+  // panel), instead of in arrival order.
+  bool orderable = false;
+  int *chunk_ord = nullptr;    // nchunks: ordinal of the chunk inside its panel
+  int *ticket = nullptr;       // P: ordinal whose turn it is (zeroed by the launcher)
 };
 
 // Two-pass copy of a CSR ("expand, then reduce"; see DESIGN.md "spmv_expand_kernel / spmv_reduce_kernel").
@@ -137,19 +144,24 @@ constexpr int kBinShareMin = 8192;     // a pass-1 workgroup streams at least th
 // two geometries of the 152 KiB of LDS: a wide band with few accumulators, or a narrower band with four times as many rows
 constexpr int kLongBandA = 16384, kLongRowsA = 3072;      // 128 KiB of x + 24 KiB of accumulators
 constexpr int kLongBandB = 8192, kLongRowsB = 12032;      //  64 KiB of x + 94 KiB of accumulators (160 KiB with the zero slots)
+constexpr int kLongOwners = kBinBlock / 64;               // the waves of a workgroup: every long row belongs to one of them
 struct LongRows {
-  int nlong = 0;                // rows taken out (ascending row ids)
-  int64_t n = 0;                // their entries, every band padded to an even count
+  int nlong = 0;                // rows taken out
+  int64_t n = 0;                // their entries, every (band, owner) segment padded to an even count
   int bcols = kLongBandA;       // columns per band (kLongBandA or kLongBandB)
   int B = 0;                    // bands of bcols columns
-  int *row = nullptr;           // nlong: row id
-  uint16_t *lcol = nullptr;     // n, (band, long row) order: column - band * bcols; padding = bcols (the zero slot)
+  // The long rows are numbered so that the rows of owner w (one of the kLongOwners waves of a workgroup, dealt out by length so
+  // that the owners carry equal numbers of entries) are the indices [own_first[w], own_first[w + 1]): inside a band the
+  // entries are sorted by this index, so every owner's entries are one contiguous SEGMENT of the band.
+  int *row = nullptr;           // nlong: row id of long row i
+  uint16_t *lcol = nullptr;     // n, (band, long row index) order: column - band * bcols; padding = bcols (the zero slot)
   uint16_t *lrow = nullptr;     // n: index of the long row; padding = the previous entry's
   double *vals = nullptr;       // n (nullptr: pattern-only)
   int64_t *band_ptr = nullptr;  // B + 1: first entry of every band
+  unsigned *seg_ptr = nullptr;  // B * (kLongOwners + 1): first entry of every owner's segment, relative to its band
   double *ylong = nullptr;      // nlong: the sums of one product, zeroed before and scattered into y after
+  double *ypart = nullptr;      // nwg * nlong: the workgroups' sums, added up in workgroup order (fixed-order products)
   int nwg = 0;                  // persistent workgroups
-  int *h_row = nullptr;         // host mirror of row (products in parts scatter the rows of a range)
 };
 
 struct BinnedCsr {
@@ -277,8 +289,24 @@ struct Options {
   int spmm_wide = 0;     // row SpMM kernel with two columns per lane and 16-byte loads: 0 auto (even k from 4 to 14, 16-byte aligned X / Y), 1 wherever legal, -1 never
   int spmm_kernel = 0;   // multi-column products: 0 auto, 1 row kernel, 2 k-column two-pass sweep (k = 2..4), 3 one
                          // single-vector sweep per column, 4 the MFMA row kernel (experiment, see spmm_mfma_kernel)
+  int cg_fixed_order = 1;  // fs_cg / fs_cg2 / fs_dist_cg run their products with fixed-order sums (as under "reproducible"), so
+                           // that a solve is bit-identical from run to run like the reference's (cg.h:25-187); 0: the default kernels
+  int dist_cg_scheme = 0;  // fs_dist_cg: 0 every device keeps whole vectors (no exchange for the dots), 1 every device keeps its
+                           // slice of the unknowns (vector work divided by the devices; see fs_dist.hip)
 };
 Options &options();
+
+// Fixed-order sums are wanted NOW, on this thread: the process-wide option, or the calling thread is inside a solver that asks
+// for them (FixedOrderScope).  Read by the launchers at every product.
+extern thread_local int tl_fixed_order;
+inline bool reproducible_now() { return options().reproducible != 0 || tl_fixed_order > 0; }
+struct FixedOrderScope {
+  bool on;
+  explicit FixedOrderScope(bool want) : on(want) { if (on) ++tl_fixed_order; }
+  ~FixedOrderScope() { if (on) --tl_fixed_order; }
+  FixedOrderScope(const FixedOrderScope &) = delete;
+  FixedOrderScope &operator=(const FixedOrderScope &) = delete;
+};
 
 // ---- launchers implemented in fs_kernels.hip --------------------------------------------
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
@@ -305,6 +333,15 @@ int cg_dev_init(int n, const double *b, double *x, double *r, double *p, double 
                 hipStream_t s);                                                // x = 0, r = p = b; b.b, the stopping threshold
 int cg_dev_steps(int n, double lambda, double *x, double *r, double *p, double *q, double *part, double *red, double *st,
                  hipStream_t s);                                               // everything of an iteration behind q = A'(A p)
+// the same steps for a SLICE of the unknowns (fs_dist_cg, scheme "gather"): every step leaves this rank's partial dot in
+// *red_out; the partials of all ranks, gathered, go through cg_dev_final, which adds them in rank order and does the scalar step
+// `mode` of final_step_kernel (0 b.b and the threshold, 1 alpha, 2 convergence and beta)
+int cg_dev_init_partial(int n, const double *b, double *x, double *r, double *p, double *part, double *red_out, hipStream_t s);
+int cg_dev_step_a(int n, double lambda, const double *p, double *q, double *part, double *red_out, const double *st, hipStream_t s);
+int cg_dev_step_b(int n, double *x, double *r, const double *p, const double *q, double *part, double *red_out, const double *st,
+                  hipStream_t s);
+int cg_dev_step_c(int n, double *p, const double *r, const double *st, hipStream_t s);
+int cg_dev_final(int mode, const double *partials, int count, double *red_out, double *st, double arg, hipStream_t s);
 // the host's view of a running solve: {done, iterations} of the two most recent iterations, in pinned memory
 struct CgFlags {
   double *h = nullptr;
@@ -334,6 +371,12 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev,
                       const int *cols_dev, const double *vals_dev, hipStream_t s);
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s);
+// row shards of A' from row shards of A on the devices (fs_dist_matrix_build_transpose_device): see fs_format.hip
+int shard_column_counts(const DeviceCsr &A, int *counts_dev, hipStream_t s);     // counts[c] += entries of the shard in column c
+int add_counts(int64_t n, int *acc_dev, const int *add_dev, hipStream_t s);
+int cut_by_counts(int n_items, const int *counts_dev, int nparts, int *bounds_host, int64_t *total, hipStream_t s);
+int shard_transpose_partition(const DeviceCsr &A, int row_lo, int nparts, const int *bounds_host, int **trow, int **tcol,
+                              double **tval, int64_t *count_host, hipStream_t s);
 int cbcsr_rows_device(DeviceCsr &out, int nrow, int ncol, int nblocks, int64_t nnz, const int *cell_ptr_dev,
                       const int *cols_dev, hipStream_t s);
 int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, const int *rows_dev, const int *cols_dev,

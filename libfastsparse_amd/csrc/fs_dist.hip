@@ -9,21 +9,27 @@
 //
 // Both directions are "rows + all-gather" ("prefer holding CSR' row-sharded too"):
 //   y = A x   rank r owns rows [bounds[r], bounds[r+1]) of A (equal non-zeros), x replicated;
-//   z = A' u  rank r owns rows of A' (= columns of A, again cut by non-zeros), built on demand from the host arrays
-//             (fs_dist_matrix_build_transpose), u replicated -- and u IS y after a product, so A then A' needs no copy.
+//   z = A' u  rank r owns rows of A' (= columns of A, again cut by non-zeros), u replicated -- and u IS y after a product, so
+//             A then A' needs no copy.  The shards of A' are built from host arrays (fs_dist_matrix_build_transpose) or, with no
+//             whole-matrix host array anywhere, from the device-resident shards of A (fs_dist_matrix_build_transpose_device).
+// A matrix comes from ONE host CSR (fs_dist_csr_create: int row_ptr, < 2^31 entries in total) or from per-rank shards
+// (fs_dist_csr_create_from_shards: every shard < 2^31 entries, the total is 64-bit -- BASELINE config 5 only exists this way).
+//
 // One product (dist_product): the local product runs in parts (fs_spmv_part: pass 2 of the two-pass pair by ranges of panels)
 // on the rank's compute stream; behind every part an event lets the rank's COMMUNICATION stream all-gather the rows that
 // part finished -- one ncclAllGather per part on a padded buffer (counts differ between ranks), all ranks' calls of a part
 // in one ncclGroupStart/End -- while the next part computes; one fs_copy_segments launch per rank unpacks the padded buffer
 // into the full vector at the end.  No n^2 broadcasts, no host round trip.
+// The CONSERVATIVE mode (FS_DIST_PARTS=1, or after a group call of the overlapped mode returned an error) is one whole-shard
+// all-gather behind the finished local product: no send window ever reaches into rows that are still being written.
 //
 // RCCL is loaded with dlopen when the first context with more than one distinct device is created, so that
 // single-GPU users never load it and a process that already holds a copy (PyTorch ships one) shares it.
 // A context whose device list names the same device more than once ("virtual ranks": RCCL refuses duplicates)
 // exchanges the parts with device-to-device copies instead; that form exists so that the sharding, the parts and the
 // padded layout can be exercised on a one-GPU machine (tests/test_gpu_parity.py) and is not a substitute for RCCL on
-// real devices.  RCCL with MORE THAN ONE rank has not run anywhere yet (no multi-GPU machine was available to the
-// builder); FS_DIST_FORCE_RCCL=1 takes a one-device context through the same group calls.
+// real devices.  UNVERIFIED ON HARDWARE: RCCL with MORE THAN ONE rank has not run anywhere yet (no multi-GPU machine was
+// available to the builder); FS_DIST_FORCE_RCCL=1 takes a one-device context through the same group calls.
 #include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
@@ -92,6 +98,14 @@ int env_parts()
   return v;
 }
 
+// FS_DIST_FAIL_PART=p (tests only): the all-gather of part p of the next overlapped product reports an error once, which takes
+// the context to the conservative mode -- the only way to walk that path without a broken fabric
+int env_fail_part()
+{
+  static const int v = [] { const char *e = getenv("FS_DIST_FAIL_PART"); return e && *e ? atoi(e) : -1; }();
+  return v;
+}
+
 }  // namespace
 
 struct fs_dist_s {
@@ -100,6 +114,8 @@ struct fs_dist_s {
   std::vector<hipStream_t> stream;    // compute stream per rank, on its device
   std::vector<hipStream_t> comm_stream;  // communication stream per rank
   bool use_rccl = false;
+  bool conservative = false;          // one whole-shard all-gather behind the product (FS_DIST_PARTS=1, or after an error)
+  bool fail_injected = false;
   std::vector<ncclComm_t> comm;
   std::mutex lock;                    // the streams and communicators serve one product at a time (a communicator must not be
                                       // used from two host threads at once): taken behind the matrix's own lock
@@ -111,31 +127,38 @@ struct DistSide {
   std::vector<int> bounds;            // rank r owns rows [bounds[r], bounds[r + 1]) of M
   std::vector<int64_t> shard_nnz;
   std::vector<fs_matrix_t> shard;
-  // per rank, on its device: the shard's rows of the output (room for a padded part behind the last row), the padded
-  // receive buffer of the parts, the table of the unpack launch, one event per part
+  int max_rows = 0;                   // the tallest shard
+  // per rank, on its device: the shard's rows of the output (room for a padded window behind the last row), the padded
+  // receive buffer, the tables of the unpack launches, one event per part
   std::vector<double *> local, pad;
-  std::vector<int64_t *> table;
+  std::vector<int64_t *> table;       // [rank]: the overlapped layout (nseg segments), then the whole-shard layout (nseg1)
   std::vector<std::vector<hipEvent_t>> ev;   // [rank][part]
   std::vector<hipEvent_t> done;              // [rank]: the unpack on the communication stream
   int nparts = 0;
   std::vector<std::vector<int>> cut;  // [rank][part]: row cuts of the local product (fs_spmv_part_rows)
   std::vector<int> maxc;              // [part]: the largest count of any rank
   std::vector<int64_t> off;           // [part]: first element of the part's region of the padded buffer
-  int nseg = 0;
+  int nseg = 0, nseg1 = 0;
   int64_t max_seg = 0;
   bool built = false;
+};
+
+struct CgWork {                       // vectors of fs_dist_cg, kept on the handle between solves
+  int F = 0;
+  std::vector<double *> sol, r, b, p, q, part, red, redall, st;
 };
 
 struct fs_dist_matrix_s {
   fs_dist_t D = nullptr;
   int nrow = 0, ncol = 0;
   int64_t nnz = 0;
-  DistSide a, t;                      // A (always), A' (fs_dist_matrix_build_transpose)
+  DistSide a, t;                      // A (always), A' (fs_dist_matrix_build_transpose[_device])
   // per rank: the whole x (ncol), y (nrow) and z (ncol) on its device.  u of z = A' u is y.
   std::vector<double *> x, y, z;
-  // host copies of the CSR are NOT kept; the transpose is built from the arrays the caller passes again
+  // host copies of the CSR are NOT kept
   double *pin = nullptr;              // pinned staging of host vectors
   size_t pin_doubles = 0;
+  CgWork cg;
   std::mutex lock;                    // products on one matrix are serialised (x, y, z and the part buffers are per matrix)
 };
 
@@ -151,6 +174,16 @@ void free_side(fs_dist_t D, DistSide &S)
     if (S.shard[r]) fs_matrix_destroy(S.shard[r]);
   }
   S = DistSide();
+}
+
+void free_cg(fs_dist_t D, CgWork &W)
+{
+  for (size_t d = 0; d < W.sol.size(); ++d) {
+    (void)hipSetDevice(D->dev[d]);
+    for (double *p : {W.sol[d], W.r[d], W.b[d], W.p[d], W.q[d], W.part[d], W.red[d], W.redall[d], W.st[d]})
+      if (p) (void)hipFree(p);
+  }
+  W = CgWork();
 }
 
 // row cuts with (almost) equal numbers of non-zeros: bounds[r] = first row whose row_ptr is >= r/n of nnz -- the cut
@@ -182,10 +215,11 @@ void free_plan(fs_dist_t D, DistSide &S)
     if (r < S.done.size() && S.done[r]) (void)hipEventDestroy(S.done[r]);
   }
   S.local.clear(); S.pad.clear(); S.table.clear(); S.ev.clear(); S.done.clear();
-  S.nseg = 0; S.max_seg = 0;
+  S.nseg = 0; S.nseg1 = 0; S.max_seg = 0;
 }
 
-// after the shards exist: the parts of every rank's local product, the padded layout, buffers, events
+// after the shards exist: the parts of every rank's local product, the padded layouts (overlapped: one region per part;
+// whole-shard: one region of max_rows per rank), buffers, events
 int plan_side(fs_dist_t D, DistSide &S, int nparts)
 {
   const int n = D->n;
@@ -200,13 +234,14 @@ int plan_side(fs_dist_t D, DistSide &S, int nparts)
   }
   S.maxc.assign((size_t)nparts, 0);
   S.off.assign((size_t)nparts + 1, 0);
-  int max_rows = 0;
-  for (int r = 0; r < n; ++r) max_rows = std::max(max_rows, S.bounds[(size_t)r + 1] - S.bounds[(size_t)r]);
+  S.max_rows = 0;
+  for (int r = 0; r < n; ++r) S.max_rows = std::max(S.max_rows, S.bounds[(size_t)r + 1] - S.bounds[(size_t)r]);
   for (int p = 0; p < nparts; ++p) {
     for (int r = 0; r < n; ++r) S.maxc[(size_t)p] = std::max(S.maxc[(size_t)p], S.cut[(size_t)r][(size_t)p + 1] - S.cut[(size_t)r][(size_t)p]);
     S.off[(size_t)p + 1] = S.off[(size_t)p] + (int64_t)n * S.maxc[(size_t)p];
   }
   std::vector<int64_t> dst, src, cnt;
+  S.max_seg = 0;
   for (int p = 0; p < nparts; ++p)
     for (int r = 0; r < n; ++r) {
       const int c = S.cut[(size_t)r][(size_t)p + 1] - S.cut[(size_t)r][(size_t)p];
@@ -221,6 +256,20 @@ int plan_side(fs_dist_t D, DistSide &S, int nparts)
   tab.insert(tab.end(), dst.begin(), dst.end());
   tab.insert(tab.end(), src.begin(), src.end());
   tab.insert(tab.end(), cnt.begin(), cnt.end());
+  // the whole-shard layout: rank r's rows at r * max_rows
+  dst.clear(); src.clear(); cnt.clear();
+  for (int r = 0; r < n; ++r) {
+    const int c = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+    if (!c) continue;
+    dst.push_back(S.bounds[(size_t)r]);
+    src.push_back((int64_t)r * S.max_rows);
+    cnt.push_back(c);
+  }
+  S.nseg1 = (int)cnt.size();
+  tab.insert(tab.end(), dst.begin(), dst.end());
+  tab.insert(tab.end(), src.begin(), src.end());
+  tab.insert(tab.end(), cnt.begin(), cnt.end());
+  const int64_t pad_doubles = std::max<int64_t>(S.off[(size_t)nparts], (int64_t)n * S.max_rows);
   S.local.assign((size_t)n, nullptr);
   S.pad.assign((size_t)n, nullptr);
   S.table.assign((size_t)n, nullptr);
@@ -229,8 +278,8 @@ int plan_side(fs_dist_t D, DistSide &S, int nparts)
   for (int r = 0; r < n; ++r) {
     FS_HIP(hipSetDevice(D->dev[r]));
     // the send window of a part starts at its first row and is maxc[p] long: it may run past the shard's last row
-    FS_HIP(hipMalloc(&S.local[(size_t)r], sizeof(double) * (size_t)(2 * (int64_t)max_rows + 1)));
-    FS_HIP(hipMalloc(&S.pad[(size_t)r], sizeof(double) * (size_t)(S.off[(size_t)nparts] + 1)));
+    FS_HIP(hipMalloc(&S.local[(size_t)r], sizeof(double) * (size_t)(2 * (int64_t)S.max_rows + 1)));
+    FS_HIP(hipMalloc(&S.pad[(size_t)r], sizeof(double) * (size_t)(pad_doubles + 1)));
     FS_HIP(hipMalloc(&S.table[(size_t)r], sizeof(int64_t) * (tab.size() + 1)));
     if (!tab.empty()) FS_HIP(hipMemcpy(S.table[(size_t)r], tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice));
     for (int p = 0; p < nparts; ++p) {
@@ -244,31 +293,109 @@ int plan_side(fs_dist_t D, DistSide &S, int nparts)
   return FS_OK;
 }
 
+// `count` doubles from every rank's send[r] to every rank's recv[d] + r * count, on the streams `st` (ordered behind the
+// events ready[r], one per rank, recorded on whatever stream produced send[r]).  RCCL: one ncclAllGather per rank in one group;
+// virtual ranks: device-to-device copies leaving the same layout.  *failed_call (RCCL only): the all-gather call returned an
+// error -- the group was closed, nothing of this exchange can be relied on.
+int exchange_equal(fs_dist_t D, const std::vector<const double *> &send, const std::vector<double *> &recv, size_t count,
+                   const std::vector<hipStream_t> &st, const std::vector<hipEvent_t> &ready, bool inject_failure = false)
+{
+  const int n = D->n;
+  if (!count) return FS_OK;
+  if (D->use_rccl) {
+    // every rank's call in one group; an error inside the group still closes it
+    ncclResult_t first = rccl().GroupStart();
+    if (first != ncclSuccess) return nccl_fail(first, "ncclGroupStart");
+    if (inject_failure) first = ncclInternalError;
+    for (int r = 0; r < n && first == ncclSuccess; ++r)
+      first = rccl().AllGather(send[(size_t)r], recv[(size_t)r], count, ncclDouble, D->comm[(size_t)r], st[(size_t)r]);
+    const ncclResult_t end = rccl().GroupEnd();
+    if (first != ncclSuccess) return nccl_fail(first, "ncclAllGather");
+    if (end != ncclSuccess) return nccl_fail(end, "ncclGroupEnd");
+    return FS_OK;
+  }
+  if (inject_failure) { fs::set_error("injected failure of an exchange (FS_DIST_FAIL_PART)"); return FS_ERR_HIP; }
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    for (int r = 0; r < n; ++r) {
+      if (ready[(size_t)r]) FS_HIP(hipStreamWaitEvent(st[(size_t)d], ready[(size_t)r], 0));
+      FS_HIP(hipMemcpyAsync(recv[(size_t)d] + (int64_t)r * (int64_t)count, send[(size_t)r], sizeof(double) * count, hipMemcpyDeviceToDevice,
+                            st[(size_t)d]));
+    }
+  }
+  return FS_OK;
+}
+
+// the cuts belong to the kernel the options select NOW (strict_order / reproducible / spmv_kernel set since the plan was
+// made move the product to another kernel, which finishes its rows elsewhere): plan again when they moved
+int replan_if_moved(fs_dist_t D, DistSide &S)
+{
+  const int n = D->n;
+  bool same = true;
+  std::vector<int> now((size_t)S.nparts + 1);
+  for (int r = 0; same && r < n; ++r) {
+    if (S.bounds[(size_t)r + 1] == S.bounds[(size_t)r]) continue;
+    FS_HIP(hipSetDevice(D->dev[r]));
+    if (int rc = fs_spmv_part_rows(S.shard[(size_t)r], 0, S.nparts, now.data())) return rc;
+    same = now == S.cut[(size_t)r];
+  }
+  if (!same) {
+    if (int rc = dist_sync(D)) return rc;
+    free_plan(D, S);
+    if (int rc = plan_side(D, S, S.nparts)) return rc;
+  }
+  return FS_OK;
+}
+
+// the whole-shard all-gather: rank r's rows [bounds[r], bounds[r + 1]) from src[r] (room for max_rows doubles) into out[d] on
+// every rank d.  Runs on the communication streams behind the compute streams' work so far; the compute streams wait for it.
+int dist_gather(fs_dist_t D, DistSide &S, const std::vector<double *> &src, const std::vector<double *> &out)
+{
+  const int n = D->n;
+  std::vector<const double *> send((size_t)n);
+  std::vector<hipEvent_t> ready((size_t)n);
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    FS_HIP(hipEventRecord(S.ev[(size_t)r][0], D->stream[r]));
+    FS_HIP(hipStreamWaitEvent(D->comm_stream[r], S.ev[(size_t)r][0], 0));
+    send[(size_t)r] = src[(size_t)r];
+    ready[(size_t)r] = S.ev[(size_t)r][0];
+  }
+  if (int rc = exchange_equal(D, send, S.pad, (size_t)S.max_rows, D->comm_stream, ready)) return rc;
+  const int64_t *skip = nullptr;
+  (void)skip;
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    if (int rc = fs_copy_segments(S.nseg1, S.table[(size_t)r] + 3 * (size_t)S.nseg, S.max_rows, S.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])) return rc;
+    FS_HIP(hipEventRecord(S.done[(size_t)r], D->comm_stream[r]));
+    FS_HIP(hipStreamWaitEvent(D->stream[r], S.done[(size_t)r], 0));
+  }
+  return FS_OK;
+}
+
 // out = M in on every rank: local products in parts, the all-gather of every finished part under the later parts, one unpack
 // per rank.  in[r] / out[r]: the replicated input and the gathered output on rank r's device.  Asynchronous: the caller
 // waits for the compute streams (dist_sync), which wait for the unpacks.
 int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, const std::vector<double *> &out)
 {
   const int n = D->n;
-  // the cuts belong to the kernel the options select NOW (strict_order / reproducible / spmv_kernel set since the plan was
-  // made move the product to another kernel, which finishes its rows elsewhere): plan again when they moved
-  {
-    bool same = true;
-    std::vector<int> now((size_t)S.nparts + 1);
-    for (int r = 0; same && r < n; ++r) {
-      if (S.bounds[(size_t)r + 1] == S.bounds[(size_t)r]) continue;
-      FS_HIP(hipSetDevice(D->dev[r]));
-      if (int rc = fs_spmv_part_rows(S.shard[(size_t)r], 0, S.nparts, now.data())) return rc;
-      same = now == S.cut[(size_t)r];
-    }
-    if (!same) {
-      if (int rc = dist_sync(D)) return rc;
-      free_plan(D, S);
-      if (int rc = plan_side(D, S, S.nparts)) return rc;
-    }
-  }
+  if (int rc = replan_if_moved(D, S)) return rc;
   const int np = S.nparts;
+  if (D->conservative || np == 1) {
+    // one whole-shard all-gather behind the finished local product: no window reaches into rows still being written
+    for (int r = 0; r < n; ++r) {
+      const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+      FS_HIP(hipSetDevice(D->dev[r]));
+      if (nl > 0)
+        for (int p = 0; p < np; ++p)
+          if (int rc = fs_spmv_part(S.shard[(size_t)r], 0, S.local[(size_t)r], in[(size_t)r], p, np, D->stream[r])) return rc;
+    }
+    return dist_gather(D, S, S.local, out);
+  }
   for (int p = 0; p < np; ++p) {
+    std::vector<const double *> send((size_t)n);
+    std::vector<double *> recv((size_t)n);
+    std::vector<hipEvent_t> ready((size_t)n);
     for (int r = 0; r < n; ++r) {
       const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
       FS_HIP(hipSetDevice(D->dev[r]));
@@ -276,30 +403,27 @@ int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, cons
         if (int rc = fs_spmv_part(S.shard[(size_t)r], 0, S.local[(size_t)r], in[(size_t)r], p, np, D->stream[r])) return rc;
       FS_HIP(hipEventRecord(S.ev[(size_t)r][(size_t)p], D->stream[r]));
       FS_HIP(hipStreamWaitEvent(D->comm_stream[r], S.ev[(size_t)r][(size_t)p], 0));
+      send[(size_t)r] = S.local[(size_t)r] + S.cut[(size_t)r][(size_t)p];
+      recv[(size_t)r] = S.pad[(size_t)r] + S.off[(size_t)p];
+      ready[(size_t)r] = S.ev[(size_t)r][(size_t)p];
     }
-    const size_t count = (size_t)S.maxc[(size_t)p];
-    if (!count) continue;
-    if (D->use_rccl) {
-      // every rank's call of this part in one group; an error inside the group still closes it
-      ncclResult_t first = rccl().GroupStart();
-      if (first != ncclSuccess) return nccl_fail(first, "ncclGroupStart");
-      for (int r = 0; r < n && first == ncclSuccess; ++r)
-        first = rccl().AllGather(S.local[(size_t)r] + S.cut[(size_t)r][(size_t)p], S.pad[(size_t)r] + S.off[(size_t)p], count, ncclDouble,
-                                 D->comm[(size_t)r], D->comm_stream[r]);
-      const ncclResult_t end = rccl().GroupEnd();
-      if (first != ncclSuccess) return nccl_fail(first, "ncclAllGather");
-      if (end != ncclSuccess) return nccl_fail(end, "ncclGroupEnd");
-    } else {
-      // virtual ranks on one device (see the header comment): every rank's window is copied into every rank's padded buffer
-      // -- the layout an all-gather of `count` elements per rank leaves
-      for (int d = 0; d < n; ++d) {
-        FS_HIP(hipSetDevice(D->dev[d]));
+    const bool inject = !D->fail_injected && env_fail_part() == p;
+    if (inject) D->fail_injected = true;
+    if (int rc = exchange_equal(D, send, recv, (size_t)S.maxc[(size_t)p], D->comm_stream, ready, inject)) {
+      // a failed group call: finish the local product, then ONE whole-shard all-gather -- and stay conservative from now on.
+      // (if that fails too, the error goes to the caller)
+      static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
+      if (trace) fprintf(stderr, "[fastsparse] the exchange of part %d failed (%s): conservative mode from here on\n", p, fs_last_error());
+      (void)rc;
+      D->conservative = true;
+      for (int q = p + 1; q < np; ++q)
         for (int r = 0; r < n; ++r) {
-          FS_HIP(hipStreamWaitEvent(D->comm_stream[d], S.ev[(size_t)r][(size_t)p], 0));
-          FS_HIP(hipMemcpyAsync(S.pad[(size_t)d] + S.off[(size_t)p] + (int64_t)r * (int64_t)count, S.local[(size_t)r] + S.cut[(size_t)r][(size_t)p],
-                                sizeof(double) * count, hipMemcpyDeviceToDevice, D->comm_stream[d]));
+          if (S.bounds[(size_t)r + 1] == S.bounds[(size_t)r]) continue;
+          FS_HIP(hipSetDevice(D->dev[r]));
+          if (int rc2 = fs_spmv_part(S.shard[(size_t)r], 0, S.local[(size_t)r], in[(size_t)r], q, np, D->stream[r])) return rc2;
         }
-      }
+      if (int rc2 = dist_sync(D)) return rc2;        // whatever of the failed exchange was enqueued has drained
+      return dist_gather(D, S, S.local, out);
     }
   }
   for (int r = 0; r < n; ++r) {
@@ -381,6 +505,50 @@ int make_shards(fs_dist_t D, DistSide &S, int nrow, int ncol, const RP *row_ptr,
   return plan_side(D, S, env_parts());
 }
 
+fs_dist_matrix_t new_dist_matrix(fs_dist_t D, int nrow, int ncol)
+{
+  fs_dist_matrix_t M = new fs_dist_matrix_s();
+  M->D = D; M->nrow = nrow; M->ncol = ncol;
+  const int n = D->n;
+  M->x.assign((size_t)n, nullptr);
+  M->y.assign((size_t)n, nullptr);
+  M->z.assign((size_t)n, nullptr);
+  return M;
+}
+
+bool alloc_xy(fs_dist_matrix_t M)
+{
+  fs_dist_t D = M->D;
+  bool ok = true;
+  for (int r = 0; ok && r < D->n; ++r) {
+    ok = hipSetDevice(D->dev[r]) == hipSuccess;
+    ok = ok && hipMalloc(&M->x[(size_t)r], sizeof(double) * (size_t)(M->ncol ? M->ncol : 1)) == hipSuccess;
+    ok = ok && hipMalloc(&M->y[(size_t)r], sizeof(double) * (size_t)(M->nrow ? M->nrow : 1)) == hipSuccess;
+    if (!ok) fs::set_error("fs_dist: out of device memory for the replicated vectors");
+  }
+  return ok;
+}
+
+// after the shards of A' exist: their plan and the z vectors
+int finish_transpose(fs_dist_matrix_t M)
+{
+  fs_dist_t D = M->D;
+  DistSide &T = M->t;
+  int rc = plan_side(D, T, env_parts());
+  for (int r = 0; rc == FS_OK && r < D->n; ++r) {
+    if (hipSetDevice(D->dev[r]) != hipSuccess || hipMalloc(&M->z[(size_t)r], sizeof(double) * (size_t)(M->ncol ? M->ncol : 1)) != hipSuccess) {
+      fs::set_error("fs_dist_matrix_build_transpose: out of device memory");
+      rc = FS_ERR_HIP;
+    }
+  }
+  if (rc != FS_OK) {
+    for (int r = 0; r < D->n; ++r)
+      if (M->z[(size_t)r]) { (void)hipSetDevice(D->dev[r]); (void)hipFree(M->z[(size_t)r]); M->z[(size_t)r] = nullptr; }
+    free_side(D, T);
+  }
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -390,9 +558,11 @@ fs_dist_t fs_dist_create(int ndev, const int *devices)
   int visible = 0;
   if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { fs::set_error("fs_dist_create: no HIP device"); return nullptr; }
   if (ndev < 1) ndev = visible;
+  if (ndev > 64) { fs::set_error("fs_dist_create: at most 64 ranks"); return nullptr; }
   DeviceGuard guard;
   fs_dist_t D = new fs_dist_s();
   D->n = ndev;
+  D->conservative = env_parts() == 1;
   bool distinct = true;
   for (int r = 0; r < ndev; ++r) {
     const int d = devices ? devices[r] : r;
@@ -441,6 +611,7 @@ void fs_dist_destroy(fs_dist_t D)
 
 int fs_dist_ndev(fs_dist_t D) { return D ? D->n : FS_ERR_ARG; }
 int fs_dist_uses_rccl(fs_dist_t D) { return D ? (int)D->use_rccl : FS_ERR_ARG; }
+int fs_dist_is_conservative(fs_dist_t D) { return D ? (int)D->conservative : FS_ERR_ARG; }
 
 void fs_dist_matrix_destroy(fs_dist_matrix_t M)
 {
@@ -449,6 +620,7 @@ void fs_dist_matrix_destroy(fs_dist_matrix_t M)
   (void)dist_sync(M->D);
   free_side(M->D, M->a);
   free_side(M->D, M->t);
+  free_cg(M->D, M->cg);
   for (size_t r = 0; r < (size_t)M->D->n; ++r) {
     (void)hipSetDevice(M->D->dev[r]);
     if (r < M->x.size() && M->x[r]) (void)hipFree(M->x[r]);
@@ -464,19 +636,54 @@ fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz
 {
   if (!D || nrow < 0 || ncol < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !cols)) { fs::set_error("fs_dist_csr_create: bad argument"); return nullptr; }
   DeviceGuard guard;
-  fs_dist_matrix_t M = new fs_dist_matrix_s();
-  M->D = D; M->nrow = nrow; M->ncol = ncol; M->nnz = nnz;
+  fs_dist_matrix_t M = new_dist_matrix(D, nrow, ncol);
+  M->nnz = nnz;
+  const bool ok = make_shards(D, M->a, nrow, ncol, row_ptr, cols, vals) == FS_OK && alloc_xy(M);
+  if (!ok) { fs_dist_matrix_destroy(M); return nullptr; }
+  return M;
+}
+
+// The matrix as the caller already holds it: one CSR per rank -- shard r = rows [sum of shard_rows[0 .. r), + shard_rows[r]) of
+// A with a LOCAL row_ptr (shard_rows[r] + 1 ints, starting at 0), GLOBAL column ids and optional values.  Nothing here ever
+// sees the whole matrix, so the total number of entries may exceed 2^31 - 1 (every shard stays below: int row_ptr,
+// csr.h:358-366) -- BASELINE config 5 (3.2 G entries) comes in this way.  space = FS_HOST: host arrays; FS_DEVICE: shard r's
+// arrays live on rank r's device (they are copied: the caller may free them).  The caller chooses the cuts (balance by
+// non-zeros for power-law matrices).
+fs_dist_matrix_t fs_dist_csr_create_from_shards(fs_dist_t D, int nrow, int ncol, const int *shard_rows, const int64_t *shard_nnz,
+                                                const int *const *row_ptr, const int *const *cols, const double *const *vals, int space)
+{
+  if (!D || nrow < 0 || ncol < 0 || !shard_rows || !shard_nnz || !row_ptr || !cols) { fs::set_error("fs_dist_csr_create_from_shards: bad argument"); return nullptr; }
   const int n = D->n;
-  M->x.assign((size_t)n, nullptr);
-  M->y.assign((size_t)n, nullptr);
-  M->z.assign((size_t)n, nullptr);
-  bool ok = make_shards(D, M->a, nrow, ncol, row_ptr, cols, vals) == FS_OK;
-  for (int r = 0; ok && r < n; ++r) {
-    ok = hipSetDevice(D->dev[r]) == hipSuccess;
-    ok = ok && hipMalloc(&M->x[(size_t)r], sizeof(double) * (size_t)(ncol ? ncol : 1)) == hipSuccess;
-    ok = ok && hipMalloc(&M->y[(size_t)r], sizeof(double) * (size_t)(nrow ? nrow : 1)) == hipSuccess;
-    if (!ok) fs::set_error("fs_dist_csr_create: out of device memory");
+  int64_t rows = 0, nnz = 0;
+  for (int r = 0; r < n; ++r) {
+    if (shard_rows[r] < 0 || shard_nnz[r] < 0 || shard_nnz[r] > 0x7fffffffll || !row_ptr[r] || (shard_nnz[r] > 0 && !cols[r])) {
+      fs::set_error("fs_dist_csr_create_from_shards: bad shard (each holds 0 .. 2^31-1 entries)");
+      return nullptr;
+    }
+    rows += shard_rows[r];
+    nnz += shard_nnz[r];
   }
+  if (rows != nrow) { fs::set_error("fs_dist_csr_create_from_shards: the shards' rows do not add up to nrow"); return nullptr; }
+  const bool valued = vals && n > 0 && vals[0] != nullptr;
+  for (int r = 0; r < n; ++r)
+    if (shard_nnz[r] > 0 && (valued != (vals && vals[r] != nullptr))) { fs::set_error("fs_dist_csr_create_from_shards: values for some shards only"); return nullptr; }
+  DeviceGuard guard;
+  fs_dist_matrix_t M = new_dist_matrix(D, nrow, ncol);
+  M->nnz = nnz;
+  DistSide &S = M->a;
+  S.nrow = nrow; S.ncol = ncol;
+  S.bounds.assign((size_t)n + 1, 0);
+  S.shard.assign((size_t)n, nullptr);
+  S.shard_nnz.assign((size_t)n, 0);
+  bool ok = true;
+  for (int r = 0; ok && r < n; ++r) {
+    S.bounds[(size_t)r + 1] = S.bounds[(size_t)r] + shard_rows[r];
+    S.shard_nnz[(size_t)r] = shard_nnz[r];
+    ok = hipSetDevice(D->dev[r]) == hipSuccess;
+    if (ok) S.shard[(size_t)r] = fs_csr_create(shard_rows[r], ncol, shard_nnz[r], row_ptr[r], cols[r], valued ? vals[r] : nullptr, space, 0);
+    ok = ok && S.shard[(size_t)r] != nullptr;
+  }
+  ok = ok && plan_side(D, S, env_parts()) == FS_OK && alloc_xy(M);
   if (!ok) { fs_dist_matrix_destroy(M); return nullptr; }
   return M;
 }
@@ -534,19 +741,122 @@ int fs_dist_matrix_build_transpose(fs_dist_matrix_t M, const int *row_ptr, const
   int rc = FS_OK;
   for (int r = 0; r < n; ++r)
     if (rcs[(size_t)r] != FS_OK) { rc = rcs[(size_t)r]; fs::set_error("fs_dist_matrix_build_transpose: " + errs[(size_t)r]); }
-  if (rc == FS_OK) rc = plan_side(D, T, env_parts());
-  for (int r = 0; rc == FS_OK && r < n; ++r) {
-    if (hipSetDevice(D->dev[r]) != hipSuccess || hipMalloc(&M->z[(size_t)r], sizeof(double) * (size_t)(ncol ? ncol : 1)) != hipSuccess) {
-      fs::set_error("fs_dist_matrix_build_transpose: out of device memory");
-      rc = FS_ERR_HIP;
+  if (rc != FS_OK) { free_side(D, T); return rc; }
+  return finish_transpose(M);
+}
+
+// The same shards of A' with no host array of the matrix anywhere: built from the device-resident shards of A.
+//   1  every rank counts its entries per column; the counts are added up on rank 0's device and cut by non-zeros there
+//      (the cut of nnz_cut: the same bounds fs_dist_matrix_build_transpose finds on the host);
+//   2  every rank partitions its entries stably by the rank that will own their column (fs::shard_transpose_partition);
+//   3  the parts travel device to device (hipMemcpyPeerAsync: one process, so no collective is needed for a one-time build;
+//      with virtual ranks these are copies inside one device), concatenated per destination in source-rank order;
+//   4  every rank orders what it received by row of A' -- fs_coo_create's stable sort -- which leaves each row of A' in
+//      ascending A-row order.
+// Temporary HBM per rank: about 30 bytes per entry sent plus 16 per entry received.  Idempotent.
+int fs_dist_matrix_build_transpose_device(fs_dist_matrix_t M)
+{
+  if (!M) { fs::set_error("fs_dist_matrix_build_transpose_device: NULL handle"); return FS_ERR_ARG; }
+  std::lock_guard<std::mutex> g(M->lock);
+  if (M->t.built) return FS_OK;
+  DeviceGuard guard;
+  fs_dist_t D = M->D;
+  const int n = D->n, nrow = M->nrow, ncol = M->ncol;
+  if (int rc = dist_sync(D)) return rc;
+  const bool valued = [&] { for (int r = 0; r < n; ++r) if (M->a.shard_nnz[(size_t)r] > 0) return M->a.shard[(size_t)r]->a.vals != nullptr; return false; }();
+  DistSide &T = M->t;
+  T.nrow = ncol; T.ncol = nrow;
+  T.bounds.assign((size_t)n + 1, 0);
+  T.shard.assign((size_t)n, nullptr);
+  T.shard_nnz.assign((size_t)n, 0);
+  struct Tmp {
+    fs_dist_t D;
+    std::vector<int *> cnt, trow, tcol, rrow, rcol;
+    std::vector<double *> tval, rval;
+    ~Tmp()
+    {
+      for (size_t r = 0; r < cnt.size(); ++r) {
+        (void)hipSetDevice(D->dev[r]);
+        for (void *p : {(void *)cnt[r], (void *)trow[r], (void *)tcol[r], (void *)rrow[r], (void *)rcol[r], (void *)tval[r], (void *)rval[r]})
+          if (p) (void)hipFree(p);
+      }
+    }
+  } W{D};
+  W.cnt.assign((size_t)n, nullptr); W.trow.assign((size_t)n, nullptr); W.tcol.assign((size_t)n, nullptr);
+  W.rrow.assign((size_t)n, nullptr); W.rcol.assign((size_t)n, nullptr);
+  W.tval.assign((size_t)n, nullptr); W.rval.assign((size_t)n, nullptr);
+  // 1: column counts, added up on rank 0's device
+  const size_t cbytes = sizeof(int) * (size_t)(ncol ? ncol : 1);
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    FS_HIP(hipMalloc(&W.cnt[(size_t)r], cbytes));
+    FS_HIP(hipMemsetAsync(W.cnt[(size_t)r], 0, cbytes, D->stream[r]));
+    if (int rc = fs::shard_column_counts(M->a.shard[(size_t)r]->a, W.cnt[(size_t)r], D->stream[r])) return rc;
+  }
+  if (int rc = dist_sync(D)) return rc;
+  {
+    int *tmp = nullptr;
+    FS_HIP(hipSetDevice(D->dev[0]));
+    if (n > 1) FS_HIP(hipMalloc(&tmp, cbytes));
+    int rc = FS_OK;
+    for (int r = 1; r < n && rc == FS_OK; ++r) {
+      if (hipMemcpyPeerAsync(tmp, D->dev[0], W.cnt[(size_t)r], D->dev[r], cbytes, D->stream[0]) != hipSuccess) { fs::set_error("fs_dist_matrix_build_transpose_device: peer copy of the column counts failed"); rc = FS_ERR_HIP; break; }
+      rc = fs::add_counts(ncol, W.cnt[0], tmp, D->stream[0]);
+    }
+    int64_t total = 0;
+    if (rc == FS_OK) rc = fs::cut_by_counts(ncol, W.cnt[0], n, T.bounds.data(), &total, D->stream[0]);
+    if (tmp) (void)hipFree(tmp);
+    if (rc != FS_OK) { T = DistSide(); return rc; }
+    if (total != M->nnz) { fs::set_error("fs_dist_matrix_build_transpose_device: the column counts do not add up to nnz"); T = DistSide(); return FS_ERR_ARG; }
+  }
+  // 2: every rank's entries by destination
+  std::vector<std::vector<int64_t>> count((size_t)n, std::vector<int64_t>((size_t)n, 0));   // [source][destination]
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    (void)hipFree(W.cnt[(size_t)r]); W.cnt[(size_t)r] = nullptr;
+    if (int rc = fs::shard_transpose_partition(M->a.shard[(size_t)r]->a, M->a.bounds[(size_t)r], n, T.bounds.data(), &W.trow[(size_t)r], &W.tcol[(size_t)r],
+                                               &W.tval[(size_t)r], count[(size_t)r].data(), D->stream[r])) { T = DistSide(); return rc; }
+  }
+  // 3: the exchange
+  for (int d = 0; d < n; ++d) {
+    int64_t cnt = 0;
+    for (int r = 0; r < n; ++r) cnt += count[(size_t)r][(size_t)d];
+    T.shard_nnz[(size_t)d] = cnt;
+    if (cnt > 0x7fffffffll) { fs::set_error("fs_dist_matrix_build_transpose_device: a shard of A' holds more than 2^31-1 non-zeros: use more devices"); T = DistSide(); return FS_ERR_ARG; }
+    FS_HIP(hipSetDevice(D->dev[d]));
+    const size_t c1 = (size_t)(cnt ? cnt : 1);
+    FS_HIP(hipMalloc(&W.rrow[(size_t)d], sizeof(int) * c1));
+    FS_HIP(hipMalloc(&W.rcol[(size_t)d], sizeof(int) * c1));
+    if (valued) FS_HIP(hipMalloc(&W.rval[(size_t)d], sizeof(double) * c1));
+  }
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    int64_t soff = 0;
+    for (int d = 0; d < n; ++d) {
+      const int64_t c = count[(size_t)r][(size_t)d];
+      int64_t doff = 0;
+      for (int q = 0; q < r; ++q) doff += count[(size_t)q][(size_t)d];
+      if (c > 0) {
+        FS_HIP(hipMemcpyPeerAsync(W.rrow[(size_t)d] + doff, D->dev[d], W.trow[(size_t)r] + soff, D->dev[r], sizeof(int) * (size_t)c, D->stream[r]));
+        FS_HIP(hipMemcpyPeerAsync(W.rcol[(size_t)d] + doff, D->dev[d], W.tcol[(size_t)r] + soff, D->dev[r], sizeof(int) * (size_t)c, D->stream[r]));
+        if (valued) FS_HIP(hipMemcpyPeerAsync(W.rval[(size_t)d] + doff, D->dev[d], W.tval[(size_t)r] + soff, D->dev[r], sizeof(double) * (size_t)c, D->stream[r]));
+      }
+      soff += c;
     }
   }
-  if (rc != FS_OK) {
-    for (int r = 0; r < n; ++r)
-      if (M->z[(size_t)r]) { (void)hipSetDevice(D->dev[r]); (void)hipFree(M->z[(size_t)r]); M->z[(size_t)r] = nullptr; }
-    free_side(D, T);
+  if (int rc = dist_sync(D)) { T = DistSide(); return rc; }
+  // 4: the local builds
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    for (void **p : {(void **)&W.trow[(size_t)d], (void **)&W.tcol[(size_t)d], (void **)&W.tval[(size_t)d]})
+      if (*p) { (void)hipFree(*p); *p = nullptr; }
+    T.shard[(size_t)d] = fs_coo_create(T.bounds[(size_t)d + 1] - T.bounds[(size_t)d], nrow, T.shard_nnz[(size_t)d], W.rrow[(size_t)d], W.rcol[(size_t)d],
+                                       valued ? W.rval[(size_t)d] : nullptr, FS_DEVICE);
+    if (!T.shard[(size_t)d]) { free_side(D, T); return FS_ERR_HIP; }
+    for (void **p : {(void **)&W.rrow[(size_t)d], (void **)&W.rcol[(size_t)d], (void **)&W.rval[(size_t)d]})
+      if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
-  return rc;
+  return finish_transpose(M);
 }
 
 int fs_dist_matrix_has_transpose(fs_dist_matrix_t M) { return M && M->t.built; }
@@ -558,10 +868,25 @@ int fs_dist_matrix_bounds(fs_dist_matrix_t M, int *bounds)
   return FS_OK;
 }
 
+int fs_dist_matrix_bounds_t(fs_dist_matrix_t M, int *bounds)
+{
+  if (!M || !bounds || !M->t.built) return FS_ERR_ARG;
+  for (size_t i = 0; i < M->t.bounds.size(); ++i) bounds[i] = M->t.bounds[i];
+  return FS_OK;
+}
+
 int64_t fs_dist_matrix_shard_nnz(fs_dist_matrix_t M, int rank)
 {
   if (!M || rank < 0 || rank >= M->D->n) return FS_ERR_ARG;
   return M->a.shard_nnz[(size_t)rank];
+}
+
+int64_t fs_dist_matrix_nnz(fs_dist_matrix_t M) { return M ? M->nnz : FS_ERR_ARG; }
+
+fs_matrix_t fs_dist_matrix_shard(fs_dist_matrix_t M, int rank, int transposed)
+{
+  if (!M || rank < 0 || rank >= M->D->n || (transposed && !M->t.built)) return nullptr;
+  return (transposed ? M->t : M->a).shard[(size_t)rank];
 }
 
 int fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host)
@@ -622,12 +947,21 @@ int fs_dist_swap_xy(fs_dist_matrix_t M)
   return FS_OK;
 }
 
-// (A'A + lambda I) x = b on the row-sharded matrix: bsbm_cg (cg.h:25-82) across the GPUs, everything resident.  Every device
-// keeps the WHOLE x, r, p, q (fs_dist_x is p, fs_dist_z is q) and runs the same fused vector kernels on them -- identical
-// inputs, identical kernels, so every device holds identical vectors and the dots need no exchange: the host reads 8 bytes
-// from device 0 per reduction.  Per iteration: y = A p and q = A' y, each with its all-gather inside the product.  The O(F)
-// vector work is replicated, not divided, by the number of devices (libfastsparse_amd/dist.py ShardedCG's "gather" scheme
-// divides it; here the products dominate).  b_host / x_host: F = ncol doubles on the host.
+// (A'A + lambda I) x = b on the row-sharded matrix: bsbm_cg (cg.h:25-82) across the GPUs, everything resident, the scalars of
+// the iteration on the devices (fs_cg.hip).  Per iteration y = A p and q = A' y; two schemes for everything else (option
+// "dist_cg_scheme"):
+//   0 "replicate"  every device keeps the WHOLE x, r, p, q and runs the same fused vector kernels on them -- identical inputs,
+//                  identical kernels, identical vectors: the dots need no exchange.  Both products carry their all-gather.
+//                  The O(F) vector work is done N times over.
+//   1 "gather"     (libfastsparse_amd/dist.py ShardedCG's scheme) rank r keeps ITS SLICE of x, r, p, q -- the rows of A' it owns.
+//                  q_r = A'_r y needs no exchange; the dots are partial: every rank's partial is all-gathered (8 bytes per
+//                  rank) and every rank adds the N values in rank order, so all ranks hold identical scalars; the new p slice is
+//                  all-gathered (whole-shard exchange) for the next product.  The vector work is divided by N; two tiny
+//                  exchanges per iteration are added.
+// Either way EVERY device decides convergence for itself and the host compares the flags of all of them one iteration behind:
+// a disagreement (which identical arithmetic rules out, and a faulty device or exchange does not) is an error return, never a
+// rank waiting in a collective for one that left.  Products run with fixed-order sums unless option "cg_fixed_order" is 0.
+// Work vectors are kept on the handle between solves.  CLOBBERS fs_dist_x / fs_dist_y / fs_dist_z of the handle.
 int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double lambda, double tol, int *out_iter)
 {
   if (!M || !x_host || !b_host) { fs::set_error("fs_dist_cg: NULL argument"); return FS_ERR_ARG; }
@@ -635,62 +969,145 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
   std::lock_guard<std::mutex> g(M->lock);
   std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
+  fs::FixedOrderScope fixed(fs::options().cg_fixed_order != 0);
   fs_dist_t D = M->D;
   const int n = D->n, F = M->ncol;
-  struct Work {
-    fs_dist_t D;
-    std::vector<double *> sol, r, b, part, red, st;
-    ~Work()
-    {
-      for (size_t d = 0; d < sol.size(); ++d) {
-        (void)hipSetDevice(D->dev[d]);
-        for (double *p : {sol[d], r[d], b[d], part[d], red[d], st[d]})
-          if (p) (void)hipFree(p);
-      }
-    }
-  } W{D, std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr),
-      std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr), std::vector<double *>((size_t)n, nullptr)};
-  for (int d = 0; d < n; ++d) {
-    FS_HIP(hipSetDevice(D->dev[d]));
-    FS_HIP(hipMalloc(&W.sol[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
-    FS_HIP(hipMalloc(&W.r[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
-    FS_HIP(hipMalloc(&W.b[(size_t)d], sizeof(double) * (size_t)(F ? F : 1)));
-    FS_HIP(hipMalloc(&W.part[(size_t)d], sizeof(double) * fs::kCgPartDoubles));
-    FS_HIP(hipMalloc(&W.red[(size_t)d], sizeof(double) * 4));
-    FS_HIP(hipMalloc(&W.st[(size_t)d], sizeof(double) * fs::kCgStateDoubles));
-  }
-  if (int rc = upload_all(M, W.b, b_host, (size_t)F)) return rc;
-  // the scalars of the iteration stay on every device (the same kernels on the same data: every device decides alike); the
-  // host watches device 0's done flag one iteration behind (see fs_cg.hip)
-  fs::CgFlags fl;
-  FS_HIP(hipSetDevice(D->dev[0]));
-  if (int rc = fl.init()) return rc;
-  for (int d = 0; d < n; ++d) {
-    FS_HIP(hipSetDevice(D->dev[d]));
-    if (int rc = fs::cg_dev_init(F, W.b[(size_t)d], W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d],
-                                 W.st[(size_t)d], tol, D->stream[d])) return rc;
-  }
-  for (int iter = 0; iter < F; iter++) {
-    if (int rc = dist_product(D, M->a, M->x, M->y)) return rc;      // y = A p
-    if (int rc = dist_product(D, M->t, M->y, M->z)) return rc;      // q = A' y
+  const bool gather = fs::options().dist_cg_scheme == 1 && n > 1;
+  DistSide &T = M->t;
+  CgWork &W = M->cg;
+  if (W.F != F || W.sol.empty()) {
+    free_cg(D, W);
+    for (auto *v : {&W.sol, &W.r, &W.b, &W.p, &W.q, &W.part, &W.red, &W.redall, &W.st}) v->assign((size_t)n, nullptr);
+    W.F = F;
+    const size_t fl = (size_t)(F ? F : 1) + (size_t)T.max_rows + 1;       // (a slice is sent as a window of max_rows doubles)
     for (int d = 0; d < n; ++d) {
       FS_HIP(hipSetDevice(D->dev[d]));
-      if (int rc = fs::cg_dev_steps(F, lambda, W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], M->z[(size_t)d], W.part[(size_t)d],
-                                    W.red[(size_t)d], W.st[(size_t)d], D->stream[d])) return rc;
+      FS_HIP(hipMalloc(&W.sol[(size_t)d], sizeof(double) * fl));
+      FS_HIP(hipMalloc(&W.r[(size_t)d], sizeof(double) * fl));
+      FS_HIP(hipMalloc(&W.b[(size_t)d], sizeof(double) * fl));
+      FS_HIP(hipMalloc(&W.p[(size_t)d], sizeof(double) * fl));
+      FS_HIP(hipMalloc(&W.q[(size_t)d], sizeof(double) * fl));
+      FS_HIP(hipMalloc(&W.part[(size_t)d], sizeof(double) * fs::kCgPartDoubles));
+      FS_HIP(hipMalloc(&W.red[(size_t)d], sizeof(double) * 4));
+      FS_HIP(hipMalloc(&W.redall[(size_t)d], sizeof(double) * (size_t)(n + 1)));
+      FS_HIP(hipMalloc(&W.st[(size_t)d], sizeof(double) * fs::kCgStateDoubles));
     }
-    bool stop = false;
-    FS_HIP(hipSetDevice(D->dev[0]));
-    if (int rc = fl.after_iteration(iter, W.st[0], D->stream[0], &stop)) return rc;
-    if (stop) break;
   }
-  double fin[2] = {0.0, 0.0};
-  FS_HIP(hipSetDevice(D->dev[0]));
-  FS_HIP(hipMemcpyAsync(fin, W.st[0] + fs::kCgStateDone, sizeof(fin), hipMemcpyDeviceToHost, D->stream[0]));
-  FS_HIP(hipStreamSynchronize(D->stream[0]));
-  const int iter = (int)fin[1];
-  if (int rc = download_from(M, 0, x_host, W.sol[0], (size_t)F)) return rc;
+  if (int rc = upload_all(M, W.b, b_host, (size_t)F)) return rc;
+  // one set of host-visible flags per device
+  std::vector<fs::CgFlags> fl((size_t)n);
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    if (int rc = fl[(size_t)d].init()) return rc;
+  }
+  std::vector<hipEvent_t> none((size_t)n, nullptr);
+  // the sum over the ranks of every rank's red[0] (left there by a partial reduction), in rank order, then the scalar step `mode`
+  // (send slots red[0] / red[1] alternate: a rank may be one exchange ahead of another that still reads its previous partial;
+  // the scalar step leaves its sum in red[2])
+  int slot = 0;
+  auto combine = [&](int mode, double arg) -> int {
+    std::vector<const double *> send((size_t)n);
+    std::vector<hipEvent_t> ready((size_t)n);
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      send[(size_t)d] = W.red[(size_t)d] + slot;
+      FS_HIP(hipEventRecord(T.ev[(size_t)d][0], D->stream[d]));
+      ready[(size_t)d] = T.ev[(size_t)d][0];
+    }
+    if (int rc = exchange_equal(D, send, W.redall, 1, D->stream, ready)) return rc;
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg_dev_final(mode, W.redall[(size_t)d], n, W.red[(size_t)d] + 2, W.st[(size_t)d], arg, D->stream[d])) return rc;
+    }
+    slot ^= 1;
+    return FS_OK;
+  };
+  if (!gather) {
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg_dev_init(F, W.b[(size_t)d], W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d],
+                                   W.st[(size_t)d], tol, D->stream[d])) return rc;
+    }
+  } else {
+    for (int d = 0; d < n; ++d) {
+      const int lo = T.bounds[(size_t)d], nl = T.bounds[(size_t)d + 1] - lo;
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg_dev_init_partial(nl, W.b[(size_t)d] + lo, W.sol[(size_t)d], W.r[(size_t)d], W.p[(size_t)d], W.part[(size_t)d], W.red[(size_t)d] + slot,
+                                           D->stream[d])) return rc;
+    }
+    if (int rc = combine(0, tol)) return rc;
+    if (int rc = dist_gather(D, T, W.p, M->x)) return rc;                // the whole p on every rank
+  }
+  int rc_loop = FS_OK;
+  for (int iter = 0; iter < F; iter++) {
+    if (int rc = dist_product(D, M->a, M->x, M->y)) return rc;           // y = A p, its all-gather inside
+    if (!gather) {
+      if (int rc = dist_product(D, T, M->y, M->z)) return rc;            // q = A' y, its all-gather inside
+      for (int d = 0; d < n; ++d) {
+        FS_HIP(hipSetDevice(D->dev[d]));
+        if (int rc = fs::cg_dev_steps(F, lambda, W.sol[(size_t)d], W.r[(size_t)d], M->x[(size_t)d], M->z[(size_t)d], W.part[(size_t)d],
+                                      W.red[(size_t)d], W.st[(size_t)d], D->stream[d])) return rc;
+      }
+    } else {
+      for (int d = 0; d < n; ++d) {                                      // q_r = A'_r y: this rank's rows of A', no exchange
+        const int nl = T.bounds[(size_t)d + 1] - T.bounds[(size_t)d];
+        FS_HIP(hipSetDevice(D->dev[d]));
+        if (nl > 0)
+          if (int rc = fs_spmv(T.shard[(size_t)d], W.q[(size_t)d], M->y[(size_t)d], D->stream[d])) return rc;
+        if (int rc = fs::cg_dev_step_a(nl, lambda, W.p[(size_t)d], W.q[(size_t)d], W.part[(size_t)d], W.red[(size_t)d] + slot, W.st[(size_t)d], D->stream[d])) return rc;
+      }
+      if (int rc = combine(1, 0.0)) return rc;                            // alpha
+      for (int d = 0; d < n; ++d) {
+        const int nl = T.bounds[(size_t)d + 1] - T.bounds[(size_t)d];
+        FS_HIP(hipSetDevice(D->dev[d]));
+        if (int rc = fs::cg_dev_step_b(nl, W.sol[(size_t)d], W.r[(size_t)d], W.p[(size_t)d], W.q[(size_t)d], W.part[(size_t)d], W.red[(size_t)d] + slot,
+                                       W.st[(size_t)d], D->stream[d])) return rc;
+      }
+      if (int rc = combine(2, 0.0)) return rc;                            // converged?  beta
+      for (int d = 0; d < n; ++d) {
+        const int nl = T.bounds[(size_t)d + 1] - T.bounds[(size_t)d];
+        FS_HIP(hipSetDevice(D->dev[d]));
+        if (int rc = fs::cg_dev_step_c(nl, W.p[(size_t)d], W.r[(size_t)d], W.st[(size_t)d], D->stream[d])) return rc;
+      }
+      if (int rc = dist_gather(D, T, W.p, M->x)) return rc;              // the new p on every rank
+    }
+    int stops = 0;
+    for (int d = 0; d < n; ++d) {
+      bool stop = false;
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fl[(size_t)d].after_iteration(iter, W.st[(size_t)d], D->stream[d], &stop)) return rc;
+      stops += stop ? 1 : 0;
+    }
+    if (stops != 0 && stops != n) {
+      fs::set_error("fs_dist_cg: the devices disagree about convergence (a device or an exchange returned different bits)");
+      rc_loop = FS_ERR_HIP;
+      break;
+    }
+    if (stops == n) break;
+  }
   if (int rc = dist_sync(D)) return rc;
-  if (out_iter) *out_iter = iter;
+  if (rc_loop != FS_OK) return rc_loop;
+  // every device's final {done, iterations} must agree as well
+  std::vector<double> fin(2 * (size_t)n, 0.0);
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    FS_HIP(hipMemcpy(&fin[2 * (size_t)d], W.st[(size_t)d] + fs::kCgStateDone, sizeof(double) * 2, hipMemcpyDeviceToHost));
+    if (fin[2 * (size_t)d] != fin[0] || fin[2 * (size_t)d + 1] != fin[1]) {
+      fs::set_error("fs_dist_cg: the devices finished in different states");
+      return FS_ERR_HIP;
+    }
+  }
+  if (!gather) {
+    if (int rc = download_from(M, 0, x_host, W.sol[0], (size_t)F)) return rc;
+  } else {
+    for (int d = 0; d < n; ++d) {
+      const int lo = T.bounds[(size_t)d], nl = T.bounds[(size_t)d + 1] - lo;
+      if (nl > 0)
+        if (int rc = download_from(M, d, x_host + lo, W.sol[(size_t)d], (size_t)nl)) return rc;
+    }
+  }
+  if (int rc = dist_sync(D)) return rc;
+  if (out_iter) *out_iter = (int)fin[1];
   return FS_OK;
 }
 

@@ -123,7 +123,8 @@ struct Scratch {
 static void free_tiled_slot(TiledCsr *&T)
 {
   if (!T) return;
-  void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item};
+  void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item,
+                   T->chunk_ord, T->ticket};
   for (void *q : owned)
     if (q) (void)traced_free(q);
   free(T->h_panel_row);
@@ -139,10 +140,9 @@ static void free_tiledx(DeviceCsr &A) { free_tiled_slot(A.tiledx); }
 static void free_long_rows(LongRows *&L)
 {
   if (!L) return;
-  void *owned[] = {L->row, L->lcol, L->lrow, L->vals, L->band_ptr, L->ylong};
+  void *owned[] = {L->row, L->lcol, L->lrow, L->vals, L->band_ptr, L->seg_ptr, L->ylong, L->ypart};
   for (void *q : owned)
     if (q) (void)traced_free(q);
-  free(L->h_row);
   delete L;
   L = nullptr;
 }
@@ -532,6 +532,171 @@ int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
   // i.e. the order in which the serial loops of At_mul_B (sparse.h:72-74) visit a column's entries
   // when the COO itself is row ordered.
   return coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows.p, A.vals, s);
+}
+
+// ---- row shards of A' from the row shards of A, without any whole-matrix host array -----------------------------------
+// (fs_dist_matrix_build_transpose_device, fs_dist.hip).  BASELINE config 5 (3.2 G entries) only exists as per-device shards:
+// the rows of A' (= columns of A) are cut by non-zeros from per-shard column counts added up on one device, every shard
+// partitions its entries stably by the device that will own their column, the parts travel device to device, and each
+// device orders what it received by row of A' with the stable COO -> CSR above.  Sources hold ascending row ranges of A
+// and are concatenated in rank order, so every row of A' keeps ascending A-row order: the order a stable column sort of
+// the whole matrix gives (what the serial At_mul_B loop, sparse.h:68-75, visits), as fs_matrix_build_transpose on one GPU.
+__global__ void column_count_kernel(int64_t nnz, const int *__restrict__ cols, int *__restrict__ counts)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) atomicAdd(&counts[cols[i]], 1);
+}
+
+__global__ void add_counts_kernel(int64_t n, int *__restrict__ acc, const int *__restrict__ add)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += add[i];
+}
+
+int shard_column_counts(const DeviceCsr &A, int *counts_dev, hipStream_t s)
+{
+  if (A.nnz <= 0) return FS_OK;
+  hipLaunchKernelGGL(column_count_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, A.cols, counts_dev);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int add_counts(int64_t n, int *acc_dev, const int *add_dev, hipStream_t s)
+{
+  if (n <= 0) return FS_OK;
+  hipLaunchKernelGGL(add_counts_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, acc_dev, add_dev);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+// bounds[r] = first item b whose exclusive prefix of counts is >= total * r / nparts (nnz_cut of fs_dist.hip on the device)
+__global__ void cut_kernel(int n_items, const int64_t *__restrict__ inc, int nparts, int *__restrict__ bounds)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nparts) return;
+  const int64_t total = n_items > 0 ? inc[n_items - 1] : 0;
+  if (r == 0) { bounds[0] = 0; return; }
+  if (r == nparts) { bounds[nparts] = n_items; return; }
+  const int64_t target = total / nparts * r + total % nparts * r / nparts;   // total * r / nparts without overflow
+  int lo = 0, hi = n_items;                       // first b in [0, n_items] with prefix(b) >= target, prefix(b) = b ? inc[b - 1] : 0
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    const int64_t pm = mid ? inc[mid - 1] : 0;
+    if (pm < target) lo = mid + 1; else hi = mid;
+  }
+  bounds[r] = lo;
+}
+
+struct IntToI64 { __device__ int64_t operator()(int v) const { return (int64_t)v; } };
+
+int cut_by_counts(int n_items, const int *counts_dev, int nparts, int *bounds_host, int64_t *total, hipStream_t s)
+{
+  Scratch<int64_t> inc;
+  Scratch<int> bd;
+  Scratch<char> tmp;
+  FS_HIP(inc.alloc((size_t)n_items + 1));
+  FS_HIP(bd.alloc((size_t)nparts + 1));
+  if (n_items > 0) {
+    size_t tmp_bytes = 0;
+    auto in = rocprim::make_transform_iterator(counts_dev, IntToI64());
+    FS_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, in, inc.p, (size_t)n_items, rocprim::plus<int64_t>(), s));
+    FS_HIP(tmp.alloc(tmp_bytes));
+    FS_HIP(rocprim::inclusive_scan((void *)tmp.p, tmp_bytes, in, inc.p, (size_t)n_items, rocprim::plus<int64_t>(), s));
+  }
+  hipLaunchKernelGGL(cut_kernel, dim3(grid_for((int64_t)nparts + 1)), dim3(256), 0, s, n_items, inc.p, nparts, bd.p);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipMemcpyAsync(bounds_host, bd.p, sizeof(int) * ((size_t)nparts + 1), hipMemcpyDeviceToHost, s));
+  int64_t tot = 0;
+  if (n_items > 0) FS_HIP(hipMemcpyAsync(&tot, inc.p + (n_items - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  for (int r = 1; r <= nparts; ++r)               // monotone, like nnz_cut
+    if (bounds_host[r] < bounds_host[r - 1]) bounds_host[r] = bounds_host[r - 1];
+  if (total) *total = tot;
+  return FS_OK;
+}
+
+constexpr int kMaxParts = 64;
+
+// key = the part that owns column cols[i]: the last d with bounds[d] <= column (empty parts own nothing); counts per part
+__global__ __launch_bounds__(256) void dest_key_kernel(int64_t nnz, int nparts, const int *__restrict__ bounds, const int *__restrict__ cols,
+                                                      unsigned char *__restrict__ key, unsigned long long *__restrict__ count)
+{
+  __shared__ int sb[kMaxParts + 1];
+  __shared__ unsigned sc[kMaxParts];
+  if (threadIdx.x <= nparts) sb[threadIdx.x] = bounds[threadIdx.x];
+  if (threadIdx.x < nparts) sc[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) {
+    const int c = cols[i];
+    int d = 0;
+    for (int r = 1; r < nparts; ++r) d = sb[r] <= c ? r : d;
+    key[i] = (unsigned char)d;
+    atomicAdd(&sc[d], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nparts && sc[threadIdx.x]) atomicAdd(&count[threadIdx.x], (unsigned long long)sc[threadIdx.x]);
+}
+
+__global__ void transpose_gather_kernel(int64_t nnz, int row_lo, const int *__restrict__ bounds, const unsigned char *__restrict__ skey,
+                                        const unsigned *__restrict__ perm, const int *__restrict__ rows, const int *__restrict__ cols,
+                                        const double *__restrict__ vals, int *__restrict__ trow, int *__restrict__ tcol,
+                                        double *__restrict__ tval)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const unsigned src = perm[i];
+  trow[i] = cols[src] - bounds[skey[i]];          // row of A', local to the part that owns it
+  tcol[i] = row_lo + rows[src];                   // column of A' = global row of A
+  if (vals) tval[i] = vals[src];
+}
+
+// The entries of one row shard of A (first global row row_lo) as entries of A', stably partitioned by owning part:
+// *trow / *tcol / *tval (hipMalloc'ed here, nnz long; *tval = nullptr for a pattern-only shard) hold part 0's entries first, then
+// part 1's ..., each part in the shard's CSR order; count_host[d] = entries of part d.
+int shard_transpose_partition(const DeviceCsr &A, int row_lo, int nparts, const int *bounds_host, int **trow, int **tcol,
+                              double **tval, int64_t *count_host, hipStream_t s)
+{
+  *trow = nullptr; *tcol = nullptr; *tval = nullptr;
+  for (int d = 0; d < nparts; ++d) count_host[d] = 0;
+  if (nparts < 1 || nparts > kMaxParts) { set_error("shard_transpose_partition: 1 to 64 parts"); return FS_ERR_ARG; }
+  const size_t n = (size_t)(A.nnz > 0 ? A.nnz : 1);
+  FS_HIP(traced_malloc(trow, sizeof(int) * n));
+  FS_HIP(traced_malloc(tcol, sizeof(int) * n));
+  if (A.vals) FS_HIP(traced_malloc(tval, sizeof(double) * n));
+  if (A.nnz <= 0) return FS_OK;
+  Scratch<int> rows, bd;
+  Scratch<unsigned char> key, skey;
+  Scratch<unsigned> idx_in, idx_out;
+  Scratch<unsigned long long> cnt;
+  Scratch<char> tmp;
+  FS_HIP(rows.alloc(n));
+  FS_HIP(bd.alloc((size_t)nparts + 1));
+  FS_HIP(key.alloc(n));
+  FS_HIP(skey.alloc(n));
+  FS_HIP(idx_in.alloc(n));
+  FS_HIP(idx_out.alloc(n));
+  FS_HIP(cnt.alloc((size_t)nparts));
+  FS_HIP(hipMemcpyAsync(bd.p, bounds_host, sizeof(int) * ((size_t)nparts + 1), hipMemcpyHostToDevice, s));
+  FS_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * (size_t)nparts, s));
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nrow, A.nnz, A.row_ptr, rows.p);
+  hipLaunchKernelGGL(dest_key_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, nparts, bd.p, A.cols, key.p, cnt.p);
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, idx_in.p);
+  FS_HIP(hipGetLastError());
+  int bits = 1;
+  while ((1 << bits) < nparts) ++bits;
+  size_t tmp_bytes = 0;
+  FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key.p, skey.p, idx_in.p, idx_out.p, (size_t)A.nnz, 0, bits, s));
+  FS_HIP(tmp.alloc(tmp_bytes));
+  FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, key.p, skey.p, idx_in.p, idx_out.p, (size_t)A.nnz, 0, bits, s));
+  hipLaunchKernelGGL(transpose_gather_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, row_lo, bd.p, skey.p, idx_out.p, rows.p,
+                     A.cols, A.vals, *trow, *tcol, *tval);
+  FS_HIP(hipGetLastError());
+  unsigned long long hc[kMaxParts];
+  FS_HIP(hipMemcpyAsync(hc, cnt.p, sizeof(unsigned long long) * (size_t)nparts, hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  for (int d = 0; d < nparts; ++d) count_host[d] = (int64_t)hc[d];
+  return FS_OK;
 }
 
 // ---- L2-tiled copy ---------------------------------------------------------------------------------
@@ -1275,42 +1440,47 @@ __global__ void split_entries_kernel(int nrow, int64_t nnz, int nlong, int bcols
   }
 }
 
-__global__ void long_band_start_kernel(int B, int nlong, int64_t n, const unsigned *__restrict__ skeys, int64_t *__restrict__ start)
+// first sorted entry of every (band, owner) segment: seg = b * kLongOwners + w starts at the first key >= b * nlong + own_first[w]
+__global__ void long_seg_start_kernel(int B, int nlong, int64_t n, const int *__restrict__ own_first, const unsigned *__restrict__ skeys,
+                                      int64_t *__restrict__ start)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > B) return;
-  const uint64_t key = (uint64_t)b * (uint64_t)nlong;
+  const int64_t sg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg > (int64_t)B * kLongOwners) return;
+  const int b = (int)(sg / kLongOwners), w = (int)(sg % kLongOwners);
+  const uint64_t key = (uint64_t)b * (uint64_t)nlong + (uint64_t)(b < B ? own_first[w] : 0);
   int64_t lo = 0, hi = n;
   while (lo < hi) {
     const int64_t mid = lo + ((hi - lo) >> 1);
     if ((uint64_t)skeys[mid] < key) lo = mid + 1; else hi = mid;
   }
-  start[b] = lo;
+  start[sg] = lo;
 }
 
+// owner_of[l]: the owner of long row l; shift[seg]: padded position - sorted position of the segment's entries
 __global__ void long_scatter_kernel(int64_t n, int nlong, int bcols, const unsigned *__restrict__ skeys, const unsigned *__restrict__ ssrc,
-                                    const int64_t *__restrict__ shift, const int *__restrict__ cols, const double *__restrict__ vals,
-                                    uint16_t *__restrict__ lcol, uint16_t *__restrict__ lrow, double *__restrict__ lvals)
+                                    const unsigned char *__restrict__ owner_of, const int64_t *__restrict__ shift,
+                                    const int *__restrict__ cols, const double *__restrict__ vals, uint16_t *__restrict__ lcol,
+                                    uint16_t *__restrict__ lrow, double *__restrict__ lvals)
 {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const unsigned key = skeys[k], src = ssrc[k];
   const unsigned b = key / (unsigned)nlong, l = key - b * (unsigned)nlong;
-  const int64_t d = k + shift[b];
+  const int64_t d = k + shift[(int64_t)b * kLongOwners + owner_of[l]];
   lcol[d] = (uint16_t)(cols[src] - (int)b * bcols);
   lrow[d] = (uint16_t)l;
   if (lvals) lvals[d] = vals[src];
 }
 
-// a band with an odd number of entries ends in one padding entry: column = the zero slot, value 0, row = its neighbour's
-__global__ void long_pad_kernel(int B, int bcols, const int64_t *__restrict__ start, const int64_t *__restrict__ band_ptr,
+// a segment with an odd number of entries ends in one padding entry: column = the zero slot, value 0, row = its neighbour's
+__global__ void long_pad_kernel(int64_t nseg, int bcols, const int64_t *__restrict__ start, const int64_t *__restrict__ shift,
                                 uint16_t *__restrict__ lcol, uint16_t *__restrict__ lrow, double *__restrict__ lvals)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const int64_t cnt = start[b + 1] - start[b];
+  const int64_t sg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= nseg) return;
+  const int64_t cnt = start[sg + 1] - start[sg];
   if (cnt & 1) {
-    const int64_t d = band_ptr[b] + cnt;
+    const int64_t d = start[sg] + shift[sg] + cnt;
     lcol[d] = (uint16_t)bcols;
     lrow[d] = lrow[d - 1];
     if (lvals) lvals[d] = 0.0;
@@ -1324,7 +1494,7 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
 {
   *out = nullptr;
   const Options &o = options();
-  if (o.long_rows == 0 || o.binning == 0 || o.reproducible || A.nrow == 0 || A.nnz < (4 << 20)) return FS_OK;
+  if (o.long_rows == 0 || o.binning == 0 || A.nrow == 0 || A.nnz < (4 << 20)) return FS_OK;
   // geometry: the narrow band with 12032 accumulators covers more entries (a config-5 shard: 50 % against 40 %) at twice the
   // number of band loads; measured on the config-5 shard: 2.24 ms against 2.29 (and 2.71 without this path), so it is the
   // default; long_geometry / FS_LONG_GEOMETRY force either
@@ -1350,8 +1520,28 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   FS_HIP(hipMemcpy(h.data(), cand, sizeof(int2) * (size_t)ncand, hipMemcpyDeviceToHost));
   std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.y != b.y ? a.y > b.y : a.x < b.x; });
   if ((int)h.size() > cap_rows) h.resize((size_t)cap_rows);          // the longest ones
-  std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
   const int nlong = (int)h.size();
+  // owners: the rows, longest first, are dealt out to the kLongOwners waves in a snake (0 .. 15, 15 .. 0, ...), so that every
+  // owner carries about the same number of entries; inside an owner's block the rows ascend.  Long row index = position in
+  // the concatenation of the blocks.
+  std::vector<int> own_first((size_t)kLongOwners + 1, 0);
+  {
+    std::vector<std::vector<int2>> blk((size_t)kLongOwners);
+    for (int i = 0; i < nlong; ++i) {
+      const int lap = i / kLongOwners, pos = i % kLongOwners;
+      blk[(size_t)((lap & 1) ? kLongOwners - 1 - pos : pos)].push_back(h[(size_t)i]);
+    }
+    h.clear();
+    for (int w = 0; w < kLongOwners; ++w) {
+      std::sort(blk[(size_t)w].begin(), blk[(size_t)w].end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
+      own_first[(size_t)w] = (int)h.size();
+      h.insert(h.end(), blk[(size_t)w].begin(), blk[(size_t)w].end());
+    }
+    own_first[(size_t)kLongOwners] = (int)h.size();
+  }
+  std::vector<unsigned char> owner_of((size_t)nlong);
+  for (int w = 0; w < kLongOwners; ++w)
+    for (int i = own_first[(size_t)w]; i < own_first[(size_t)w + 1]; ++i) owner_of[(size_t)i] = (unsigned char)w;
   int64_t nl = 0;
   std::vector<int> rows((size_t)nlong);
   std::vector<int64_t> lptr((size_t)nlong + 1, 0);
@@ -1366,9 +1556,6 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   L->nlong = nlong; L->B = B; L->bcols = bcols;
   FS_HIP(traced_malloc(&L->row, sizeof(int) * (size_t)nlong));
   FS_HIP(hipMemcpyAsync(L->row, rows.data(), sizeof(int) * (size_t)nlong, hipMemcpyHostToDevice, s));
-  L->h_row = (int *)malloc(sizeof(int) * (size_t)nlong);
-  if (!L->h_row) { set_error("out of host memory"); return FS_ERR_HIP; }
-  memcpy(L->h_row, rows.data(), sizeof(int) * (size_t)nlong);
   FS_HIP(traced_malloc(&L->ylong, sizeof(double) * (size_t)nlong));
 
   // ---- split the entries -------------------------------------------------------------------------------------------
@@ -1408,34 +1595,57 @@ static int split_long_rows(const DeviceCsr &A, hipStream_t s, LongRows **out, Sc
   FS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, (size_t)nl, 0, bits, s));     // stable: CSR order inside a run
   FS_HIP(tmp2.alloc(tmp_bytes));
   FS_HIP(rocprim::radix_sort_pairs((void *)tmp2.p, tmp_bytes, dk, dv, (size_t)nl, 0, bits, s));
-  FS_HIP(start.alloc((size_t)B + 1));
-  FS_HIP(shift.alloc((size_t)B + 1));
-  hipLaunchKernelGGL(long_band_start_kernel, dim3(grid_for((int64_t)B + 1)), dim3(256), 0, s, B, nlong, nl, dk.current(), start.p);
+  // the segments: (band, owner) in that order, each padded to an even count
+  const int64_t nseg = (int64_t)B * kLongOwners;
+  Scratch<int> d_own_first;
+  Scratch<unsigned char> d_owner_of;
+  FS_HIP(start.alloc((size_t)nseg + 1));
+  FS_HIP(shift.alloc((size_t)nseg + 1));
+  FS_HIP(d_own_first.alloc((size_t)kLongOwners + 1));
+  FS_HIP(d_owner_of.alloc((size_t)nlong));
+  FS_HIP(hipMemcpyAsync(d_own_first, own_first.data(), sizeof(int) * own_first.size(), hipMemcpyHostToDevice, s));
+  FS_HIP(hipMemcpyAsync(d_owner_of, owner_of.data(), owner_of.size(), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(long_seg_start_kernel, dim3(grid_for(nseg + 1)), dim3(256), 0, s, B, nlong, nl, d_own_first.p, dk.current(), start.p);
   FS_HIP(hipGetLastError());
-  std::vector<int64_t> hs((size_t)B + 1), hp((size_t)B + 1, 0), hsh((size_t)B + 1, 0);
+  std::vector<int64_t> hs((size_t)nseg + 1), hp((size_t)B + 1, 0), hsh((size_t)nseg + 1, 0);
+  std::vector<unsigned> hseg((size_t)B * (kLongOwners + 1), 0u);
   FS_HIP(hipMemcpyAsync(hs.data(), start, sizeof(int64_t) * hs.size(), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
-  for (int b = 0; b < B; ++b) {
-    const int64_t c = hs[(size_t)b + 1] - hs[(size_t)b];
-    hp[(size_t)b + 1] = hp[(size_t)b] + ((c + 1) & ~(int64_t)1);
-    hsh[(size_t)b] = hp[(size_t)b] - hs[(size_t)b];
+  {
+    int64_t at = 0;                                 // padded position of the next segment
+    for (int b = 0; b < B; ++b) {
+      hp[(size_t)b] = at;
+      for (int w = 0; w < kLongOwners; ++w) {
+        const int64_t sg = (int64_t)b * kLongOwners + w;
+        const int64_t c = hs[(size_t)sg + 1] - hs[(size_t)sg];
+        hseg[(size_t)b * (kLongOwners + 1) + (size_t)w] = (unsigned)(at - hp[(size_t)b]);
+        hsh[(size_t)sg] = at - hs[(size_t)sg];
+        at += (c + 1) & ~(int64_t)1;
+      }
+      hseg[(size_t)b * (kLongOwners + 1) + (size_t)kLongOwners] = (unsigned)(at - hp[(size_t)b]);
+      if (at - hp[(size_t)b] >= (1ll << 32)) return FS_OK;   // (a band of 4 G entries: not this path)
+    }
+    hp[(size_t)B] = at;
   }
   L->n = hp[(size_t)B];
   FS_HIP(traced_malloc(&L->band_ptr, sizeof(int64_t) * ((size_t)B + 1)));
+  FS_HIP(traced_malloc(&L->seg_ptr, sizeof(unsigned) * hseg.size()));
   FS_HIP(hipMemcpyAsync(L->band_ptr, hp.data(), sizeof(int64_t) * hp.size(), hipMemcpyHostToDevice, s));
+  FS_HIP(hipMemcpyAsync(L->seg_ptr, hseg.data(), sizeof(unsigned) * hseg.size(), hipMemcpyHostToDevice, s));
   FS_HIP(hipMemcpyAsync(shift, hsh.data(), sizeof(int64_t) * hsh.size(), hipMemcpyHostToDevice, s));
   FS_HIP(traced_malloc(&L->lcol, sizeof(uint16_t) * (size_t)(L->n + 2)));
   FS_HIP(traced_malloc(&L->lrow, sizeof(uint16_t) * (size_t)(L->n + 2)));
   if (A.vals) FS_HIP(traced_malloc(&L->vals, sizeof(double) * (size_t)(L->n + 2)));
-  hipLaunchKernelGGL(long_scatter_kernel, dim3(grid_for(nl)), dim3(256), 0, s, nl, nlong, bcols, dk.current(), dv.current(), shift.p, A.cols,
-                     A.vals, L->lcol, L->lrow, L->vals);
-  hipLaunchKernelGGL(long_pad_kernel, dim3(grid_for(B)), dim3(256), 0, s, B, bcols, start.p, L->band_ptr, L->lcol, L->lrow, L->vals);
+  hipLaunchKernelGGL(long_scatter_kernel, dim3(grid_for(nl)), dim3(256), 0, s, nl, nlong, bcols, dk.current(), dv.current(), d_owner_of.p,
+                     shift.p, A.cols, A.vals, L->lcol, L->lrow, L->vals);
+  hipLaunchKernelGGL(long_pad_kernel, dim3(grid_for(nseg)), dim3(256), 0, s, nseg, bcols, start.p, shift.p, L->lcol, L->lrow, L->vals);
   FS_HIP(hipGetLastError());
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
   const int64_t by_size = (L->n + kBinShareMin - 1) / kBinShareMin;
   L->nwg = (int)(by_size < ncu ? by_size : ncu);
+  FS_HIP(traced_malloc(&L->ypart, sizeof(double) * (size_t)(L->nwg > 0 ? L->nwg : 1) * (size_t)nlong));
   FS_HIP(hipStreamSynchronize(s));
   guard.keep = true;
   *out = L;

@@ -1464,18 +1464,22 @@ __global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
 // address would serialise) and only the last lane of every run adds to the accumulator (ds_add_f64).  At the end of its
 // share a workgroup adds its accumulators to ylong in HBM (one atomic per row it touched).  10 bytes per entry where the
 // two-pass pair moves 28.
+// ORDERED (fixed-order sums: option "reproducible", the solvers): every long row belongs to ONE wave of the workgroup and the
+// builder keeps an owner's entries of a band in one contiguous segment (seg_ptr); wave w walks ITS segments, so an accumulator
+// only ever sees the LDS instructions of one wave, which execute in program order -- the same sum, bit for bit, every run.
+// The workgroups' sums go to ypart and are added up in workgroup order by longrows_combine_kernel instead of with atomics.
 // ------------------------------------------------------------------------------------------
-template <bool VALUED, int BC, int NACC>
+template <bool VALUED, int BC, int NACC, bool ORDERED>
 __global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
-    int ncol, int B, int nlong, const int64_t *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
-    const uint16_t *__restrict__ lrow, const double *__restrict__ vals, const double *__restrict__ x, int xs,
-    double *__restrict__ ylong)
+    int ncol, int B, int nlong, const int64_t *__restrict__ band_ptr, const unsigned *__restrict__ seg_ptr,
+    const uint16_t *__restrict__ lcol, const uint16_t *__restrict__ lrow, const double *__restrict__ vals,
+    const double *__restrict__ x, int xs, double *__restrict__ ylong, double *__restrict__ ypart)
 {
   __shared__ double xband[BC + 8];
   __shared__ double acc[NACC];
-  const int t = threadIdx.x, lane = t & 63;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int i = t; i < nlong; i += kBinBlock) acc[i] = 0.0;
-  const int64_t pairs = band_ptr[B] >> 1;                         // every band holds an even number of entries
+  const int64_t pairs = band_ptr[B] >> 1;                         // every segment holds an even number of entries
   const int64_t e_beg = 2 * (pairs * blockIdx.x / gridDim.x), e_end = 2 * (pairs * (blockIdx.x + 1) / gridDim.x);
   if (e_beg < e_end) {
     int b;
@@ -1501,6 +1505,31 @@ __global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
       }
       have = bb;
     };
+    // 128 entries of one wave: products, run sums by a segmented scan over the lanes, one LDS add per run
+    auto wave_step = [&](int64_t o, bool live, int64_t oc) {
+      const unsigned a = *reinterpret_cast<const unsigned *>(lcol + oc);
+      const unsigned rr = *reinterpret_cast<const unsigned *>(lrow + oc);
+      v2d p = {xband[a & 0xffffu], xband[a >> 16]};
+      if (VALUED) { const v2d v = *reinterpret_cast<const v2d *>(vals + oc); p.x *= v.x; p.y *= v.y; }
+      unsigned key = 0xffffffffu;
+      double sum = 0.0;
+      if (live) {
+        const unsigned r0 = rr & 0xffffu, r1 = rr >> 16;
+        if (r0 == r1) { key = r0; sum = p.x + p.y; }
+        else { __hip_atomic_fetch_add(&acc[r0], p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); key = r1; sum = p.y; }
+      }
+      // segmented inclusive scan over the wave: keys are sorted, so an equal key d lanes down means one run
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned ku = __shfl_up(key, d);
+        const double su = __shfl_up(sum, d);
+        if (lane >= d && ku == key) sum += su;
+      }
+      const unsigned kn = __shfl_down(key, 1);
+      if (live && (lane == 63 || kn != key))
+        __hip_atomic_fetch_add(&acc[key], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)o;
+    };
     for (int64_t e = e_beg; e < e_end; ++b) {
       const int64_t eb = band_ptr[b + 1] < e_end ? band_ptr[b + 1] : e_end;
       if (eb <= e) continue;
@@ -1516,41 +1545,46 @@ __global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
       if (t < 8) xband[BC + t] = 0.0;
       __syncthreads();
       if (b + 1 < B && eb < e_end) request(b + 1);
-      // whole rounds of the workgroup (2048 entries); lanes past the end of the segment carry a sentinel key and add nothing
-      for (int64_t o0 = e; o0 < eb; o0 += 2 * kBinBlock) {
-        const int64_t o = o0 + 2 * t;
-        const bool live = o < eb;
-        const int64_t oc = live ? o : e;                             // clamped address, masked below
-        const unsigned a = *reinterpret_cast<const unsigned *>(lcol + oc);
-        const unsigned rr = *reinterpret_cast<const unsigned *>(lrow + oc);
-        v2d p = {xband[a & 0xffffu], xband[a >> 16]};
-        if (VALUED) { const v2d v = *reinterpret_cast<const v2d *>(vals + oc); p.x *= v.x; p.y *= v.y; }
-        unsigned key = 0xffffffffu;
-        double sum = 0.0;
-        if (live) {
-          const unsigned r0 = rr & 0xffffu, r1 = rr >> 16;
-          if (r0 == r1) { key = r0; sum = p.x + p.y; }
-          else { __hip_atomic_fetch_add(&acc[r0], p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); key = r1; sum = p.y; }
+      if (ORDERED) {
+        // this wave's segment of the band, clipped to the share: nobody else touches the accumulators of its rows
+        const int64_t s0 = band_ptr[b] + seg_ptr[b * (kLongOwners + 1) + wave], s1 = band_ptr[b] + seg_ptr[b * (kLongOwners + 1) + wave + 1];
+        const int64_t lo = s0 > e ? s0 : e, hi = s1 < eb ? s1 : eb;
+        for (int64_t o0 = lo; o0 < hi; o0 += 128) {
+          const int64_t o = o0 + 2 * lane;
+          const bool live = o < hi;
+          wave_step(o, live, live ? o : lo);
         }
-        // segmented inclusive scan over the wave: keys are sorted, so an equal key d lanes down means one run
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const unsigned ku = __shfl_up(key, d);
-          const double su = __shfl_up(sum, d);
-          if (lane >= d && ku == key) sum += su;
+      } else {
+        // whole rounds of the workgroup (2048 entries); lanes past the end of the segment carry a sentinel key and add nothing
+        for (int64_t o0 = e; o0 < eb; o0 += 2 * kBinBlock) {
+          const int64_t o = o0 + 2 * t;
+          const bool live = o < eb;
+          wave_step(o, live, live ? o : e);                          // clamped address, masked inside
         }
-        const unsigned kn = __shfl_down(key, 1);
-        if (live && (lane == 63 || kn != key))
-          __hip_atomic_fetch_add(&acc[key], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       e = eb;
     }
   }
   __syncthreads();
-  for (int i = t; i < nlong; i += kBinBlock) {
-    const double v = acc[i];
-    if (v != 0.0) unsafeAtomicAdd(ylong + i, v);
+  if (ORDERED) {
+    double *__restrict__ mine = ypart + (int64_t)blockIdx.x * nlong;
+    for (int i = t; i < nlong; i += kBinBlock) mine[i] = acc[i];
+  } else {
+    for (int i = t; i < nlong; i += kBinBlock) {
+      const double v = acc[i];
+      if (v != 0.0) unsafeAtomicAdd(ylong + i, v);
+    }
   }
+}
+
+// ylong[i] = the workgroups' sums of long row i, added in workgroup order
+__global__ __launch_bounds__(kBlock) void longrows_combine_kernel(int nlong, int nwg, const double *__restrict__ ypart, double *__restrict__ ylong)
+{
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nlong) return;
+  double acc = 0.0;
+  for (int w = 0; w < nwg; ++w) acc += ypart[(int64_t)w * nlong + i];
+  ylong[i] = acc;
 }
 
 // y[row[i]] = ylong[i] for the long rows inside [row0, row1): the two-pass pair wrote 0 there (their entries are not in it)
@@ -1565,15 +1599,23 @@ __global__ __launch_bounds__(kBlock) void longrows_scatter_kernel(int nlong, con
 
 static int launch_longrows(const DeviceCsr &A, const LongRows &L, const double *x, int xs, hipStream_t s)
 {
-  FS_HIP(hipMemsetAsync(L.ylong, 0, sizeof(double) * (size_t)L.nlong, s));
+  const bool ordered = reproducible_now();
+  if (!ordered || L.n == 0 || L.nwg == 0) FS_HIP(hipMemsetAsync(L.ylong, 0, sizeof(double) * (size_t)L.nlong, s));
   if (L.n == 0 || L.nwg == 0) return FS_OK;
-#define FS_LONG(V, BC, NA)                                                                                                   \
-  hipLaunchKernelGGL((spmv_longrows_kernel<V, BC, NA>), dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, L.lcol, \
-                     L.lrow, L.vals, x, xs, L.ylong)
-  if (L.bcols == kLongBandB) { if (A.vals) FS_LONG(true, kLongBandB, kLongRowsB); else FS_LONG(false, kLongBandB, kLongRowsB); }
-  else                       { if (A.vals) FS_LONG(true, kLongBandA, kLongRowsA); else FS_LONG(false, kLongBandA, kLongRowsA); }
+#define FS_LONG(V, BC, NA, ORD)                                                                                              \
+  hipLaunchKernelGGL((spmv_longrows_kernel<V, BC, NA, ORD>), dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, \
+                     L.seg_ptr, L.lcol, L.lrow, L.vals, x, xs, L.ylong, L.ypart)
+#define FS_LONG2(V, BC, NA) do { if (ordered) FS_LONG(V, BC, NA, true); else FS_LONG(V, BC, NA, false); } while (0)
+  if (L.bcols == kLongBandB) { if (A.vals) FS_LONG2(true, kLongBandB, kLongRowsB); else FS_LONG2(false, kLongBandB, kLongRowsB); }
+  else                       { if (A.vals) FS_LONG2(true, kLongBandA, kLongRowsA); else FS_LONG2(false, kLongBandA, kLongRowsA); }
+#undef FS_LONG2
 #undef FS_LONG
   FS_HIP(hipGetLastError());
+  if (ordered) {
+    hipLaunchKernelGGL(longrows_combine_kernel, dim3((unsigned)((L.nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, L.nlong, L.nwg, L.ypart,
+                       L.ylong);
+    FS_HIP(hipGetLastError());
+  }
   return FS_OK;
 }
 
@@ -1961,7 +2003,7 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
     if (int rc = launch_longrows(A, *N.lr, x, xs, s)) return rc;
   if (p1 > p0) {
     // "reproducible" (or bit 5 of bin_flags): one wave per panel, additions in stream order, bit-identical run to run
-    const bool ordered = options().reproducible || (options().bin_flags & 32);
+    const bool ordered = reproducible_now() || (options().bin_flags & 32);
     if (N.bcols == kBinColsBig && ordered)
       hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsBig, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
                          N.panel_row, N.lrow, N.prod, out, os, p0);
@@ -2123,7 +2165,7 @@ int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const 
   }
 #undef FS_XP
   if (p1 > p0) {
-    const bool ordered = options().reproducible || (options().bin_flags & 32);   // one wave per panel, stream order
+    const bool ordered = reproducible_now() || (options().bin_flags & 32);   // one wave per panel, stream order
     if (K == 2 && ordered)
       hipLaunchKernelGGL((spmm_reduce_ordered_kernel<2, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
     else if (ordered)
@@ -2191,10 +2233,12 @@ int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long
 // sweeps; the long-row path).
 int spmv_choice(const DeviceCsr &A, const Options &o)
 {
-  // (the two-pass pair under "reproducible": its pass 2 then runs one wave per panel in stream order -- not with the long-row side
-  // path, whose waves add in arrival order)
-  if (A.binned && A.binned->built && !o.strict_order && (!o.reproducible || !A.binned->lr) && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
-  if (A.tiledx && A.tiledx->built && !o.strict_order && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
+  // (fixed-order sums -- "reproducible", the solvers -- keep the builder's choice: pass 2 of the two-pass pair then runs one wave per
+  // panel in stream order, the long-row path gives every row to one wave, the LDS-staged kernel waits for a phase's adds before
+  // its barrier; only an LDS-staged copy whose items could not be arranged row-per-wave, TiledCsr::orderable, drops out)
+  const bool repro = o.reproducible != 0 || tl_fixed_order > 0;
+  if (A.binned && A.binned->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
+  if (A.tiledx && A.tiledx->built && !o.strict_order && (!repro || A.tiledx->orderable) && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
   if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
   return o.spmv_kernel == 2 ? 2 : 1;
 }
@@ -2213,7 +2257,7 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
   }
   // "reproducible" / "strict_order" set AFTER the matrix was created leave its kept copy unusable: the product then runs on
   // the chunk-streaming kernel (correct, but slow on large matrices).  Said once under FS_TRACE_BUILD.
-  if ((o.reproducible || o.strict_order) && o.spmv_kernel == 0 && ((A.binned && A.binned->built) || (A.tiledx && A.tiledx->built))) {
+  if ((reproducible_now() || o.strict_order) && o.spmv_kernel == 0 && ((A.binned && A.binned->built) || (A.tiledx && A.tiledx->built))) {
     static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
     static bool said = false;
     if (trace && !said) {
@@ -2320,13 +2364,13 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
   const size_t nx = A.ncol > 0 ? (size_t)A.ncol : 1, ny = (size_t)A.nrow;
   if (int rc = host_pipe_ready(H, nx, ny, want_chunks)) return rc;
   const bool two_pass = A.binned && A.binned->built && !A.binned->split && !A.binned->lr && A.binned->nwg1 > 0 && !o.strict_order &&
-                        !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 7) && o.bin_flags == 0 && want_chunks > 1;
+                        !reproducible_now() && (o.spmv_kernel == 0 || o.spmv_kernel == 7) && o.bin_flags == 0 && want_chunks > 1;
   if (!two_pass) {
     // the panel kernels (LDS-staged, L2-tiled) need all of x, but a workgroup that owns its rows finishes them: launched in
     // ranges of workgroups, y comes down range by range under the later ranges (a tall matrix: config 3, y 80 MB, x 8 MB)
     const TiledCsr *T = nullptr;
     if (!(A.binned && A.binned->built) && !o.strict_order && want_chunks > 1) {
-      if (A.tiledx && A.tiledx->built && !o.reproducible && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) T = A.tiledx;
+      if (A.tiledx && A.tiledx->built && !reproducible_now() && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) T = A.tiledx;
       else if (A.tiled && A.tiled->built && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) T = A.tiled;
     }
     if (T && T->ldsx && T->shared && T->nchunks >= 2 * want_chunks && A.ncol >= (1 << 20)) {
@@ -2561,9 +2605,10 @@ int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
 {
   const Options &o = options();
   if (needs_prepare) *needs_prepare = 0;
-  const bool free_order = !o.strict_order && !o.reproducible;   // the LDS-staged kernels add in arrival order
+  const bool repro = reproducible_now();
+  const bool free_order = !o.strict_order && (!repro || (A.tiledx && A.tiledx->orderable));   // fixed-order sums on the LDS-staged copy: see spmv_choice
   // the two-pass kernels: under "reproducible" their pass 2 runs one wave per panel in stream order -- not the long-row side path
-  const bool bin_order = !o.strict_order && (!o.reproducible || !(A.binned && A.binned->lr));
+  const bool bin_order = !o.strict_order;
   const int want = o.spmm_kernel;
   const bool hb = A.binned && A.binned->built, hx = A.tiledx && A.tiledx->built, ht = A.tiled && A.tiled->built;
   const bool bin_ok = o.spmv_kernel == 0 || o.spmv_kernel == 7, ldsx_ok = o.spmv_kernel == 0 || o.spmv_kernel == 8;

@@ -2050,3 +2050,222 @@ def test_products_with_host_vectors_overlap_copies(hip, valued):
     A.spmv_host(y, np.array([1.0, 2.0, 3.0]))
     assert capi.lib().fs_debug_last_host_path() == 0
     assert np.array_equal(y, [1.5 - 6.0, 0.0, 8.0])
+
+
+def _shard_arrays(rp, cc, vv, cuts):
+    """per-rank arrays of a CSR cut at the rows `cuts`: local row_ptr, global columns, values"""
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(rp[a]), int(rp[b])
+        out.append((np.ascontiguousarray(rp[a:b + 1] - rp[a]).astype(np.int32), np.ascontiguousarray(cc[lo:hi]),
+                    None if vv is None else np.ascontiguousarray(vv[lo:hi])))
+    return out
+
+
+def _ptr_array(C, arrays):
+    return (C.c_void_p * len(arrays))(*[None if a is None else a.ctypes.data for a in arrays])
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_native_multi_gpu_matrix_from_per_rank_shards_and_device_transpose(hip, space):
+    """the native C path must hold a matrix that only exists as per-rank shards (BASELINE config 5: 3.2 G
+    entries, more than one `int row_ptr` can index, csr.h:358-366).  fs_dist_csr_create_from_shards takes one CSR per rank (local
+    row_ptr, global columns) from host or device memory; fs_dist_matrix_build_transpose_device builds the row shards of A' from
+    the device-resident shards of A -- no whole-matrix host array anywhere.  Three virtual ranks on this one GPU: both must equal
+    what fs_dist_csr_create + fs_dist_matrix_build_transpose make of the whole matrix: same cuts of A', the same shard arrays
+    entry for entry (every row of A' in ascending A-row order), and products bit-exact for integer x, row-scaled otherwise."""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    L = capi.lib()
+    ranks = 3
+    nrow, ncol = 150_000, 110_000
+    rp, cc, vv = pysynth.powerlaw(nrow, ncol, 2.3, 30_000, 0x5A4D)
+    rows_all = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+    devs = (C.c_int * ranks)(*([0] * ranks))
+    D = L.fs_dist_create(ranks, devs)
+    assert D
+    try:
+        for vals in (vv, None):
+            W = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None if vals is None else vals.ctypes.data)
+            assert W, L.fs_last_error()
+            b = (C.c_int * (ranks + 1))()
+            assert L.fs_dist_matrix_bounds(W, b) == 0
+            cuts = list(b)
+            shards = _shard_arrays(rp, cc, vals, cuts)
+            keep = []                                  # device copies stay alive until the matrix is made
+            if space == "device":
+                import torch
+                dev = []
+                for s_rp, s_cc, s_vv in shards:
+                    t = (torch.from_numpy(s_rp).cuda(), torch.from_numpy(s_cc).cuda(), None if s_vv is None else torch.from_numpy(s_vv).cuda())
+                    keep.append(t)
+                    dev.append(t)
+                torch.cuda.synchronize()
+                p_rp = (C.c_void_p * ranks)(*[t[0].data_ptr() for t in dev])
+                p_cc = (C.c_void_p * ranks)(*[t[1].data_ptr() for t in dev])
+                p_vv = None if vals is None else (C.c_void_p * ranks)(*[t[2].data_ptr() for t in dev])
+            else:
+                p_rp = _ptr_array(C, [s[0] for s in shards])
+                p_cc = _ptr_array(C, [s[1] for s in shards])
+                p_vv = None if vals is None else _ptr_array(C, [s[2] for s in shards])
+            srows = (C.c_int * ranks)(*[cuts[i + 1] - cuts[i] for i in range(ranks)])
+            snnz = (C.c_int64 * ranks)(*[len(s[1]) for s in shards])
+            M = L.fs_dist_csr_create_from_shards(D, nrow, ncol, srows, snnz, p_rp, p_cc, p_vv, capi.FS_DEVICE if space == "device" else capi.FS_HOST)
+            assert M, L.fs_last_error()
+            del keep
+            assert L.fs_dist_matrix_nnz(M) == len(cc)
+            b2 = (C.c_int * (ranks + 1))()
+            assert L.fs_dist_matrix_bounds(M, b2) == 0 and list(b2) == cuts
+            # A x
+            for x in (S.x_int(9, ncol), S.x_sin(ncol)):
+                y, yw = np.full(nrow, -1.0), np.full(nrow, -2.0)
+                assert L.fs_dist_spmv(M, y.ctypes.data, x.ctypes.data) == 0, L.fs_last_error()
+                assert L.fs_dist_spmv(W, yw.ctypes.data, x.ctypes.data) == 0, L.fs_last_error()
+                ref = O.csr_mul(nrow, rp, cc, vals, x)
+                if vals is None and np.all(x == np.round(x)):
+                    assert np.array_equal(y, ref) and np.array_equal(yw, ref)
+                else:
+                    sc = np.maximum(O.csr_abs_scale(nrow, rp, cc, vals, x), 1e-300)
+                    assert np.all(np.abs(y - ref) <= TOL * sc) and np.all(np.abs(yw - ref) <= TOL * sc)
+            # A': device build on the sharded matrix, host build on the whole one
+            assert L.fs_dist_matrix_has_transpose(M) == 0
+            assert L.fs_dist_matrix_build_transpose_device(M) == 0, L.fs_last_error()
+            assert L.fs_dist_matrix_build_transpose_device(M) == 0                      # idempotent
+            assert L.fs_dist_matrix_build_transpose(W, rp.ctypes.data, cc.ctypes.data, None if vals is None else vals.ctypes.data) == 0, \
+                L.fs_last_error()
+            bt, btw = (C.c_int * (ranks + 1))(), (C.c_int * (ranks + 1))()
+            assert L.fs_dist_matrix_bounds_t(M, bt) == 0 and L.fs_dist_matrix_bounds_t(W, btw) == 0
+            assert list(bt) == list(btw), (list(bt), list(btw))
+            for r in range(ranks):                    # the shards of A' entry for entry
+                got, want = [], []
+                for H_, store in ((M, got), (W, want)):
+                    sh = L.fs_dist_matrix_shard(H_, r, 1)
+                    assert sh
+                    n_r, z_r = L.fs_matrix_nrow(sh), L.fs_matrix_nnz(sh)
+                    a_rp, a_cc = np.empty(n_r + 1, np.int32), np.empty(max(z_r, 1), np.int32)
+                    a_vv = np.empty(max(z_r, 1)) if vals is not None else None
+                    assert L.fs_matrix_download(sh, 0, a_rp.ctypes.data, a_cc.ctypes.data, None if a_vv is None else a_vv.ctypes.data) == 0
+                    store.extend([a_rp, a_cc[:z_r], None if a_vv is None else a_vv[:z_r]])
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), r
+                assert vals is None or np.array_equal(got[2], want[2]), r
+            for u in (S.x_int(6, nrow), np.sin(11.0 * np.arange(nrow) - 0.2)):
+                z, zw = np.full(ncol, -1.0), np.full(ncol, -2.0)
+                assert L.fs_dist_spmv_t(M, z.ctypes.data, u.ctypes.data) == 0, L.fs_last_error()
+                assert L.fs_dist_spmv_t(W, zw.ctypes.data, u.ctypes.data) == 0, L.fs_last_error()
+                zref = O.coo_tmul(ncol, rows_all, cc, vals, u)
+                if vals is None and np.all(u == np.round(u)):
+                    assert np.array_equal(z, zref) and np.array_equal(zw, zref)
+                else:
+                    sc = np.maximum(O.coo_tmul(ncol, rows_all, cc, None if vals is None else np.abs(vals), np.abs(u)), 1e-300)
+                    assert np.all(np.abs(z - zref) <= TOL * sc) and np.all(np.abs(zw - zref) <= TOL * sc)
+            L.fs_dist_matrix_destroy(M)
+            L.fs_dist_matrix_destroy(W)
+    finally:
+        L.fs_dist_destroy(D)
+
+
+def test_native_multi_gpu_cg_with_the_vector_work_divided_by_rows(hip):
+    """fs_dist_cg, scheme "gather" (option dist_cg_scheme = 1): every rank keeps its slice of x, r, p, q, the
+    partial dots are all-gathered and added in rank order, the new p is all-gathered -- against the replicated scheme and the
+    oracle's solver, on three virtual ranks; under fixed-order sums (the solvers' default) two solves are bit-identical."""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    L = capi.lib()
+    ranks = 3
+    nrow, ncol = 90_000, 70_000
+    rp, cc, _ = pysynth.powerlaw(nrow, ncol, 2.3, 5_000, 0xC6C6)
+    rows_all = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+    devs = (C.c_int * ranks)(*([0] * ranks))
+    D = L.fs_dist_create(ranks, devs)
+    assert D
+    capi.set_option("binning", 2)          # the two-pass copy on these small shards: products in parts, fixed-order pass 2
+    try:
+        M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None)
+        assert M, L.fs_last_error()
+        assert L.fs_dist_matrix_build_transpose_device(M) == 0, L.fs_last_error()
+        bvec = np.sin(0.37 * np.arange(ncol) + 1.0)
+        bnorm = float(np.linalg.norm(bvec))
+        lam, tol = 40.0, 1e-9
+        xref, itref = O.cg_normal(nrow, ncol, rows_all, cc, bvec, lam, tol)
+        res_ref = _normal_residual(nrow, ncol, rp, cc, rows_all, lam, xref, bvec)
+        out = {}
+        for scheme in (0, 1):
+            capi.set_option("dist_cg_scheme", scheme)
+            sols = []
+            for _ in range(2):
+                xs = np.full(ncol, -1.0)
+                it = C.c_int(-1)
+                assert L.fs_dist_cg(M, xs.ctypes.data, bvec.ctypes.data, lam, tol, C.byref(it)) == 0, L.fs_last_error()
+                sols.append((xs, it.value))
+            res = _normal_residual(nrow, ncol, rp, cc, rows_all, lam, sols[0][0], bvec)
+            rep = dict(scheme=scheme, iterations=[s[1] for s in sols], oracle_iterations=itref, residual=res, oracle_residual=res_ref,
+                       err2=float(np.linalg.norm(sols[0][0] - xref)), err2_bound=(res + res_ref) * bnorm / lam,
+                       differing=int(np.count_nonzero(sols[0][0] != sols[1][0])))
+            print("fs_dist_cg scheme:", rep)
+            assert sols[0][1] == sols[1][1] and np.array_equal(sols[0][0], sols[1][0]), rep      # fixed-order sums: bit-identical
+            assert res <= 2 * tol and res_ref <= 2 * tol, rep
+            assert rep["err2"] <= 1.01 * rep["err2_bound"], rep
+            assert abs(sols[0][1] - itref) <= max(2, itref // 10), rep
+            out[scheme] = sols[0]
+        # the two schemes add the dots in different orders: same solve to rounding, not bit for bit
+        assert np.max(np.abs(out[0][0] - out[1][0])) <= 1e-6 * max(1e-300, float(np.abs(xref).max()))
+        L.fs_dist_matrix_destroy(M)
+    finally:
+        capi.set_option("dist_cg_scheme", 0)
+        capi.set_option("binning", 1)
+        L.fs_dist_destroy(D)
+
+
+def test_native_multi_gpu_conservative_exchange_and_fallback(hip):
+    """the overlapped exchange (one all-gather per part, padded windows) has never run with more than one RCCL rank,
+    so there is a conservative mode -- ONE whole-shard all-gather behind the finished local product: FS_DIST_PARTS=1 selects it, and
+    a group call that returns an error in the overlapped mode (injected here with FS_DIST_FAIL_PART) finishes that product
+    conservatively and keeps the context there.  Virtual ranks and the forced one-rank RCCL group, separate processes (the
+    environment is read once)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from libfastsparse_amd import capi
+from oracle import pyoracle as O, pysynth
+L = capi.lib()
+ranks = int(sys.argv[1])
+nrow, ncol = 300_000, 90_000
+rp, cc, vv = pysynth.powerlaw(nrow, ncol, 2.3, 20_000, 78)
+xi = (np.arange(ncol) %% 13 - 6).astype(np.float64)
+capi.set_option("binning", 2)
+capi.set_option("bin_rows", 256)     # many panels: the local products really run in parts
+D = L.fs_dist_create(ranks, (C.c_int * ranks)(*([0] * ranks)) if ranks > 1 else None)
+assert D, L.fs_last_error()
+assert L.fs_dist_uses_rccl(D) == (1 if os.environ.get("FS_DIST_FORCE_RCCL") == "1" else 0)
+start = L.fs_dist_is_conservative(D)
+assert start == (1 if os.environ.get("FS_DIST_PARTS") == "1" else 0)
+M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None)
+assert M, L.fs_last_error()
+ref = O.csr_mul(nrow, rp, cc, None, xi)
+for rep in range(3):
+    y = np.full(nrow, -1.0)
+    assert L.fs_dist_spmv(M, y.ctypes.data, xi.ctypes.data) == 0, L.fs_last_error()
+    assert np.array_equal(y, ref), rep
+    for r in range(ranks):
+        g = np.empty(nrow); assert L.fs_copy_to_host(g.ctypes.data, L.fs_dist_y(M, r), 8 * nrow) == 0
+        assert np.array_equal(g, ref), (rep, r)
+want = 1 if (os.environ.get("FS_DIST_PARTS") == "1" or os.environ.get("FS_DIST_FAIL_PART")) else 0
+assert L.fs_dist_is_conservative(D) == want, (L.fs_dist_is_conservative(D), want)
+assert L.fs_dist_matrix_build_transpose_device(M) == 0, L.fs_last_error()
+ui = (np.arange(nrow) %% 11 - 5).astype(np.float64)
+z = np.full(ncol, -1.0)
+assert L.fs_dist_spmv_t(M, z.ctypes.data, ui.ctypes.data) == 0, L.fs_last_error()
+assert np.array_equal(z, O.coo_tmul(ncol, np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp)), cc, None, ui))
+L.fs_dist_matrix_destroy(M); L.fs_dist_destroy(D)
+print("OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    runs = [("3", {}), ("3", {"FS_DIST_PARTS": "1"}), ("3", {"FS_DIST_FAIL_PART": "1"}),
+            ("1", {"FS_DIST_FORCE_RCCL": "1"}), ("1", {"FS_DIST_FORCE_RCCL": "1", "FS_DIST_FAIL_PART": "0"}),
+            ("1", {"FS_DIST_FORCE_RCCL": "1", "FS_DIST_PARTS": "1"})]
+    for ranks, extra in runs:
+        p = subprocess.run([sys.executable, "-c", code, ranks], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, (ranks, extra, p.stdout[-1500:] + p.stderr[-1500:])
