@@ -477,7 +477,7 @@ def cpu_baseline_c4(n, per_row, k, sample_rows=400_000, reps=2):
 # workloads
 # ------------------------------------------------------------------------------------------------------------
 KERNEL_LABELS = {"two-pass": "fs::spmv_expand_kernel + fs::spmv_reduce_kernel (one product)",
-                 "tiled": "fs::spmv_tiled_kernel", "lds-staged": "fs::spmv_ldsx_kernel", "stream": "fs::spmv_stream_kernel"}
+                 "tiled": "fs::spmv_tiled_kernel", "lds-staged": "fs::spmv_ldsx_dma_kernel", "stream": "fs::spmv_stream_kernel"}
 
 
 def _klabel(ka, kt=None):
@@ -527,6 +527,63 @@ def _same_on_all_ranks(values, dev_or_cpu):
     dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
     return bool(torch.equal(lo_, hi_))
+
+
+def fixed_order_cost(prov, capi, products, kernel_name, how):
+    """What fixed-order (run-to-run bit-identical) sums cost on this workload: the SAME handles, the same loop of ten steps, option
+    "reproducible" toggled -- arrival order timed before and after, the smaller taken as the base.  `products()` enqueues one
+    step's products; `kernel_name()` names the kernel(s) that run under the option."""
+    try:
+        def ten(reproducible):
+            capi.set_option("reproducible", reproducible)
+            for _ in range(2):
+                products()
+            e0, e1 = prov.event(), prov.event()
+            e0.record()
+            for _ in range(10):
+                products()
+            e1.record()
+            prov.synchronize()
+            return prov.elapsed_ms(e0, e1) / 10
+        try:
+            ms0 = ten(0)
+            ms1 = ten(1)
+            kname1 = kernel_name()
+            ms0b = ten(0)
+        finally:
+            capi.set_option("reproducible", 0)
+        base = min(ms0, ms0b)
+        return {"kernel": kname1, "step_ms": ms1, "step_ms_arrival_order_same_loop": base, "how": how,
+                "reproducible_cost_pct": 100.0 * (ms1 / base - 1.0)}
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
+def config2_bound(alg_bytes):
+    """Why 0.60 of peak is out of reach on config 2, as numbers in the line.  Uniformly random columns over an
+    80 MB x leave two ways to touch x[col]: (a) ONE cache-line request per non-zero -- the chip answers at most ~250 G of them per
+    second even when every one hits L2 (profiles/r01_probe_gather.jsonl: 160 M gathers from an L2-resident window take 0.61-0.67 ms,
+    2.9 ms from the whole 80 MB table), next to which the 12-byte entry stream has to run (0.31 ms at the copy rate); the two were
+    measured NOT to overlap in a kernel with an LDS-resident y slice (probe_mix, DESIGN.md "gather ceiling"), but even perfectly
+    overlapped the gathers alone bound the product; or (b) no gathers at all -- every random access in LDS, which costs a pass
+    over an intermediate: 28 bytes per entry (the kept two-pass pair), 2.33 x the algorithmic bytes."""
+    gather_floor_ms = 0.61                      # 160 M L2-hit gathers, best of profiles/r01_probe_gather.jsonl ("tiled", 0.26 MB window)
+    stream_floor_ms = 1.92e9 / (HBM_COPY_GBS * 1e9) * 1e3     # the 12-byte entry stream at the copy rate
+    overlapped = max(gather_floor_ms, stream_floor_ms)
+    two_pass_floor_ms = (28.0 * 160e6 + 2 * 8e7 + 4e7) / (HBM_COPY_GBS * 1e9) * 1e3
+    best = min(overlapped, two_pass_floor_ms)
+    return {"gather_floor_ms": gather_floor_ms, "stream_floor_ms": stream_floor_ms,
+            "gather_kernel_ceiling_frac": alg_bytes / (overlapped * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "gather_kernel_ceiling_if_not_overlapped_frac": alg_bytes / ((gather_floor_ms + stream_floor_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "two_pass_floor_ms": two_pass_floor_ms,
+            "any_kernel_ceiling_frac": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "bound_sources": ["profiles/r01_probe_gather.jsonl (L2-hit gather rate)", "profiles/r01_probe_mix.jsonl (gathers + stream in one "
+                              "kernel: 0.79-0.98 ms, not overlapped)", "profiles/r02_probe_hybrid_cu_mask.jsonl (gather kernel and two-pass "
+                              "pair side by side: no overlap)", "profiles/r01_probe_mall.jsonl (intermediate through the Infinity Cache: x 1.3 only)",
+                              "MI355X_MICROARCH.md (6.29 TB/s copy rate)"],
+            "bound_statement": "uniform-random columns over an 80 MB x: measured, this algorithm's ceiling (design_ceiling_frac) and the "
+                               "ceiling of any exact-fp64 kernel on this chip (any_kernel_ceiling_frac); the 0.60 target needs 364 G "
+                               "gathers/s or 14 bytes per entry"}
 
 
 def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
@@ -699,32 +756,9 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     # wave per panel (the default pass 2 adds with sixteen waves in arrival order)
     repro = None
     if not _multi(world) and hasattr(prov, "capi") and not args.no_reproducible_cost:
-        try:
-            def ten(reproducible):      # the SAME handle, the same loop, the option toggled (it may be set after creation)
-                prov.capi.set_option("reproducible", reproducible)
-                for _ in range(2):
-                    A.spmv(y, x, prov.stream())
-                e0, e1 = prov.event(), prov.event()
-                e0.record()
-                for _ in range(10):
-                    A.spmv(y, x, prov.stream())
-                e1.record()
-                prov.synchronize()
-                return prov.elapsed_ms(e0, e1) / 10
-            try:
-                ms0 = ten(0)
-                ms1 = ten(1)
-                kname1 = A.kernel_name()
-                ms0b = ten(0)
-            finally:
-                prov.capi.set_option("reproducible", 0)
-            base = min(ms0, ms0b)
-            repro = {"kernel": kname1, "A_mul_B_ms": ms1, "A_mul_B_ms_arrival_order_same_loop": base,
-                     "how": "the same handle with option reproducible = 1: pass 2 of the two-pass pair then runs one wave per panel "
-                            "and adds in stream order (bit-identical run to run); ten products each, arrival order timed before and after",
-                     "reproducible_cost_pct": 100.0 * (ms1 / base - 1.0)}
-        except Exception as ex:
-            repro = {"error": repr(ex)}
+        repro = fixed_order_cost(prov, prov.capi, lambda: A.spmv(y, x, prov.stream()), lambda: A.kernel_name(),
+                                 "the same handle with option reproducible = 1: pass 2 of the two-pass pair then runs one wave per panel "
+                                 "and adds in stream order (bit-identical run to run); ten products each")
 
     if rank != 0:
         return None
@@ -761,6 +795,8 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    if not _multi(world) and not strong and n_global == 10_000_000 and per == 16:
+        rec["roofline"].update(config2_bound(bytes_per_launch))
     if _multi(world):
         rec["config"].update({
             "exchange": {"y": "all-gather of the y shards, started part by part inside the product (%d parts)" % nparts,
@@ -850,6 +886,26 @@ def run_c3(args, prov, world, rank, nccl):
     except Exception as ex:
         sc = {"ok": False, "error": repr(ex)}
     ka_name, kt_name = A.kernel_name(), At.kernel_name()
+    repro = None
+    if not args.no_reproducible_cost:
+        xs_, us_ = prov.sin_vector(ncol, 7.0, 0.3), prov.sin_vector(nrow, 11.0, -0.2)      # non-integer data: the order matters
+
+        def both():
+            A.spmv(y, xs_, st)
+            At.spmv(z, us_, st)
+        repro = fixed_order_cost(prov, capi, both, lambda: "A: %s; A': %s" % (A.kernel_name(), At.kernel_name()),
+                                 "the same two handles with option reproducible = 1, x = sin: the LDS-staged kernel then waits for a "
+                                 "phase's adds before its barrier (the builder keeps a row's entries of a work item with one wave) and "
+                                 "chunks that share a panel (A') add their slices in turn; ten steps each")
+        if "error" not in repro:
+            try:                        # and the point of it: two runs, the same bits
+                capi.set_option("reproducible", 1)
+                both(); y1, z1 = y.clone(), z.clone()
+                both()
+                repro["two_runs_bit_identical"] = bool(torch.equal(y, y1) and torch.equal(z, z1))
+            finally:
+                capi.set_option("reproducible", 0)
+        del xs_, us_
     rec = {
         "metric": "binary SpMV (A_mul_B + At_mul_B) effective GB/s (% HBM3E peak)", "value": value, "unit": "GB/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -865,6 +921,9 @@ def run_c3(args, prov, world, rank, nccl):
         "roofline": _roofline(_klabel(ka_name, kt_name), achieved, _traffic((ka_name,), "c3", nrow, per), bpl, avg_ms,
                               2 * args.steps, "profiles/traffic_c3_%s.json" % ka_name.replace("-", "_")),
     }
+    if repro is not None:
+        rec["config"]["fixed_order_sums"] = repro
+        rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
     if not args.no_cpu_baseline:
         try:
             rec["cpu_baseline"] = cpu_baseline_c3(nrow, ncol, per, sample_rows=args.cpu_sample_rows or 2_500_000)
@@ -1132,6 +1191,20 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         sc["ok"] = all(v for v in sc.values())
     except Exception as ex:
         sc = {"ok": False, "error": repr(ex)}
+    repro = None
+    if not _multi(world) and hasattr(prov, "capi") and not args.no_reproducible_cost:
+        repro = fixed_order_cost(prov, prov.capi, lambda: prov.spmv(A, y, x), lambda: prov.kernel_name(A),
+                                 "the same handle with option reproducible = 1: one-wave pass 2 in stream order, the long rows each with "
+                                 "one wave of a workgroup and the workgroups' sums added in workgroup order; ten products each")
+        if "error" not in repro:
+            try:
+                prov.capi.set_option("reproducible", 1)
+                prov.spmv(A, y, x); y1 = y.clone()
+                prov.spmv(A, y, x)
+                repro["two_runs_bit_identical"] = bool(torch.equal(y, y1))
+                del y1
+            finally:
+                prov.capi.set_option("reproducible", 0)
     if rank != 0:
         return None
     kname = prov.kernel_name(A)
@@ -1156,6 +1229,9 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         "roofline": _roofline(_klabel(kname), achieved, _traffic((kname,), "c5", n_local, 0) if not _multi(world) else None, bytes_local,
                               local_ms, args.steps, "profiles/traffic_c5_%s.json" % kname.replace("-", "_")),
     }
+    if repro is not None:
+        rec["config"]["fixed_order_sums"] = repro
+        rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
     if _multi(world):
         rec["config"]["rccl_status"] = "first contact: no multi-GPU machine was available to the builder"
     if not _multi(world) and not args.no_cpu_baseline and hasattr(prov, "capi"):

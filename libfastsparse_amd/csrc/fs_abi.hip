@@ -394,6 +394,15 @@ int fs_debug_long_rows(fs_matrix_t A, int transposed, int64_t *out2)
   return FS_OK;
 }
 
+// 1 when the LDS-staged copy of A (transposed != 0: of A') can give fixed-order sums (TiledCsr::orderable), 0 when not, < 0 without one
+int fs_debug_ldsx_orderable(fs_matrix_t A, int transposed)
+{
+  if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.tiledx || !a.tiledx->built) return FS_ERR_ARG;
+  return a.tiledx->orderable ? 1 : 0;
+}
+
 int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
 {
   const bool hx = A && A->a.tiledx && A->a.tiledx->built;     // the LDS-staged copy when that is the one built
@@ -403,8 +412,8 @@ int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
   return FS_OK;
 }
 
-#if defined(FS_DMA_TRACE) && FS_DMA_TRACE
-// instrumented builds only (-DFS_DMA_TRACE=1|2, tools/dma_phase_trace.py): clock sums of wave 0 of every workgroup of the DMA kernel
+#if defined(FS_LAB) && defined(FS_DMA_TRACE) && FS_DMA_TRACE
+// instrumented builds only (-DFS_LAB -DFS_DMA_TRACE=1|2, tools/dma_phase_trace.py): clock sums of wave 0 of every workgroup of the DMA kernel
 int fs_debug_dma_trace(unsigned long long *out8, int reset) { return fs::debug_dma_trace(out8, reset); }
 #endif
 

@@ -270,8 +270,8 @@ struct Options {
   int tile_rows = 0;     // override R (0 = auto)
   int tile_cols = 0;     // override W (0 = auto)
   int tile_split = 0;    // rows longer than this are cut into virtual rows (0 = 256)
-  int tiled_flags = 0;   // tuning switches of the tiled kernels (launch_spmv_tiled): bit 0 cached entry loads, bit 1 the first
-                         // LDS-staged kernel, bit 2 no LDS DMA for the x slices (spmv_ldsx_pipe_kernel); FS_TILED_FLAGS presets it
+  int tiled_flags = 0;   // tuning switches of the tiled kernels (launch_spmv_tiled): bit 0 cached entry loads, bit 2 no LDS DMA
+                         // for the x slices (spmv_ldsx_pipe_kernel); FS_TILED_FLAGS presets it
   int reproducible = 0;  // 1: only kernels whose sums are bit-identical run to run (the two-pass kernels add with LDS
                          // atomics in arrival order); read when a matrix is created and at every product
   int bin_wgs = 0;       // override the number of persistent pass-1 workgroups (0 = one per CU)
@@ -310,7 +310,7 @@ struct FixedOrderScope {
 
 // ---- launchers implemented in fs_kernels.hip --------------------------------------------
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
-int debug_dma_trace(unsigned long long *out8, int reset);   // defined in -DFS_DMA_TRACE builds only
+int debug_dma_trace(unsigned long long *out8, int reset);   // defined in -DFS_LAB -DFS_DMA_TRACE builds only (experiments/ldsx_dma_lab.inc)
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // never builds, never waits: see prepare_spmm
 int prepare_spmm(DeviceCsr &A, int k, hipStream_t s);   // k-column copy, scratch, measured choice: synchronous, idempotent
 int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare);   // which kernel launch_spmm runs for this k (kPlan* in fs_kernels.hip)

@@ -191,7 +191,7 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
     int64_t b = 4 * A.nnz + (T->vals ? 8 * A.nnz : 0) + 16ll * T->nitems + 4ll * (T->P + 1) * 2;
     if (T->vfirst) b += 4ll * (A.nrow + 1);
     if (T->yv) b += 8ll * (T->split ? T->nvrow : A.nrow);
-    b += 12ll * T->nchunks;
+    b += 16ll * T->nchunks + (T->ticket ? 4ll * T->P : 0);
     return b;
   };
   auto binned_bytes = [&](const BinnedCsr *N) -> int64_t {
@@ -199,7 +199,8 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
     int64_t b = N->n * (2 + 2 + 8ll * N->kw + (N->vals ? 8 : 0)) + 4 * (N->n / (kBinGroup / N->kw)) + 4ll * (N->B + 1) + 8ll * (N->P + 1);
     if (N->vfirst) b += 4ll * (A.nrow + 1);
     if (N->yv) b += 8ll * N->nvrow * N->kw;
-    if (N->lr) b += N->lr->n * (4 + (N->lr->vals ? 8 : 0)) + 12ll * N->lr->nlong + 8ll * (N->lr->B + 1);
+    if (N->lr) b += N->lr->n * (4 + (N->lr->vals ? 8 : 0)) + 12ll * N->lr->nlong + (8ll + 4ll * (kLongOwners + 1)) * (N->lr->B + 1) +
+                    8ll * N->lr->nwg * N->lr->nlong;
     return b;
   };
   out[0] = (A.owns ? 4ll * (A.nrow + 1) + 4 * A.nnz + (A.vals ? 8 * A.nnz : 0) : 0) + 4ll * (A.nchunks + 1) + 16ll * A.nchunks;
@@ -859,9 +860,23 @@ constexpr int kReorderThreads = 256;
 constexpr int kReorderSegs = kReorderThreads / 32;               // the item is counted in 8 segments at once
 constexpr int kReorderPer = kTiledItem / kReorderThreads;        // entries per thread when the item is copied out
 
+// Fixed-order sums (TiledCsr::orderable): a half of the sequence of 64 places is what ONE wave of the kernel adds with one
+// instruction (thread = stored position / 2, wave = thread / 64), and a wave's LDS adds execute in program order.  So when all
+// entries of a row inside an item sit with one wave, the row's y slot receives them in a fixed order whatever the other waves do.
+// Rows with more than one entry in an item are few (config 3: 1 700 entries over 13 000 rows, ~110 of them) -- after the
+// rounds, every such row is brought together: its entries swap places with single-entry rows of the same class (the class
+// decides the LDS bank, so the bank arrangement of the rows is untouched; the column banks of the swapped pair change).
+// *bad counts the items where that was not possible (a row with more entries than a wave has places for its class, a class
+// too large to search): fixed-order products then leave this copy alone.
+constexpr int kRepairMaxClass = 256;   // entries of one class the repair searches (2048 / 32 = 64 on average)
+constexpr int kRepairMaxGroup = 8;     // entries of one row inside an item the per-class pass handles
+constexpr int kRepairMaxLeft = 128;    // rows of an item left to the any-class pass
+constexpr int kRepairMaxBig = 96;      // entries of one row inside an item at most (a wave holds 128 entries of an item)
+
 template <bool ARRANGE>
 __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int4 *__restrict__ items, int lcol_bits,
-                                                                      unsigned *__restrict__ pk, double *__restrict__ vals)
+                                                                      unsigned *__restrict__ pk, double *__restrict__ vals,
+                                                                      int *__restrict__ bad)
 {
   __shared__ unsigned w[kTiledItem];
   __shared__ unsigned short lst[kTiledItem];   // entries grouped by (row class, column bank), stored order inside a group
@@ -871,6 +886,14 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
   __shared__ unsigned short size[32 * 32];     // entries of (class, bank)
   __shared__ unsigned short off[32 * 32];      // first entry of (class, bank) in lst
   __shared__ int owner[32];
+  // the repair: per class (entries of class c are indices off[c * 32] .. of these arrays, in round order)
+  __shared__ unsigned short cplace[kTiledItem];   // place in the sequence
+  __shared__ unsigned short crow[kTiledItem];     // local row
+  __shared__ unsigned short lead[kTiledItem];     // first index of the class with the same row
+  __shared__ unsigned char flag[kTiledItem];      // bit 0: a leader whose row has further entries; bit 1: placed for good
+  __shared__ unsigned short unres[kRepairMaxLeft]; // leaders of the rows the per-class pass could not bring together
+  __shared__ unsigned short pmem[kRepairMaxBig];  // the entries of one such row
+  __shared__ int nunres, ndup, wcount[32];
   const int4 d = items[blockIdx.x];
   const int n = d.y, t = threadIdx.x;
   for (int i = t; i < n; i += kReorderThreads) w[i] = pk[(int64_t)d.x + i];
@@ -956,15 +979,133 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
         const int before = left[k];
         left[k] = (unsigned short)(before - 1);
         if (before == 1) avail &= ~(1u << bank);
+        const int place = placed + __popc(nonempty & ((1u << t) - 1u));
+        seq[place] = lst[off[k] + (size[k] - before)];
+        cplace[off[t * 32] + (mine - remaining)] = (unsigned short)place;
         --remaining;
-        seq[placed + __popc(nonempty & ((1u << t) - 1u))] = lst[off[k] + (size[k] - before)];
       }
       placed += __popc(nonempty);
     }
   }
   __syncthreads();
-  // copy out: sources into registers first (the item is permuted in place)
   const int half = (n + 1) >> 1;
+  // ---- the repair: the entries of a row with one wave ----------------------------------------------------------------------
+  {
+    // (a) every index: its row, and the first index of its class with the same row
+    for (int g = t; g < n; g += kReorderThreads) crow[g] = (unsigned short)(w[seq[cplace[g]]] >> lcol_bits);
+    __syncthreads();
+    bool too_large = false;
+    for (int g = t; g < n; g += kReorderThreads) {
+      const int c = crow[g] & 31;
+      const int base = off[c * 32];
+      flag[g] = 0;
+      if (g - base >= kRepairMaxClass) { too_large = true; lead[g] = (unsigned short)g; continue; }
+      int first = g;
+      for (int j = base; j < g; ++j)
+        if (crow[j] == crow[g]) { first = j; break; }
+      lead[g] = (unsigned short)first;
+    }
+    __syncthreads();
+    if (t == 0) { nunres = 0; ndup = 0; }
+    __syncthreads();
+    {
+      int mydup = 0;
+      for (int g = t; g < n; g += kReorderThreads)
+        if (lead[g] != g) { flag[lead[g]] = 1; ++mydup; }          // (several writers, one value)
+      if (mydup) atomicAdd(&ndup, mydup);
+    }
+    __syncthreads();
+    // an item in which every fourth entry repeats a row (dense rows: long rows of a short panel) is not worth the search: the
+    // copy then simply has no fixed-order form
+    const bool hopeless = 4 * ndup > n && n > 128;   // (up to 128 entries all sit with wave 0 anyway)
+    // (b) lane c of wave 0 brings the rows of class c together, one after the other, trading places with single-entry rows of
+    // the SAME class only (the lanes work on disjoint lists); what does not fit that way goes on the list of (c)
+    bool failed = too_large || hopeless;
+    auto wave_of = [&](int g) { const int sp = cplace[g]; return (sp < half ? sp : sp - half) >> 6; };
+    auto trade = [&](int j, int k, int g) {                     // member at index j <-> single-entry row at index k
+      const unsigned short ej = seq[cplace[j]], ek = seq[cplace[k]];
+      seq[cplace[j]] = ek; seq[cplace[k]] = ej;
+      const unsigned short rj = crow[j]; crow[j] = crow[k]; crow[k] = rj;
+      lead[k] = (unsigned short)g; flag[k] = 2;                  // the member now lives at k, for good
+      lead[j] = (unsigned short)j; flag[j] = 0;                  // j holds the single-entry row
+    };
+    if (t < 32 && mine > 0 && !hopeless) {
+      const int base = off[t * 32], m = mine < kRepairMaxClass ? mine : kRepairMaxClass;
+      for (int g = base; g < base + m; ++g) {
+        if (lead[g] != g || !(flag[g] & 1) || (flag[g] & 2)) continue;
+        int mem[kRepairMaxGroup], gs = 0;
+        bool fits = true;
+        for (int j = g; j < base + m; ++j)
+          if (lead[j] == g) { if (gs < kRepairMaxGroup) mem[gs++] = j; else fits = false; }
+        bool done = false;
+        for (int cand = 0; fits && !done && cand < gs + 16; ++cand) {
+          const int v = cand < gs ? wave_of(mem[cand]) : cand - gs;     // the members' own waves first, then every wave
+          int room = 0;
+          for (int j = base; j < base + m; ++j)
+            if (wave_of(j) == v && (lead[j] == g || (lead[j] == j && !(flag[j] & 3)))) ++room;
+          if (room < gs) continue;
+          int next = base;
+          for (int q = 0; q < gs; ++q) {
+            const int j = mem[q];
+            if (wave_of(j) == v) { flag[j] |= 2; continue; }
+            while (next < base + m && !(wave_of(next) == v && lead[next] == next && !(flag[next] & 3))) ++next;   // a single-entry row with wave v
+            if (next >= base + m) { failed = true; break; }      // (cannot happen: `room` counted it)
+            trade(j, next, g);
+          }
+          done = true;
+        }
+        if (!done) {
+          const int slot = atomicAdd(&nunres, 1);
+          if (slot < kRepairMaxLeft) unres[slot] = (unsigned short)g; else failed = true;
+        }
+      }
+    }
+    __syncthreads();
+    // (c) what is left -- rows with more entries than a wave has places for their class, or an unlucky packing -- trades places
+    // with single-entry rows of ANY class of the chosen wave (a few lanes of that wave then share a bank: rare).  One row after
+    // the other; the whole workgroup counts the members and the free single-entry rows per wave, thread 0 chooses and trades.
+    {
+      const int left = hopeless ? 0 : (nunres < kRepairMaxLeft ? nunres : kRepairMaxLeft);    // (uniform: nunres is in LDS)
+      if (!hopeless && nunres > kRepairMaxLeft) failed = true;
+      for (int u = 0; u < left; ++u) {
+        const int g = unres[u];
+        if (t < 32) wcount[t] = 0;                               // [0, 16): members per wave, [16, 32): free single-entry rows
+        __syncthreads();
+        for (int j = t; j < n; j += kReorderThreads) {
+          const int v = wave_of(j);
+          if (lead[j] == g) atomicAdd(&wcount[v], 1);
+          else if (lead[j] == j && !(flag[j] & 3)) atomicAdd(&wcount[16 + v], 1);
+        }
+        __syncthreads();
+        if (t == 0 && !failed) {
+          const int c = crow[g] & 31, base = off[c * 32];
+          int m = (c < 31 ? (int)off[(c + 1) * 32] : n) - base;
+          if (m > kRepairMaxClass) m = kRepairMaxClass;
+          int gs = 0;
+          for (int j = g; j < base + m; ++j)
+            if (lead[j] == g) { if (gs < kRepairMaxBig) pmem[gs] = (unsigned short)j; ++gs; }
+          int best = -1;                                         // the wave that already holds most of the row, among those with room
+          for (int v = 0; v < 16; ++v)
+            if (wcount[v] + wcount[16 + v] >= gs && (best < 0 || wcount[v] > wcount[best])) best = v;
+          if (gs > kRepairMaxBig || best < 0) failed = true;
+          else {
+            int next = 0;
+            for (int q = 0; q < gs; ++q) {
+              const int j = pmem[q];
+              if (wave_of(j) == best) { flag[j] |= 2; continue; }
+              while (next < n && !(wave_of(next) == best && lead[next] == next && !(flag[next] & 3))) ++next;
+              if (next >= n) { failed = true; break; }
+              trade(j, next, g);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (failed) atomicAdd(bad, 1);
+  }
+  __syncthreads();
+  // copy out: sources into registers first (the item is permuted in place)
   double v[kReorderPer];
 #pragma unroll
   for (int j = 0; j < kReorderPer; ++j) {
@@ -1038,7 +1179,6 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   const Options &o = options();
   const int mode = ldsx ? o.ldsx : o.tiling;   // 0 never, 1 when the estimates do not rule it out, 2 always
   if (mode == 0 || A.nrow == 0 || A.nnz == 0) return FS_OK;
-  if (ldsx && o.reproducible) return FS_OK;    // the LDS-staged kernel adds with atomics in arrival order
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -1230,12 +1370,19 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
   if (ldsx && T->nitems > 0) {
     static const bool arrange = [] { const char *v = getenv("FS_LDSX_ARRANGE"); return !(v && *v == '0'); }();
+    Scratch<int> bad;
+    FS_HIP(bad.alloc(1));
+    FS_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
     if (arrange)
-      hipLaunchKernelGGL(ldsx_reorder_kernel<true>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
+      hipLaunchKernelGGL(ldsx_reorder_kernel<true>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals, bad.p);
     else
-      hipLaunchKernelGGL(ldsx_reorder_kernel<false>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals);
+      hipLaunchKernelGGL(ldsx_reorder_kernel<false>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals, bad.p);
     FS_HIP(hipGetLastError());
+    int hbad = 0;
+    FS_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
     FS_HIP(hipStreamSynchronize(s));
+    T->orderable = hbad == 0;                       // every row of every item with one wave: fixed-order sums possible
+    if (trace_build() && hbad) fprintf(stderr, "[fastsparse] LDS-staged copy: %d of %d work items hold a row that does not fit one wave -- no fixed-order sums on this copy\n", hbad, T->nitems);
   }
   if (ldsx) {
     // chunks: exactly `total` of them (a whole number of generations of resident workgroups: 264 equal chunks on 256
@@ -1302,18 +1449,22 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
           return (a.ordinal & 7) < (b.ordinal & 7);
         });
     }
-    std::vector<int> chunk_panel, chunk_item;
+    std::vector<int> chunk_panel, chunk_item, chunk_ord;
     for (const Chunk &c : chunks) {
       chunk_panel.push_back(c.panel);
       chunk_item.push_back(c.first);
       chunk_item.push_back(c.last);
+      chunk_ord.push_back(c.ordinal);
     }
     T->nchunks = (int)chunk_panel.size();
     FS_HIP(traced_malloc(&T->chunk_panel, sizeof(int) * (chunk_panel.size() ? chunk_panel.size() : 1)));
     FS_HIP(traced_malloc(&T->chunk_item, sizeof(int) * (chunk_item.size() ? chunk_item.size() : 2)));
+    FS_HIP(traced_malloc(&T->chunk_ord, sizeof(int) * (chunk_ord.size() ? chunk_ord.size() : 1)));
+    FS_HIP(traced_malloc(&T->ticket, sizeof(int) * (size_t)(P > 0 ? P : 1)));
     if (!chunk_panel.empty()) {
       FS_HIP(hipMemcpy(T->chunk_panel, chunk_panel.data(), sizeof(int) * chunk_panel.size(), hipMemcpyHostToDevice));
       FS_HIP(hipMemcpy(T->chunk_item, chunk_item.data(), sizeof(int) * chunk_item.size(), hipMemcpyHostToDevice));
+      FS_HIP(hipMemcpy(T->chunk_ord, chunk_ord.data(), sizeof(int) * chunk_ord.size(), hipMemcpyHostToDevice));
     }
     if (T->shared && !T->yv) FS_HIP(traced_malloc(&T->yv, sizeof(double) * (size_t)A.nrow));
   }

@@ -12,8 +12,10 @@
 //                        default for large matrices.  Pass 1 keeps a band of x in LDS and writes the products,
 //                        regrouped by row panel, to HBM; pass 2 keeps a panel of y in LDS and adds them up.
 //                        Neither pass gathers from L2 or HBM.
-//   spmv_ldsx_kernel     y = A x on a tiled copy with bands of <= 2048 columns: the band's slice of x is staged
-//                        in LDS, so gathers and adds are LDS operations.  For dense tiles (config 3, cbcsr).
+//   spmv_ldsx_dma_kernel / spmv_ldsx_pipe_kernel
+//                        y = A x on a tiled copy with bands of <= 2048 columns: the band's slice of x is staged in LDS
+//                        (by LDS DMA when x is contiguous and aligned), so gathers and adds are LDS operations.  For dense
+//                        tiles (config 3, cbcsr).  ata_ldsx_kernel: the fused A'A x on the same copy (opt-in).
 //   spmv_tiled_kernel    y = A x on the L2-tiled copy (row panels x column bands): x gathered from L2 inside
 //                        the current band.  One 1024-thread workgroup per CU; producer waves stream the
 //                        entries and gather, consumer waves reduce the staged products into the panel's y
@@ -383,20 +385,17 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
   __syncthreads();  // ytile zeroed
   // phase IT: producers stage item IT (register set 0) into buffer IT&1, then issue the loads of IT+3
   // (set 3) and the gathers of IT+2 (set 2); consumers reduce item IT-1 from the other buffer.
-#ifndef FS_TABL
-#define FS_TABL 0
-#endif
 #define FS_PHASE(IT, D0, W0, V0, X0, D2, W2, X2, D3, W3, V3)                                   \
   if (producer) {                                                                              \
     if (DEBUG && t == 0 && (IT) >= it0 && (IT) < it1) dbg_time[(IT)] = (long long)wall_clock64(); \
-    if (FS_TABL != 4 && (IT) >= it0 && (IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
+    if ((IT) >= it0 && (IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
     D3 = FS_ITEM((IT) + 3);                                                                    \
-    if (FS_TABL != 2) tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                        \
-    if (FS_TABL != 1) tiled_gather<VALUED>(D2, W, cmask, x, xs, W2, X2);                       \
-  } else if (FS_TABL != 3 && (IT) > it0 && (IT) <= it1) {                                      \
+    tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                                          \
+    tiled_gather<VALUED>(D2, W, cmask, x, xs, W2, X2);                                         \
+  } else if ((IT) > it0 && (IT) <= it1) {                                                      \
     tiled_reduce(ytile, sprod[((IT) - 1) & 1], spk[((IT) - 1) & 1], tr, items[(IT) - 1].y, lcol_bits); \
   }                                                                                            \
-  if (FS_TABL != 5) __syncthreads();
+  __syncthreads();
   // whole rounds of four phases (no early exit: a loop body with one way through is what lets the compiler count
   // the loads in flight); phases past the last item stage and reduce nothing
   for (int it = it0 - 3; it <= it1; it += 4) {
@@ -428,6 +427,40 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
 // the residue classes): ds_add_f64 on random rows runs at 2.97 lanes per clock, conflict-free at 6.9, and the adds
 // are the largest share of the LDS time (config 3: 1.07 -> 0.87 ms with perfectly conflict-free rows).
 // ------------------------------------------------------------------------------------------
+// s_waitcnt immediate of gfx9: vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8
+#define FS_WAIT_IMM(VM, LGKM) (((VM) & 0xF) | (0x7 << 4) | (((LGKM) & 0xF) << 8) | (((VM) >> 4) << 14))
+
+// The panel's slice of y leaves LDS.  A workgroup that owns its rows stores them.  Chunks that share a panel add theirs into the
+// (zeroed) output with HBM atomics -- in arrival order, or, for fixed-order sums (`ordered`), one chunk after the other in the
+// order of their ordinals inside the panel: *ticket says whose turn it is.  Chunks of one panel are launched in ascending
+// ordinal order and workgroups are dispatched in index order, so the chunk waited for is running or done; the wait is bounded
+// all the same (a chunk that gives up adds out of turn: a wrong ORDER, never a hang).
+__device__ __forceinline__ void ldsx_store_slice(const double *__restrict__ ytile, int nr, int row0, double *__restrict__ y, int ys, bool shared,
+                                                 bool ordered, int *__restrict__ ticket, int ord)
+{
+  const int t = threadIdx.x;
+  if (!shared) {
+    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+    return;
+  }
+  // (the adds are device-scope atomics, performed at the memory side, and the ticket is read and written there too: relaxed
+  // accesses and a wait for this chunk's atomics to be acknowledged order the chunks' adds -- no cache flush is involved, which an
+  // acquire / release pair would cost on every chunk)
+  if (ordered) {
+    if (t == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ord && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
+  if (ordered) {
+    __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));   // this thread's adds are acknowledged ...
+    __syncthreads();                                 // ... and everybody's: the next chunk may start its own
+    if (t == 0) __hip_atomic_store(ticket, ord + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 constexpr int kLdsxSets = 4;                          // register sets = items in flight (8 measured no faster: 0.92 vs
                                                       // 0.89 ms on config 3, 1.87 vs 1.84 ms on its transpose)
 constexpr int kLdsxPer = kTiledItem / kTiledBlock;    // entries per thread and item (2)
@@ -459,16 +492,15 @@ __device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, 
   }
 }
 
-// A workgroup takes one CHUNK: a contiguous range of the work items of one panel (normally the whole panel; panels
-// that hold far more than their share of the entries are cut into several chunks, whose y slices are added up in
-// HBM with atomics -- the launcher then routes the output through a zeroed scratch vector).
-// ATA = true turns the kernel into the fused y = A'A x of bcsr_AA_mul_B (csr.h:305-319): the sweep above leaves
-// t = (A x) of the panel's rows in the LDS slice; a second sweep over the same work items then scatters t back through
-// the tiles, y[col] += t[row], accumulating a band's slice of y in LDS (the buffer the x slices used) and adding it to
-// y in HBM with atomics whenever the sweep moves to another band.  One pass over A's copy per phase, no copy of A'.
-// Needs one chunk per panel (the launcher checks) and a zeroed y.
-template <bool VALUED, bool NT, int NSETS, bool ATA = false>
-__global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
+// The fused y = A'A x of bcsr_AA_mul_B (csr.h:305-319) on the LDS-staged copy (fs_ata_mul, option ata_kernel = 2; opt-in: measured
+// slower than the two products it replaces).  A workgroup takes one chunk = one whole panel (the launcher checks).  Sweep 1 is the
+// LDS-staged product in its first, simplest form -- phase IT gathers x from the slice of item IT and adds into the y slice, memory
+// NSETS - 1 phases ahead in registers -- and leaves t = (A x) of the panel's rows in LDS; sweep 2 walks the same work items again
+// and scatters t back through the tiles, y[col] += t[row], accumulating a band's slice of y in LDS (the buffer the x slices
+// used) and adding it to y in HBM with atomics whenever the sweep moves to another band.  One pass over A's copy per sweep, no
+// copy of A'.  Needs a zeroed y.
+template <bool VALUED, bool NT, int NSETS>
+__global__ __launch_bounds__(kTiledBlock) void ata_ldsx_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
     const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
@@ -476,9 +508,7 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
   __shared__ double ytile[kLdsxRows];
   __shared__ double xsl[2][kLdsxCols];
   const int t = threadIdx.x;
-  const int cp = chunk_panel[blockIdx.x];
-  const int p = cp & 0x7fffffff;
-  const bool shared = cp < 0;                  // other chunks add into the same rows
+  const int p = chunk_panel[blockIdx.x] & 0x7fffffff;
   const int row0 = panel_row[p];
   const int nr = panel_row[p + 1] - row0;
   for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
@@ -542,45 +572,37 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_kernel(
     }
   }
   __syncthreads();
-  if (ATA) {
-    double *yb = xsl[0];                              // the band's slice of y (W <= kLdsxCols doubles)
-    for (int i = t; i < kLdsxCols; i += kTiledBlock) yb[i] = 0.0;
-    int band = it0 < it1 ? items[it0].z : 0;
-    __syncthreads();
-    for (int it = it0; it < it1; ++it) {
-      const int4 d = items[it];
-      if (d.z != band) {                              // wave-uniform: the sweep leaves the band, its slice goes to HBM
-        __syncthreads();
-        for (int lc = t; lc < W; lc += kTiledBlock) {
-          const double v = yb[lc];
-          if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
-          yb[lc] = 0.0;
-        }
-        band = d.z;
-        __syncthreads();
+  double *yb = xsl[0];                              // the band's slice of y (W <= kLdsxCols doubles)
+  for (int i = t; i < kLdsxCols; i += kTiledBlock) yb[i] = 0.0;
+  int band = it0 < it1 ? items[it0].z : 0;
+  __syncthreads();
+  for (int it = it0; it < it1; ++it) {
+    const int4 d = items[it];
+    if (d.z != band) {                              // wave-uniform: the sweep leaves the band, its slice goes to HBM
+      __syncthreads();
+      for (int lc = t; lc < W; lc += kTiledBlock) {
+        const double v = yb[lc];
+        if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
+        yb[lc] = 0.0;
       }
+      band = d.z;
+      __syncthreads();
+    }
 #pragma unroll
-      for (int q = 0; q < kLdsxPer; ++q) {
-        const int pos = q * kTiledBlock + t;
-        if (pos < d.y) {
-          const unsigned wq = pk[(int64_t)d.x + pos];
-          double pr = ytile[wq >> lcol_bits];
-          if (VALUED) pr *= vals[(int64_t)d.x + pos];
-          __hip_atomic_fetch_add(&yb[wq & cmask], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+    for (int q = 0; q < kLdsxPer; ++q) {
+      const int pos = q * kTiledBlock + t;
+      if (pos < d.y) {
+        const unsigned wq = pk[(int64_t)d.x + pos];
+        double pr = ytile[wq >> lcol_bits];
+        if (VALUED) pr *= vals[(int64_t)d.x + pos];
+        __hip_atomic_fetch_add(&yb[wq & cmask], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    __syncthreads();
-    for (int lc = t; lc < W; lc += kTiledBlock) {
-      const double v = yb[lc];
-      if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
-    }
-    return;
   }
-  if (shared) {
-    for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
-  } else {
-    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
+  __syncthreads();
+  for (int lc = t; lc < W; lc += kTiledBlock) {
+    const double v = yb[lc];
+    if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
   }
 }
 
@@ -610,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void ata_csr_kernel(int nrow, const int *__
 
 // The same sweep with (1) the LDS work of consecutive items overlapped and (2) half as many vector-memory instructions.
 //
-// (1) In spmv_ldsx_kernel a phase is a dependency chain per wave -- gather, wait, add, gather, wait, add, publish, drain,
+// (1) In the first version (what ata_ldsx_kernel's first sweep still is) a phase is a dependency chain per wave -- gather, wait, add, gather, wait, add, publish, drain,
 // barrier -- that all 16 waves walk in step.  Here item k's slice is published in phase k-2, its x values are gathered in
 // phase k-1 and added in phase k: nothing inside a phase waits for anything issued in it.  Costs a third slice buffer
 // (panels of <= 14336 rows) and two more register sets.  Worth 2 % (A) to 8 % (A') on config 3.
@@ -648,15 +670,6 @@ __device__ __forceinline__ void ldsx_load2_entries(const int4 d, int t, const un
   // on an odd end reads one entry of the next item (or of the slack behind the array), masked too
   const int64_t e = (int64_t)d.x + (2 * t < d.y ? 2 * t : 0);
   // (the pair types carry the alignment of ONE element: spelled out here, a template would deduce the plain vector type)
-#if defined(FS_DMA_ABL) && FS_DMA_ABL == 5
-  // ablation (timing only, results wrong): HALF the entry bytes with the same number of loads -- what a 16-bit entry would move
-  if (!VALUED) {
-    const unsigned *p1 = pk + (e >> 1);
-    const unsigned one = NT ? __builtin_nontemporal_load(p1) : *p1;
-    w[0] = one; w[1] = one;
-    return;
-  }
-#endif
   const v2u_a4 *pp = reinterpret_cast<const v2u_a4 *>(pk + e);
   const v2u_a4 pw = NT ? __builtin_nontemporal_load(pp) : *pp;
   w[0] = pw.x; w[1] = pw.y;
@@ -676,7 +689,8 @@ template <bool VALUED, bool NT, bool XS1, int NSETS>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_pipe_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
-    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
+    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys, int ordered,
+    const int *__restrict__ chunk_ord, int *__restrict__ ticket)
 {
   static_assert(kLdsxPer == 2 && kLdsxXPer == 2, "pair loads assume two entries and two slice values per thread");
   __shared__ double ytile[kLdsxRows];
@@ -752,11 +766,9 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_pipe_kernel(
     }
   }
   __syncthreads();
-  if (shared) {
-    for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
-  } else {
-    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
-  }
+  // (every phase ends in __syncthreads, which waits for the phase's adds: with the builder's row-per-wave items the sums of this
+  // kernel are in a fixed order as they are; `ordered` only matters for chunks that share a panel)
+  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ordered != 0, ticket + p, shared ? chunk_ord[blockIdx.x] : 0);
 }
 
 // y[r * ys] = v[r] (output of a product that went through a contiguous scratch vector)
@@ -1037,37 +1049,24 @@ __global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int n
 #ifndef FS_DMA_SETS
 #define FS_DMA_SETS 6
 #endif
-#ifndef FS_DMA_ADDS_LAST
-#define FS_DMA_ADDS_LAST 1
-#endif
-#ifndef FS_DMA_ABL
-#define FS_DMA_ABL 0   // ablation builds (timing only, results wrong): 1 no slice DMA, 3 no adds, 4 no gathers, 5 half the entry bytes, 6 neither gathers nor adds, 7 = 6 without the slice DMA
-#endif
 constexpr int kLdsxDmaSets = FS_DMA_SETS;
-#define FS_WAIT_IMM(VM, LGKM) (((VM) & 0xF) | (0x7 << 4) | (((LGKM) & 0xF) << 8) | (((VM) >> 4) << 14))
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-#ifndef FS_DMA_TRACE
-#define FS_DMA_TRACE 0   // instrumented builds (tools/dma_phase_trace.py): wave 0 of every workgroup times the segments of its phases
-#endif
-#if FS_DMA_TRACE
-__device__ unsigned long long g_dma_trace[8];
-__device__ __forceinline__ unsigned long long dma_clock()
-{
-  unsigned long long c;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : : "memory");
-  return c;
-}
-#endif
-
-template <bool VALUED, bool NT, int NSETS>
+#ifdef FS_LAB   // tools/build_variants.py only: the instrumented copy of this kernel (ablations, phase clocks) takes its place
+#include "experiments/ldsx_dma_lab.inc"
+#else
+// ORDERED (fixed-order sums): the builder has put all entries of a row inside one work item with ONE wave (TiledCsr::orderable),
+// whose LDS adds execute in program order; here the adds of a phase are additionally waited for before the phase's barrier, so
+// that adds of different phases -- which may come from different waves -- reach a y slot in phase order.
+template <bool VALUED, bool NT, int NSETS, bool ORDERED>
 __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
     const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
     const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
-    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int ys)
+    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int ys,
+    const int *__restrict__ chunk_ord, int *__restrict__ ticket)
 {
   static_assert(NSETS % 3 == 0, "the slice buffer of a phase is a compile-time constant");
   static_assert(NSETS >= 4, "the sweep starts NSETS - 1 phases early and the DMA of an item is sent three phases before it");
@@ -1108,9 +1107,6 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
   const unsigned ybase = lds_addr(ytile);
   const unsigned xbase[3] = {lds_addr(xs0), lds_addr(xs1), lds_addr(xs2)};
   __syncthreads();
-#if FS_DMA_TRACE
-  unsigned long long tr_a = 0, tr_bc = 0, tr_d = 0, tr_n = 0, tr_0 = dma_clock();
-#endif
   for (int it = first; it < it1; it += NSETS) {
 #pragma unroll
     for (int ph = 0; ph < NSETS; ++ph) {
@@ -1124,108 +1120,49 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const unsigned a = xbase[(ph + 1) % 3] + ((w[s1][q] & cmask) << 3);                // item IT+1: gathered now
-        if (FS_DMA_ABL != 4 && FS_DMA_ABL != 6 && FS_DMA_ABL != 7) asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
-        else gnew[q] = 1.0;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
       }
       {
         const int c0 = dS.z * W + 2 * t;
         const int cc = c0 + 1 < ncol ? c0 : ncol - 2;            // ncol is even and >= 2 here
-        if (FS_DMA_ABL != 1 && FS_DMA_ABL != 7)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(x + cc),
-                                           (void __attribute__((address_space(3))) *)(bfree + wave_cols), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(x + cc),
+                                         (void __attribute__((address_space(3))) *)(bfree + wave_cols), 16, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       dS = item(IT + 4);
-#if FS_DMA_ADDS_LAST
       // the gathers (and the descriptor loads) have returned: their buffer may be refilled once every wave is past the
-      // barrier.  The adds go out AFTER this wait and are not waited for: nothing but the end of the kernel reads the y slice,
-      // so they drain under the barrier and the next phase instead of holding it up
+      // barrier.  The adds go out AFTER this wait and (unless ORDERED) are not waited for: nothing but the end of the kernel
+      // reads the y slice, so they drain under the barrier and the next phase instead of holding it up
       __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(63, 0));
       // the gathered values are written by the hardware some time after the ds_read was issued: tell the compiler they are
       // live up to here, whatever uses them later, so that it can never hand their registers to something else in between
       asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));
       __builtin_amdgcn_sched_barrier(0);
-#endif
-#if FS_DMA_TRACE
-      unsigned long long tr_1 = 0;
-      if (t < 64) { tr_1 = dma_clock(); tr_a += tr_1 - tr_0; }
-      __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         if (2 * t + q < dset[s0].y) {
           double pr = gcur[q];
           if (VALUED) pr *= v[s0][q];
           const unsigned a = ybase + ((w[s0][q] >> lcol_bits) << 3);
-          if (FS_DMA_ABL != 3 && FS_DMA_ABL != 6 && FS_DMA_ABL != 7) asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
-          else asm volatile("" : : "v"(a), "v"(pr));     // (the ablation keeps the entries it no longer uses alive: their loads must stay)
+          asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
         }
       }
       // (the entries after the adds: requested right behind the DMA, 0.70 -> 0.74 ms -- memory instructions issued in a
       // burst queue up in front of the address unit)
       ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
       __builtin_amdgcn_sched_barrier(0);
-#if defined(FS_DMA_EXTRA_SALU)      // issue-slot probe: that many more scalar (and, FS_DMA_EXTRA_VALU, vector) instructions per phase
-      {
-        int dummy_s = IT;
-#pragma unroll
-        for (int e = 0; e < FS_DMA_EXTRA_SALU; ++e) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy_s));
-#if defined(FS_DMA_EXTRA_VALU)
-        int dummy_v = t;
-#pragma unroll
-        for (int e = 0; e < FS_DMA_EXTRA_VALU; ++e) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy_v));
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-#if FS_DMA_TRACE == 2      // the clock BEFORE the wait for the slice: what the issue of the adds and entries (and the adds' drain) takes
-      unsigned long long tr_3 = 0;
-      if (t < 64) { tr_3 = dma_clock(); tr_bc += tr_3 - tr_1; }
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      // (ablation 7, no DMA in the queue: the entries of item IT+2 are home, NSETS - 3 phases of entry loads stay in flight)
-      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(FS_DMA_ABL == 7 ? (VALUED ? 2 : 1) * (NSETS - 3) : (VALUED ? 5 : 3), FS_DMA_ADDS_LAST ? 15 : 0));
-#if !FS_DMA_ADDS_LAST
-      asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));   // see above
-#endif
-#if FS_DMA_TRACE == 1
-      unsigned long long tr_3 = 0;
-      if (t < 64) { tr_3 = dma_clock(); tr_bc += tr_3 - tr_1; }
-      __builtin_amdgcn_sched_barrier(0);
-#endif
+      // this wave's DMA of item IT+2 has landed (the operations issued behind it stay in flight); ORDERED: and its adds are done
+      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(VALUED ? 5 : 3, ORDERED ? 0 : 15));
       __builtin_amdgcn_s_barrier();
-#if FS_DMA_TRACE
-      if (t < 64) { tr_0 = dma_clock(); tr_d += tr_0 - tr_3; tr_n += 1; }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       gcur[0] = gnew[0]; gcur[1] = gnew[1];
     }
   }
   __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));
   __syncthreads();
-#if FS_DMA_TRACE
-  if (t == 0) {
-    atomicAdd(&g_dma_trace[0], tr_a); atomicAdd(&g_dma_trace[1], tr_bc); atomicAdd(&g_dma_trace[2], tr_d);
-    atomicAdd(&g_dma_trace[3], tr_n); atomicAdd(&g_dma_trace[4], 1ull);
-  }
-#endif
-  if (shared) {
-    for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
-  } else {
-    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
-  }
+  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ORDERED, ticket + p, shared ? chunk_ord[blockIdx.x] : 0);
 }
-
-#if FS_DMA_TRACE
-int debug_dma_trace(unsigned long long *out8, int reset)
-{
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  FS_HIP(hipDeviceSynchronize());
-  if (out8) FS_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dma_trace), sizeof(z)));
-  if (reset) FS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dma_trace), z, sizeof(z)));
-  return FS_OK;
-}
-#endif
+#endif   // FS_LAB
 
 // ------------------------------------------------------------------------------------------
 // y = A x in two streaming passes (BinnedCsr in fs_common.h).  Same callers as the kernels above.
@@ -1902,38 +1839,37 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
   if (T.ldsx) {
     // chunks of one panel add into the same rows: the output then goes through the zeroed scratch vector (a part launch
     // adds into T.yv as it is and leaves the copy to y to its caller, who zeroed T.yv before the first part)
+    // fixed-order sums: the chunks of a panel take turns (a ticket per panel, zeroed here) -- see ldsx_store_slice
+    const bool ordered = reproducible_now() && T.orderable;
     if (T.shared) {
       if (!part) FS_HIP(hipMemsetAsync(T.yv, 0, sizeof(double) * (size_t)A.nrow, s));
+      if (!part && ordered) FS_HIP(hipMemsetAsync(T.ticket, 0, sizeof(int) * (size_t)T.P, s));
       out = T.yv;
     }
     const int ost = T.shared ? 1 : ys;
     if (T.nchunks > 0) {
-#define FS_LDSX(V, N)                                                                                              \
-  hipLaunchKernelGGL((spmv_ldsx_kernel<V, N, kLdsxSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
-                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, xs, ost)
 #define FS_LDSXP(V, N, X1)                                                                                         \
   hipLaunchKernelGGL((spmv_ldsx_pipe_kernel<V, N, X1, kLdsxPipeSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s,       \
                      T.panel_row, T.W, T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, \
-                     out, xs, ost)
+                     out, xs, ost, (int)ordered, T.chunk_ord + c0, T.ticket)
       // slices by LDS DMA: unit-stride x, 16-byte aligned, an even number of columns (bit 2 of tiled_flags turns it off)
-      if (!(options().tiled_flags & (2 | 4)) && xs == 1 && A.ncol >= 2 && (A.ncol & 1) == 0 &&
+      if (!(options().tiled_flags & 4) && xs == 1 && A.ncol >= 2 && (A.ncol & 1) == 0 &&
           (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
-#define FS_LDSXD(V, N)                                                                                              \
-  hipLaunchKernelGGL((spmv_ldsx_dma_kernel<V, N, kLdsxDmaSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
-                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, ost)
-        if (A.vals) { if (nt) FS_LDSXD(true, true); else FS_LDSXD(true, false); }
-        else        { if (nt) FS_LDSXD(false, true); else FS_LDSXD(false, false); }
+#define FS_LDSXD(V, N, O)                                                                                           \
+  hipLaunchKernelGGL((spmv_ldsx_dma_kernel<V, N, kLdsxDmaSets, O>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
+                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, ost,    \
+                     T.chunk_ord + c0, T.ticket)
+#define FS_LDSXD2(V, N) do { if (ordered) FS_LDSXD(V, N, true); else FS_LDSXD(V, N, false); } while (0)
+        if (A.vals) { if (nt) FS_LDSXD2(true, true); else FS_LDSXD2(true, false); }
+        else        { if (nt) FS_LDSXD2(false, true); else FS_LDSXD2(false, false); }
+#undef FS_LDSXD2
 #undef FS_LDSXD
-      } else if (options().tiled_flags & 2) {      // bit 1: the first version (gather and add of an item in one phase)
-        if (A.vals) { if (nt) FS_LDSX(true, true); else FS_LDSX(true, false); }
-        else        { if (nt) FS_LDSX(false, true); else FS_LDSX(false, false); }
       } else if (xs == 1 && A.ncol >= 2) {
         if (A.vals) { if (nt) FS_LDSXP(true, true, true); else FS_LDSXP(true, false, true); }
         else        { if (nt) FS_LDSXP(false, true, true); else FS_LDSXP(false, false, true); }
       } else {                                     // one column of a row-major X: strided slice loads
         if (A.vals) FS_LDSXP(true, true, false); else FS_LDSXP(false, true, false);
       }
-#undef FS_LDSX
 #undef FS_LDSXP
       FS_HIP(hipGetLastError());
     }
@@ -2197,7 +2133,7 @@ int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t
   const TiledCsr *T = A.tiledx;
   if (T && T->built && !T->shared && T->nchunks > 0) {
 #define FS_ATA(V)                                                                                                        \
-  hipLaunchKernelGGL((spmv_ldsx_kernel<V, true, kLdsxSets, true>), dim3(T->nchunks), dim3(kTiledBlock), 0, s, T->panel_row, \
+  hipLaunchKernelGGL((ata_ldsx_kernel<V, true, kLdsxSets>), dim3(T->nchunks), dim3(kTiledBlock), 0, s, T->panel_row, \
                      T->W, T->lcol_bits, A.ncol, T->items, T->chunk_panel, T->chunk_item, T->pk, T->vals, x, y, 1, 1)
     if (A.vals) FS_ATA(true); else FS_ATA(false);
 #undef FS_ATA

@@ -779,12 +779,11 @@ def test_lds_staged_kernel_dense_tiles(hip, valued):
             capi.set_option("ldsx", 1)
         chosen.append(A.kernel_name())
         y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
-        # the three generations of the kernel on the same copy: slices by LDS DMA (default), through the registers
-        # (tiled_flags bit 2), the first version (bit 1); x 16-byte aligned (DMA) and 8 bytes off (falls back)
+        # the two forms of the kernel on the same copy: slices by LDS DMA (default), through the registers (tiled_flags bit 2);
+        # x 16-byte aligned (DMA) and 8 bytes off (falls back)
         xpad = torch.zeros(ncol + 1, dtype=torch.float64, device="cuda")
         xpad[1:] = torch.from_numpy(xs_).cuda()
-        for flags, xdev in ((0, torch.from_numpy(xs_).cuda()), (4, torch.from_numpy(xs_).cuda()), (2, torch.from_numpy(xs_).cuda()),
-                            (0, xpad[1:])):
+        for flags, xdev in ((0, torch.from_numpy(xs_).cuda()), (4, torch.from_numpy(xs_).cuda()), (0, xpad[1:])):
             capi.set_option("tiled_flags", flags)
             try:
                 y.fill_(-1.0)
@@ -1321,6 +1320,28 @@ def test_longest_rows_outside_the_two_pass_copy(hip, valued, geometry):
             yh = np.full(nrow, -1.0)
             A.spmv_host(yh, x)                                   # host vectors: copy, product, copy (no band ranges with long rows)
             check(yh, ("host", mode))
+            if mode == 2:
+                # fixed-order sums: the long rows STAY on their path -- every long row belongs to one wave of a
+                # workgroup, the workgroups' sums are added in workgroup order -- and repeated products are bit-identical
+                xs_ = np.sin(7.0 * np.arange(ncol) + 0.3)
+                ref_s, sc_s = O.csr_mul(nrow, rp, cc, vv, xs_), O.csr_abs_scale(nrow, rp, cc, vv, xs_)
+                xsd = torch.from_numpy(xs_).cuda()
+                capi.set_option("reproducible", 1)
+                try:
+                    assert A.kernel_name() == "two-pass"
+                    assert L.fs_debug_long_rows(A.h, 0, info) == 0 and info[0] == want
+                    runs = []
+                    for _ in range(4):
+                        y.fill_(-1.0)
+                        A.spmv(y, xsd, st)
+                        runs.append(y.cpu().numpy().copy())
+                    assert all(np.array_equal(runs[0], r_) for r_ in runs[1:]), "fixed-order long rows differ between runs"
+                    assert np.all(np.abs(runs[0] - ref_s) <= TOL * np.maximum(sc_s, 1e-300))
+                finally:
+                    capi.set_option("reproducible", 0)
+                y.fill_(-1.0)
+                A.spmv(y, xsd, st)                               # arrival order: the same sums to rounding
+                assert np.all(np.abs(y.cpu().numpy() - ref_s) <= TOL * np.maximum(sc_s, 1e-300))
             del A
     finally:
         for k_, v_ in (("binning", 1), ("long_rows", 1), ("long_min_len", 0), ("long_geometry", 0)):
@@ -2269,3 +2290,72 @@ print("OK")
     for ranks, extra in runs:
         p = subprocess.run([sys.executable, "-c", code, ranks], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, (ranks, extra, p.stdout[-1500:] + p.stderr[-1500:])
+
+
+@pytest.mark.parametrize("valued", [False, True])
+def test_lds_staged_kernel_fixed_order_sums(hip, valued):
+    """the LDS-staged kernel under fixed-order sums.  A config-3-shaped matrix (tall, dense tiles; binary like
+    config 3, and valued) keeps its LDS-staged copy under option "reproducible" -- the builder puts all entries of a row inside a
+    work item with ONE wave (fs_debug_ldsx_orderable), the kernel waits for a phase's adds before the phase's barrier, chunks that
+    share a panel (the transpose: few, long rows) add their slices in turn -- and then: x = sin, repeated products bit-identical,
+    every row within 1e-12 row-scaled of the oracle, both directions; the slices through the registers (x 8 bytes off) as well."""
+    import ctypes as C
+    import torch
+    from libfastsparse_amd import capi
+    L = capi.lib()
+    nrow, ncol, per = 1_200_000, 200_000, 48
+    rp, cc, vv = capi.synth_uniform(nrow, ncol, per, 0x0C3, valued=valued)
+    rpn, ccn = rp.cpu().numpy(), cc.cpu().numpy()
+    vvn = vv.cpu().numpy() if valued else None
+    st = capi.current_stream()
+    L.fs_debug_ldsx_orderable.argtypes = [C.c_void_p, C.c_int]
+    capi.set_option("ldsx", 2)
+    try:
+        A = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+        A.build_transpose(st)
+    finally:
+        capi.set_option("ldsx", 1)
+    assert A.kernel_name() == "lds-staged" and A.kernel_name(True) == "lds-staged"
+    assert L.fs_debug_ldsx_orderable(A.h, 0) == 1 and L.fs_debug_ldsx_orderable(A.h, 1) == 1
+    rows_all = np.repeat(np.arange(nrow, dtype=np.int32), per)
+    xs_ = np.sin(7.0 * np.arange(ncol) + 0.3)
+    us_ = np.sin(11.0 * np.arange(nrow) - 0.2)
+    ref = O.csr_mul(nrow, rpn, ccn, vvn, xs_)
+    sc = np.maximum(O.csr_abs_scale(nrow, rpn, ccn, vvn, xs_), 1e-300)
+    reft = O.coo_tmul(ncol, rows_all, ccn, vvn, us_)
+    sct = np.maximum(O.coo_tmul(ncol, rows_all, ccn, None if vvn is None else np.abs(vvn), np.abs(us_)), 1e-300)
+    xd, ud = torch.from_numpy(xs_).cuda(), torch.from_numpy(us_).cuda()
+    xoff = torch.zeros(ncol + 1, dtype=torch.float64, device="cuda")
+    xoff[1:] = xd
+    y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+    z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+    capi.set_option("reproducible", 1)
+    try:
+        assert A.kernel_name() == "lds-staged" and A.kernel_name(True) == "lds-staged"      # the copy stays
+        ys, zs = [], []
+        for _ in range(4):
+            y.fill_(-1.0); z.fill_(-1.0)
+            A.spmv(y, xd, st)
+            A.spmv(z, ud, st, transposed=True)
+            ys.append(y.cpu().numpy().copy()); zs.append(z.cpu().numpy().copy())
+        assert all(np.array_equal(ys[0], v_) for v_ in ys[1:]), "A x differs between runs under fixed-order sums"
+        assert all(np.array_equal(zs[0], v_) for v_ in zs[1:]), "A' u differs between runs under fixed-order sums"
+        assert np.all(np.abs(ys[0] - ref) <= TOL * sc) and np.all(np.abs(zs[0] - reft) <= TOL * sct)
+        # the form without LDS DMA (x not 16-byte aligned): every phase ends in a full barrier, the same guarantee
+        yo = []
+        for _ in range(2):
+            y.fill_(-1.0)
+            A.spmv(y, xoff[1:], st)
+            yo.append(y.cpu().numpy().copy())
+        assert np.array_equal(yo[0], yo[1]) and np.all(np.abs(yo[0] - ref) <= TOL * sc)
+    finally:
+        capi.set_option("reproducible", 0)
+    y.fill_(-1.0); z.fill_(-1.0)
+    A.spmv(y, xd, st)
+    A.spmv(z, ud, st, transposed=True)
+    assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * sc) and np.all(np.abs(z.cpu().numpy() - reft) <= TOL * sct)
+    # integer x: exact in every mode
+    if not valued:
+        xi = S.x_int(3, ncol)
+        A.spmv(y, torch.from_numpy(xi).cuda(), st)
+        assert np.array_equal(y.cpu().numpy(), O.csr_mul(nrow, rpn, ccn, None, xi))
