@@ -135,7 +135,9 @@ int fs_spmv_t(fs_matrix_t A, double *y, const double *x, fs_stream_t stream);
  * are final, where rows[0 .. nparts] comes from fs_spmv_part_rows (fixed for a handle, nparts and the current options:
  * the product is cut where its kernel finishes rows anyway -- panels of pass 2 of the two-pass pair, generations of
  * workgroups of the tiled kernels; a kernel that cannot be cut does everything with part 0 and reports rows = {0, nrow,
- * nrow, ...}).  All parts together are exactly fs_spmv / fs_spmv_t. */
+ * nrow, ...}).  All parts together are exactly fs_spmv / fs_spmv_t.
+ * The cuts of a (handle, nparts, kernel) are computed on first use -- a small synchronous download of the panel tables -- and kept
+ * (the eight most recent): call fs_spmv_part_rows once before a timed or captured loop; fs_spmv_part itself then only launches. */
 int fs_spmv_part_rows(fs_matrix_t A, int transposed, int nparts, int *rows /* nparts + 1 */);
 int fs_spmv_part(fs_matrix_t A, int transposed, double *y, const double *x, int part, int nparts, fs_stream_t stream);
 /* the same for k row-major columns (fs_spmm / fs_spmm_t in parts: the block-CG iteration): the one-sweep kernel of k = 2, 4 is cut

@@ -327,8 +327,19 @@ class ColBlockMatrix:
             pass
 
 
+_option_epoch = 0
+
+
 def set_option(name, value):
+    """process-wide option of the library (include/fastsparse_hip.h).  Every call moves the option epoch on: plans that depend on
+    which kernel a product runs (the row cuts of products in parts, dist.ShardedOperator) are re-made when it has moved."""
+    global _option_epoch
     check(lib().fs_set_option(name.encode(), int(value)), "fs_set_option")
+    _option_epoch += 1
+
+
+def option_epoch():
+    return _option_epoch
 
 
 def synth_uniform(nrow, ncol, per_row, seed, row_offset=0, valued=True, device="cuda"):

@@ -50,11 +50,10 @@ struct DeviceCsr {
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
-  // products in parts (spmv_part_bounds): the cuts computed last, for part_n parts of the kernel part_kind
-  int part_n = 0, part_kind = 0;
-  bool part_cut = false;
-  std::vector<int> part_rows, part_units;
+  // products in parts (spmv_part_bounds): the cuts per (number of parts, kernel), computed on first use (a synchronous download
+  // of the panel tables: call fs_spmv_part_rows before timing) and kept
   struct PartCuts { int n = 0, kind = 0; bool cut = false; std::vector<int> rows, units; };
+  std::vector<PartCuts> part_plans;
   PartCuts partk[2];           // the same for the k-column sweeps: [0] k = 2, [1] k = 4
 };
 
@@ -190,6 +189,7 @@ struct BinnedCsr {
   // cuts both passes into ranges of bands / panels so that the PCIe copies of x and y overlap them)
   unsigned *h_band_ptr = nullptr;
   int *h_panel_row = nullptr;
+  int *h_vfirst = nullptr;     // host mirror of vfirst (cut rows: the row cuts of products in parts)
 };
 
 // staging vectors, stream and events of products with HOST vectors (fs_spmv_host); one set per handle, made on first use
@@ -316,7 +316,7 @@ int prepare_spmm(DeviceCsr &A, int k, hipStream_t s);   // k-column copy, scratc
 int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare);   // which kernel launch_spmm runs for this k (kPlan* in fs_kernels.hip)
 int launch_cbcsr(const fs_cbcsr_s &A, double *y, const double *x, hipStream_t s);
 int spmv_choice(const DeviceCsr &A, const Options &o);   // 7 two-pass, 8 LDS-staged, 6 L2-tiled, 2 lanes per row, 1 chunk-streaming
-int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out);
+int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out, int *kind_out = nullptr, bool *cut_out = nullptr);
 int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int nparts, hipStream_t s);
 int spmm_part_bounds(DeviceCsr &A, int k, int nparts, const int **rows_out, const int **units_out, int *plan_out);
 int launch_spmm_part(DeviceCsr &A, double *Y, const double *X, int k, int part, int nparts, hipStream_t s);

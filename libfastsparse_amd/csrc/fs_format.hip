@@ -156,6 +156,7 @@ static void free_binned_slot(BinnedCsr *&N)
     if (q) (void)traced_free(q);
   free(N->h_band_ptr);
   free(N->h_panel_row);
+  free(N->h_vfirst);
   delete N;
   N = nullptr;
 }
@@ -894,6 +895,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
   __shared__ unsigned short unres[kRepairMaxLeft]; // leaders of the rows the per-class pass could not bring together
   __shared__ unsigned short pmem[kRepairMaxBig];  // the entries of one such row
   __shared__ int nunres, ndup, wcount[32];
+  __shared__ unsigned short wfree[32][16];
   const int4 d = items[blockIdx.x];
   const int n = d.y, t = threadIdx.x;
   for (int i = t; i < n; i += kReorderThreads) w[i] = pk[(int64_t)d.x + i];
@@ -1031,32 +1033,36 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
     };
     if (t < 32 && mine > 0 && !hopeless) {
       const int base = off[t * 32], m = mine < kRepairMaxClass ? mine : kRepairMaxClass;
+      unsigned short *free1 = &wfree[t][0];                       // free single-entry rows of this class per wave
+      for (int v = 0; v < 16; ++v) free1[v] = 0;
+      for (int j = base; j < base + m; ++j)
+        if (lead[j] == j && !(flag[j] & 3)) ++free1[wave_of(j)];
       for (int g = base; g < base + m; ++g) {
         if (lead[g] != g || !(flag[g] & 1) || (flag[g] & 2)) continue;
         int mem[kRepairMaxGroup], gs = 0;
         bool fits = true;
         for (int j = g; j < base + m; ++j)
           if (lead[j] == g) { if (gs < kRepairMaxGroup) mem[gs++] = j; else fits = false; }
-        bool done = false;
-        for (int cand = 0; fits && !done && cand < gs + 16; ++cand) {
-          const int v = cand < gs ? wave_of(mem[cand]) : cand - gs;     // the members' own waves first, then every wave
-          int room = 0;
-          for (int j = base; j < base + m; ++j)
-            if (wave_of(j) == v && (lead[j] == g || (lead[j] == j && !(flag[j] & 3)))) ++room;
-          if (room < gs) continue;
-          int next = base;
-          for (int q = 0; q < gs; ++q) {
-            const int j = mem[q];
-            if (wave_of(j) == v) { flag[j] |= 2; continue; }
-            while (next < base + m && !(wave_of(next) == v && lead[next] == next && !(flag[next] & 3))) ++next;   // a single-entry row with wave v
-            if (next >= base + m) { failed = true; break; }      // (cannot happen: `room` counted it)
-            trade(j, next, g);
-          }
-          done = true;
+        int best = -1, best_have = -1;                             // the wave that holds most of the row already, among those with room
+        for (int v = 0; fits && v < 16; ++v) {
+          int have = 0;
+          for (int q = 0; q < gs; ++q) have += wave_of(mem[q]) == v;
+          if (have + free1[v] >= gs && have > best_have) { best = v; best_have = have; }
         }
-        if (!done) {
+        if (best < 0) {
           const int slot = atomicAdd(&nunres, 1);
           if (slot < kRepairMaxLeft) unres[slot] = (unsigned short)g; else failed = true;
+          continue;
+        }
+        int next = base;
+        for (int q = 0; q < gs; ++q) {
+          const int j = mem[q];
+          if (wave_of(j) == best) { flag[j] |= 2; continue; }
+          while (next < base + m && !(wave_of(next) == best && lead[next] == next && !(flag[next] & 3))) ++next;   // a single-entry row with that wave
+          if (next >= base + m) { failed = true; break; }          // (cannot happen: free1 counted it)
+          trade(j, next, g);
+          --free1[best];
+          ++free1[wave_of(j)];                                     // j now holds the single-entry row
         }
       }
     }

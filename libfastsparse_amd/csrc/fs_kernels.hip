@@ -1995,11 +1995,14 @@ static int binned_part_cuts(const DeviceCsr &A, BinnedCsr &N, int nparts, std::v
     if (e != hipSuccess) { free(hp); return hip_fail(e, "hipMemcpy(panel_row)", __FILE__, __LINE__); }
     N.h_panel_row = hp;
   }
-  std::vector<int> vfirst;
-  if (N.split) {
-    vfirst.resize((size_t)A.nrow + 1);
-    FS_HIP(hipMemcpy(vfirst.data(), N.vfirst, sizeof(int) * vfirst.size(), hipMemcpyDeviceToHost));
+  if (N.split && !N.h_vfirst) {
+    int *hv = (int *)malloc(sizeof(int) * ((size_t)A.nrow + 1));
+    if (!hv) { set_error("out of host memory"); return FS_ERR_HIP; }
+    const hipError_t e = hipMemcpy(hv, N.vfirst, sizeof(int) * ((size_t)A.nrow + 1), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(hv); return hip_fail(e, "hipMemcpy(vfirst)", __FILE__, __LINE__); }
+    N.h_vfirst = hv;
   }
+  const int *vfirst = N.h_vfirst;
   // one pass-2 workgroup per CU (its y slice fills LDS) and launches of one stream run one after the other: a part is a
   // whole number of generations of resident workgroups -- 4 parts of 192 panels on 256 CUs would take 4 generations where
   // the undivided pass takes 3 (config 2: 768 panels)
@@ -2010,20 +2013,23 @@ static int binned_part_cuts(const DeviceCsr &A, BinnedCsr &N, int nparts, std::v
     units[(size_t)p] = (int)(w < N.P ? w : N.P);
     const int vcut = N.h_panel_row[units[(size_t)p]];
     rows[(size_t)p] = !N.split ? vcut : p == nparts ? A.nrow :
-                      (int)(std::upper_bound(vfirst.begin(), vfirst.end(), vcut) - vfirst.begin()) - 1;
+                      (int)(std::upper_bound(vfirst, vfirst + A.nrow + 1, vcut) - vfirst) - 1;
   }
   *cut = true;
   return FS_OK;
 }
 
-int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out)
+int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int **units_out, int *kind_out, bool *cut_out)
 {
   const Options &o = options();
   const int kind = spmv_choice(A, o);
-  if (A.part_n == nparts && A.part_kind == kind && !A.part_rows.empty()) {
-    *rows_out = A.part_rows.data(); if (units_out) *units_out = A.part_units.data();
-    return FS_OK;
-  }
+  for (const DeviceCsr::PartCuts &C : A.part_plans)
+    if (C.n == nparts && C.kind == kind) {
+      *rows_out = C.rows.data(); if (units_out) *units_out = C.units.data();
+      if (kind_out) *kind_out = kind;
+      if (cut_out) *cut_out = C.cut;
+      return FS_OK;
+    }
   std::vector<int> rows((size_t)nparts + 1, A.nrow), units((size_t)nparts + 1, 0);
   rows[0] = 0;
   bool cut = false;
@@ -2064,9 +2070,14 @@ int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int *
     rows.assign((size_t)nparts + 1, A.nrow);
     rows[0] = 0;
   }
-  A.part_n = nparts; A.part_kind = kind; A.part_cut = cut;
-  A.part_rows.swap(rows); A.part_units.swap(units);
-  *rows_out = A.part_rows.data(); if (units_out) *units_out = A.part_units.data();
+  if (A.part_plans.size() >= 8) A.part_plans.erase(A.part_plans.begin());
+  A.part_plans.emplace_back();
+  DeviceCsr::PartCuts &C = A.part_plans.back();
+  C.n = nparts; C.kind = kind; C.cut = cut;
+  C.rows.swap(rows); C.units.swap(units);
+  *rows_out = C.rows.data(); if (units_out) *units_out = C.units.data();
+  if (kind_out) *kind_out = kind;
+  if (cut_out) *cut_out = cut;
   return FS_OK;
 }
 
@@ -2074,11 +2085,13 @@ int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int npa
 {
   if (A.nrow == 0) return FS_OK;
   const int *rows = nullptr, *units = nullptr;
-  if (int rc = spmv_part_bounds(A, nparts, &rows, &units)) return rc;
-  if (!A.part_cut) return part == 0 ? launch_spmv(A, y, x, s) : FS_OK;
-  if (A.part_kind == 7) return launch_spmv_binned(A, y, x, s, 1, 1, units[part], units[part + 1], rows[part], rows[part + 1]);
+  int kind = 0;
+  bool cut = false;
+  if (int rc = spmv_part_bounds(A, nparts, &rows, &units, &kind, &cut)) return rc;
+  if (!cut) return part == 0 ? launch_spmv(A, y, x, s) : FS_OK;
+  if (kind == 7) return launch_spmv_binned(A, y, x, s, 1, 1, units[part], units[part + 1], rows[part], rows[part + 1]);
   if (units[part + 1] <= units[part]) return FS_OK;
-  return launch_spmv_tiled(A, A.part_kind == 8 ? *A.tiledx : *A.tiled, y, x, s, 1, 1, units[part], units[part + 1]);
+  return launch_spmv_tiled(A, kind == 8 ? *A.tiledx : *A.tiled, y, x, s, 1, 1, units[part], units[part + 1]);
 }
 
 // one sweep of a k-column two-pass copy: Y[:, 0:kw] = A X[:, 0:kw]; X / Y rows are xs / ys doubles apart
@@ -2535,8 +2548,22 @@ constexpr int kLdsxSweepMaxK = 16;
 enum { kPlanRow = 1, kPlanBinnedK = 2, kPlanBinnedCols = 3, kPlanMfma = 4, kPlanLdsxColumns = 5, kPlanLdsxStrided = 6,
        kPlanTiledStrided = 7 };
 
+// doubles of column-major scratch a k-column product on the LDS-staged copy needs (X and Y, 16-byte aligned columns)
+static size_t spmm_scratch_need(const DeviceCsr &A, int k, int64_t *ldx_out, int64_t *ldy_out)
+{
+  const int64_t ldx = ((int64_t)A.ncol + 1) & ~(int64_t)1, ldy = ((int64_t)A.nrow + 1) & ~(int64_t)1;
+  *ldx_out = ldx; *ldy_out = ldy;
+  return (size_t)k * (size_t)(ldx + ldy);
+}
+
+static bool spmm_scratch_ready(const DeviceCsr &A, int k)
+{
+  int64_t ldx, ldy;
+  return A.spmm_scratch && A.spmm_scratch_doubles >= spmm_scratch_need(A, k, &ldx, &ldy);
+}
+
 // *needs_prepare: what prepare_spmm would still do for this k -- bit 0 build the k-column two-pass copy, bit 1 measure
-// column sweeps against the row kernel (0: the plan is final)
+// column sweeps against the row kernel, bit 2 allocate the column-major scratch (0: the plan is final)
 int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
 {
   const Options &o = options();
@@ -2561,6 +2588,13 @@ int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
   // sweeps: 3.0 ms on config 2 against 3.8 ms for the row kernel; four: 4.0 against 3.5)
   if (want != 1 && (k <= 3 || want == 3) && hb && bin_order && bin_ok) return kPlanBinnedCols;
   if (want != 1 && want != 4 && k >= 2 && k <= kLdsxSweepMaxK && hx && !hb && free_order && ldsx_ok) {
+    // the sweeps run on column-major copies of X and Y in the handle's scratch, which only prepare_spmm allocates (a product
+    // never allocates: hipMalloc synchronises the device and fails under stream capture -- ADVICE r3): until then the strided
+    // sweeps (k = 2) or the row kernel serve
+    if (!spmm_scratch_ready(A, k)) {
+      if (needs_prepare) *needs_prepare |= 4 | ((want == 0 && k > 2 && A.spmm_choice[k] == 0) ? 2 : 0);
+      return k <= 2 ? kPlanLdsxStrided : kPlanRow;
+    }
     if (want != 0 || k == 2) return kPlanLdsxColumns;          // k = 2: the sweeps won every measurement
     if (A.spmm_choice[k] == 0 && needs_prepare) *needs_prepare |= 2;
     return A.spmm_choice[k] == 2 ? kPlanRow : kPlanLdsxColumns;
@@ -2570,17 +2604,16 @@ int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
   return want == 4 ? kPlanMfma : kPlanRow;
 }
 
-static int spmm_scratch_ready(DeviceCsr &A, int k, int64_t *ldx_out, int64_t *ldy_out)
+static int spmm_scratch_alloc(DeviceCsr &A, int k)      // prepare_spmm only
 {
-  const int64_t ldx = ((int64_t)A.ncol + 1) & ~(int64_t)1, ldy = ((int64_t)A.nrow + 1) & ~(int64_t)1;   // 16-byte aligned columns
-  const size_t need = (size_t)k * (size_t)(ldx + ldy);
+  int64_t ldx, ldy;
+  const size_t need = spmm_scratch_need(A, k, &ldx, &ldy);
   if (A.spmm_scratch_doubles < need) {
     if (A.spmm_scratch) FS_HIP(hipFree(A.spmm_scratch));
     A.spmm_scratch = nullptr; A.spmm_scratch_doubles = 0;
     FS_HIP(hipMalloc(&A.spmm_scratch, sizeof(double) * need));
     A.spmm_scratch_doubles = need;
   }
-  *ldx_out = ldx; *ldy_out = ldy;
   return FS_OK;
 }
 
@@ -2632,7 +2665,7 @@ static int launch_spmm_row(const DeviceCsr &A, double *Y, const double *X, int k
 static int launch_spmm_ldsx_columns(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
   int64_t ldx = 0, ldy = 0;
-  if (int rc = spmm_scratch_ready(A, k, &ldx, &ldy)) return rc;
+  if (A.spmm_scratch_doubles < spmm_scratch_need(A, k, &ldx, &ldy)) { set_error("launch_spmm: no column-major scratch (fs_matrix_prepare allocates it)"); return FS_ERR_ARG; }
   double *xt = A.spmm_scratch, *yt = A.spmm_scratch + (size_t)k * (size_t)ldx;
   if (A.ncol > 0)
     hipLaunchKernelGGL(rows_to_columns_kernel, dim3((unsigned)(((int64_t)A.ncol + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
@@ -2755,14 +2788,14 @@ int prepare_spmm(DeviceCsr &A, int k, hipStream_t s)
     if (int rc = build_binned_k(A, k == 4 ? 4 : 2, s)) return rc;     // declines (and says so in tried2 / tried4) where it would not pay
     plan = spmm_plan(A, k, &needs);
   }
-  if (plan == kPlanLdsxColumns) {                 // scratch first: its hipMalloc may stall and must not be inside a timed run
-    int64_t ldx, ldy;
-    if (spmm_scratch_ready(A, k, &ldx, &ldy) != FS_OK) {
-      (void)hipGetLastError();                     // no room for the column-major copies: this k runs on the row kernel
-      if (k <= kLdsxSweepMaxK) A.spmm_choice[k] = 2;
+  if (needs & 4) {                                // scratch first: its hipMalloc may stall and must not be inside a timed run
+    if (spmm_scratch_alloc(A, k) != FS_OK) {
+      (void)hipGetLastError();                     // no room for the column-major copies: this k stays on the strided sweeps / the row kernel
       return FS_OK;
     }
+    plan = spmm_plan(A, k, &needs);
   }
+  (void)plan;
   if (!(needs & 2)) return FS_OK;
   // LDS-staged copy, k = 3..16: time one run of each candidate on zero operands (same addresses and traffic as any X)
   // after an untimed run of each (code objects loaded, TLB warm)

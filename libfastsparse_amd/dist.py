@@ -16,6 +16,15 @@ import torch
 import torch.distributed as dist
 
 
+def _option_epoch():
+    """the library's option epoch (capi.set_option counts); 0 when the HIP library is not in use (gloo tests with injected kernels)"""
+    try:
+        from . import capi
+        return capi.option_epoch()
+    except Exception:
+        return 0
+
+
 def _single(world):
     """one rank and nothing to exchange -- unless FS_DIST_FORCE_COLLECTIVES=1 asks for the multi-rank code path anyway (a
     one-rank RCCL group on the one-GPU box: the collectives, their stream ordering and the unpack all run; the counterpart
@@ -253,6 +262,13 @@ class ShardedOperator:
     # ---- the exchange inside the product ---------------------------------------------------------------------
     def _part_plan(self, nparts, like):
         """once per nparts: every rank's row cuts (exchanged), the padded count of every part, the unpack table"""
+        # the cuts belong to the kernel the options select: an option set since the plan was made (strict_order, reproducible,
+        # spmv_kernel move the product to another kernel, which finishes its rows elsewhere) makes every rank plan again at
+        # its next product -- ranks set options in step (SPMD), so they enter the exchange of the cuts together (ADVICE r3)
+        epoch = _option_epoch()
+        if getattr(self, "_plan_epoch", None) != epoch:
+            self._plan.clear()
+            self._plan_epoch = epoch
         key = (nparts, like.device)
         if key in self._plan:
             return self._plan[key]

@@ -1421,7 +1421,10 @@ def test_spmm_never_waits_prepare_decides(hip, k):
         X = np.ascontiguousarray(np.stack([S.x_int(11 + j, ncol) for j in range(k)], 1))
         ref = O.csr_mul_n(nrow, rp, cc, None, X, k)
         Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
-        assert A.spmm_plan(k) == "lds-staged per column"
+        # before prepare: nothing is allocated inside a product -- strided sweeps of the LDS-staged kernel (k = 2) or
+        # the row kernel run on what the handle holds; prepare allocates the column-major scratch and measures
+        assert A.spmm_plan(k) == ("lds-staged strided" if k == 2 else "row"), A.spmm_plan(k)
+        assert A.device_bytes()[2] == 0
         A.spmm(Y, torch.from_numpy(X).cuda(), k, st)
         assert np.array_equal(Y.cpu().numpy(), ref)
         A.prepare(k, st)

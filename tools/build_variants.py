@@ -1,7 +1,10 @@
 """Experiment builds of the library next to the product build: fs_kernels.hip (and fs_abi.hip, for the debug exports) compiled with
 extra -D flags, linked with the product build's other objects into libfastsparse_amd/build/variants/libfs_<name>.so; a tool then runs
 with FS_LIB_PATH=<that file>.  Several variants fit into ONE gpurun call, i.e. are timed on the same box.
-    python tools/build_variants.py name=-DFS_DMA_ABL=3 other="-DFS_DMA_ABL=4 -DFS_DMA_SETS=9" ..."""
+    python tools/build_variants.py name=-DFS_DMA_ABL=3 other="-DFS_DMA_ABL=4 -DFS_DMA_SETS=9" ...
+A variant whose flags name one of the laboratory switches (FS_DMA_ABL, FS_DMA_TRACE, FS_DMA_EXTRA_*, FS_DMA_ADDS_LAST) is built with
+-DFS_LAB, which swaps the instrumented copy of the LDS-DMA kernel (csrc/experiments/ldsx_dma_lab.inc) in for the product kernel;
+the product build never sees that file."""
 import os
 import subprocess
 import sys
@@ -14,6 +17,8 @@ from libfastsparse_amd import _build  # noqa: E402
 
 def one(spec):
     name, flags = spec.split("=", 1)
+    if any(k in flags for k in ("FS_DMA_ABL", "FS_DMA_TRACE", "FS_DMA_EXTRA", "FS_DMA_ADDS_LAST")) and "-DFS_LAB" not in flags:
+        flags = "-DFS_LAB " + flags
     out_dir = os.path.join(_build.OBJ, "variants")
     os.makedirs(out_dir, exist_ok=True)
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + _build.CSRC]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for one python program of this repo: kernel stats + PMC passes (separate runs, --kernel-trace only, the
-# program directly behind `--`).   tools/profile_r03.sh <tag> <outdir> <script.py> <args...>      (run from the repo root)
+# program directly behind `--`).   tools/profile.sh <tag> <outdir> <script.py> <args...>      (run from the repo root)
 # Summaries: <outdir>/<tag>_kernel_stats.csv and <outdir>/<tag>_pmc_summary.csv (tools/pmc_summary.py).  FULL=1 adds the SQ / GRBM passes.
 set -u
 tag=$1; out=$2; shift 2

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""profiles/traffic_*.json (what bench.py's roofline.traffic reads) from this round's PMC summaries (tools/profile.sh ->
+tools/pmc_summary.py): HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB, per dispatch; the x 2 is the gfx950
+correction of MI355X_MICROARCH.md's HBM section: FETCH_SIZE counts a 128-byte fabric request as 64 bytes).
+    python tools/refresh_traffic.py r04"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+
+
+def rows_of(name):
+    out = {}
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
+        out[(r["kernel"], int(r["workgroups"]))] = (2.0 * float(r["mean_FETCH_SIZE"]) + float(r["mean_WRITE_SIZE"])) * 1024.0
+    return out
+
+
+def pick(d, prefix, wg=None):
+    ks = [k for k in d if k[0].startswith(prefix) and (wg is None or k[1] == wg)]
+    assert len(ks) == 1, (prefix, wg, list(d))
+    return d[ks[0]], "%s (%d workgroups)" % ks[0]
+
+
+def dump(name, obj):
+    json.dump(obj, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
+    print(name, "%.3f GB" % (obj["hbm_bytes_per_launch"] / 1e9))
+
+
+c2 = rows_of("%s_c2_pmc_summary.csv" % tag)
+e, en = pick(c2, "fs::spmv_expand_kernel")
+r, rn = pick(c2, "fs::spmv_reduce_kernel")
+dump("traffic_spmv_two_pass.json", {
+    "kernel": "%s + %s (one product of the two-pass SpMV)" % (en, rn), "workload": "BASELINE config 2 (10M x 10M, 16 nnz/row)",
+    "rows": 10000000, "per_row": 16, "parts": {"expand": e, "reduce": r}, "hbm_bytes_per_launch": e + r,
+    "algorithmic_bytes": 2120000004, "bytes_per_entry": (e + r) / 160e6,
+    "source": "profiles/%s_c2_pmc_summary.csv: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+              "`python3 bench.py --workload c2 --steps 10 --warmup 2`; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)" % tag})
+c3 = rows_of("%s_c3_pmc_summary.csv" % tag)
+a, an = pick(c3, "fs::spmv_ldsx_dma_kernel", 768)
+t, tn = pick(c3, "fs::spmv_ldsx_dma_kernel", 2048)
+dump("traffic_c3_lds_staged.json", {
+    "rows": 10000000, "per_row": 64, "kernel": "%s; A': %s" % (an, tn), "hbm_bytes_per_launch": (a + t) / 2.0, "A_mul_B_bytes": a,
+    "At_mul_B_bytes": t, "algorithmic_bytes": 2670000004,
+    "source": "profiles/%s_c3_pmc_summary.csv: 2 x FETCH_SIZE + WRITE_SIZE per dispatch, mean over the step's two products" % tag})
+c5 = rows_of("%s_c5_pmc_summary.csv" % tag)
+e, en = pick(c5, "fs::spmv_expand_kernel")
+lr, ln = pick(c5, "fs::spmv_longrows_kernel")
+r, rn = pick(c5, "fs::spmv_reduce_kernel")
+cb, cn = pick(c5, "fs::tiled_combine_kernel")
+old = json.load(open(os.path.join(ROOT, "profiles", "traffic_c5_two_pass.json")))
+dump("traffic_c5_two_pass.json", {
+    "rows": old["rows"], "per_row": 0, "kernel": "%s + %s + %s + %s (one product)" % (en, ln, rn, cn),
+    "hbm_bytes_per_launch": e + lr + r + cb, "parts": {"expand": e, "longrows": lr, "reduce": r, "combine": cb},
+    "algorithmic_bytes": old["algorithmic_bytes"],
+    "source": "profiles/%s_c5_pmc_summary.csv (the 12 032 longest rows outside the two-pass copy); 2 x FETCH_SIZE + WRITE_SIZE" % tag})
