@@ -308,7 +308,7 @@ struct FixedOrderScope {
   FixedOrderScope &operator=(const FixedOrderScope &) = delete;
 };
 
-// ---- launchers implemented in fs_kernels.hip --------------------------------------------
+// ---- launchers implemented in fs_kernels.hip, fs_kernels_tiled.hip, fs_kernels_twopass.hip ------------
 int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, bool force_stream = false);
 int debug_dma_trace(unsigned long long *out8, int reset);   // defined in -DFS_LAB -DFS_DMA_TRACE builds only (experiments/ldsx_dma_lab.inc)
 int launch_spmm(DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s);   // never builds, never waits: see prepare_spmm
@@ -320,6 +320,10 @@ int spmv_part_bounds(DeviceCsr &A, int nparts, const int **rows_out, const int *
 int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int nparts, hipStream_t s);
 int spmm_part_bounds(DeviceCsr &A, int k, int nparts, const int **rows_out, const int **units_out, int *plan_out);
 int launch_spmm_part(DeviceCsr &A, double *Y, const double *X, int k, int part, int nparts, hipStream_t s);
+int launch_tiled_combine(int row_end, const int *vfirst, const double *yv, double *y, int ys, int row0, hipStream_t s);   // rows row0 .. row_end
+int launch_strided_copy(int n, const double *v, double *y, int ys, hipStream_t s);
+int launch_expand_groups(const DeviceCsr &A, const double *x, unsigned g0, unsigned g1, int wgs, hipStream_t s);   // pass 1, groups g0 .. g1
+int launch_reduce_panels(const DeviceCsr &A, double *y, int p0, int p1, hipStream_t s);                             // pass 2, panels p0 .. p1
 int launch_copy_segments(int nseg, const int64_t *tab_dev, int64_t max_count, const double *src, double *dst, hipStream_t s);
 int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s);   // y[ncol] = A'A x, one kernel
 // y_host = A x_host: copies and kernels overlapped where the kept copy allows it (two-pass copy without cut rows)

@@ -6,60 +6,31 @@
 // storage order is bit-identical to the CPU order.  All kernels are HBM/gather bound
 // (0.17 flop/B), the spare multiply issue slot costs nothing.
 //
-// Kernels
-//   spmv_expand_kernel / spmv_reduce_kernel
-//                        y = A x in two streaming passes on the two-pass copy (column bands x row panels): the
-//                        default for large matrices.  Pass 1 keeps a band of x in LDS and writes the products,
-//                        regrouped by row panel, to HBM; pass 2 keeps a panel of y in LDS and adds them up.
-//                        Neither pass gathers from L2 or HBM.
-//   spmv_ldsx_dma_kernel / spmv_ldsx_pipe_kernel
-//                        y = A x on a tiled copy with bands of <= 2048 columns: the band's slice of x is staged in LDS
-//                        (by LDS DMA when x is contiguous and aligned), so gathers and adds are LDS operations.  For dense
-//                        tiles (config 3, cbcsr).  ata_ldsx_kernel: the fused A'A x on the same copy (opt-in).
-//   spmv_tiled_kernel    y = A x on the L2-tiled copy (row panels x column bands): x gathered from L2 inside
-//                        the current band.  One 1024-thread workgroup per CU; producer waves stream the
-//                        entries and gather, consumer waves reduce the staged products into the panel's y
-//                        slice in LDS.  The fixed-order (run-to-run reproducible) kernel for large matrices.
-//   (which of the three runs on a matrix is the format builder's measured choice: fs_format.hip, choose_copy)
-//   spmv_stream_kernel   y = A x, CSR or pattern-only CSR.  One 256-thread workgroup streams a
-//                        fixed 2048-non-zero chunk of cols/vals with 16-byte loads, gathers x,
-//                        parks the products in LDS and reduces them per row.  Work per
-//                        workgroup is independent of the row-length distribution.
-//   spmv_fixup_kernel    adds up the partial sums of rows that cross chunk boundaries
-//   spmv_vector_kernel   classic G-lanes-per-row CSR kernel (A/B alternative, option spmv_kernel=2)
-//   spmm_kernel          Y = A X, k row-major right-hand sides, one lane per output column
-//   cbcsr_kernel         column-blocked binary CSR, x tile staged in LDS per column block
+// Where the kernels live
+//   fs_kernels_twopass.hip  spmv_expand_kernel / spmv_reduce_kernel (+ the fixed-order pass 2), spmv_longrows_kernel,
+//                           spmm_expand_kernel / spmm_reduce_kernel: y = A x in two streaming passes on the two-pass copy (column
+//                           bands x row panels), the default for large matrices; neither pass gathers from L2 or HBM
+//   fs_kernels_tiled.hip    spmv_ldsx_dma_kernel / spmv_ldsx_pipe_kernel (the band's slice of x staged in LDS: dense tiles,
+//                           config 3, cbcsr), spmv_tiled_kernel (x gathered from an L2-resident band), ata_ldsx_kernel
+//   here                    spmv_stream_kernel + fix-ups (one workgroup per 2048-entry chunk, storage-order sums: small x,
+//                           strict_order), spmv_vector_kernel (lanes per row, A/B alternative), spmm_kernel / spmm_wide_kernel /
+//                           spmm_mfma_kernel (k right-hand sides, one lane per output column), cbcsr_kernel, and everything that
+//                           decides: spmv_choice, spmm_plan, products in parts, host-vector products
+//   (which copy a matrix keeps is the format builder's measured choice: fs_format.hip, choose_copy)
 #include <stdlib.h>
 
 #include <algorithm>
 #include <chrono>
 #include <vector>
 
-#include "fs_common.h"
+#include "fs_kernel_util.h"
 
 namespace fs {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 // LDS slot of the i-th product of a chunk: one pad slot per 16 products makes the stride
 // between consecutive 16-entry rows odd (17), so a thread-per-row sweep is conflict free.
 __device__ __forceinline__ int lds_slot(int i) { return i + (i >> 4); }
 constexpr int kLdsDoubles = kChunk + (kChunk >> 4) + 8;
-
-template <bool NT, typename T>
-__device__ __forceinline__ T stream_load(const T *p)
-{
-  if (NT) return __builtin_nontemporal_load(p);
-  return *p;
-}
-
-template <bool NT, typename T>
-__device__ __forceinline__ void stream_store(T v, T *p)
-{
-  if (NT) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
 
 // ------------------------------------------------------------------------------------------
 // y = A x, chunk-streaming kernel.
@@ -234,548 +205,6 @@ __global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__
     acc += VALUED ? xv * vals[i] : xv;
   }
   y[r] = acc;
-}
-
-// ------------------------------------------------------------------------------------------
-// y = A x on the L2-tiled copy (TiledCsr, fs_common.h).  Same products and the same per-row
-// terms as csr_A_mul_B (csr.h:425-438); the order in which a row's terms are added is
-// band-major (deterministic, run-to-run reproducible), so arbitrary x agrees with the CPU order
-// to rounding (1e-12 bar) and integer-valued x bit for bit.
-//
-// Why: with x far larger than the 4 MiB L2 of an XCD every gather of x[col] misses and pulls a
-// whole line across the fabric; measured 53-56 G gathers/s however the kernel is shaped, against
-// ~240 G/s when the gathered range is L2-resident (tools/probe_gather, profiles/).  Here one
-// workgroup owns a panel of R rows (its y slice lives in LDS) and sweeps the column bands left
-// to right; the workgroups resident together start together and advance at the same pace, so at
-// any moment an XCD gathers from one or two bands (<= 2 MiB each) that stay in its L2.
-//
-// Per work item (<= 2048 consecutive entries of one tile): coalesced loads of the packed
-// (head, row, col) words and the values, gathers of x inside the band, products parked in LDS,
-// barrier, then every entry that starts a row-run adds the run's sum into its y slot (rows of
-// different runs are distinct inside an item, so plain LDS read-add-write is race free).
-// The next item's entries are loaded while the current one is being reduced.
-// ------------------------------------------------------------------------------------------
-constexpr int kTiledPer = kTiledItem / kTiledProd;  // 4 entries per producer (and per consumer) thread
-
-// ---- producer side (waves 0-7): entries of one item for producer thread tp are positions q*512 + tp.
-// Whole 512-entry slabs past the item's end are skipped (wave-uniform test); inside the last slab the
-// position is clamped to the last entry, so the loads themselves are unconditional and the clamped lanes
-// re-read one cached word.
-// Pattern-only: every load is unconditional and nothing touches its result before the phase that needs it -- a load
-// under a branch (or a select on its result) makes the compiler lose count of what is in flight and wait for more
-// than it has to (LDS-staged kernel below: 1.63 ms with skipped slabs, 1.08 ms with straight-line phases; here 0.85
-// -> 0.82 ms).  Valued: the kernel sits at the 128-register limit and the 512-entry slabs past an item's end are
-// still skipped (unconditional: 1.23 ms, skipped: 1.05 ms on config 2).
-template <bool VALUED, bool NT>
-__device__ __forceinline__ void tiled_load(const int4 d, int tp, const unsigned *__restrict__ pk,
-                                           const double *__restrict__ vals, unsigned (&w)[kTiledPer],
-                                           double (&v)[kTiledPer])
-{
-  const int last = d.y > 0 ? d.y - 1 : 0;
-#pragma unroll
-  for (int q = 0; q < kTiledPer; ++q) {
-    if (!VALUED || q * kTiledProd < d.y || q == 0) {   // see above: slabs past the item's end are skipped when valued
-      const int pos = q * kTiledProd + tp;
-      const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
-      w[q] = stream_load<NT>(pk + e);
-      if (VALUED) v[q] = stream_load<NT>(vals + e);
-    }
-  }
-}
-
-// x may be one column of a row-major k-column X: element c lives at x[c * xs] (xs = 1 for a plain vector)
-template <bool VALUED>
-__device__ __forceinline__ void tiled_gather(const int4 d, int W, unsigned cmask, const double *__restrict__ x, int xs,
-                                             const unsigned (&w)[kTiledPer], double (&xv)[kTiledPer])
-{
-  const double *xb = x + (int64_t)d.z * W * xs;
-#pragma unroll
-  for (int q = 0; q < kTiledPer; ++q)
-    if (!VALUED || q * kTiledProd < d.y || q == 0) xv[q] = xb[(int64_t)(w[q] & cmask) * xs];
-}
-
-// products and packed words of one item into a stage buffer (entry i at spk[i + 1]; spk[0], spk[n + 1] guards)
-template <bool VALUED>
-__device__ __forceinline__ void tiled_stage(double *__restrict__ sprod, unsigned *__restrict__ spk, int tp, int n,
-                                            const unsigned (&w)[kTiledPer], const double (&v)[kTiledPer],
-                                            const double (&xv)[kTiledPer])
-{
-#pragma unroll
-  for (int q = 0; q < kTiledPer; ++q) {
-    const int pos = q * kTiledProd + tp;
-    if (pos < n) {
-      sprod[pos] = VALUED ? xv[q] * v[q] : xv[q];
-      spk[pos + 1] = w[q];
-    }
-  }
-  if (tp == 0) { spk[0] = 0xFFFFFFFFu; spk[n + 1] = 0xFFFFFFFFu; }  // row id no entry has: runs stop at both ends
-}
-
-// ---- consumer side (waves 8-15): every entry that starts a row-run adds the run's sum to its row of the
-// y slice.  The runs of one item are distinct rows: one add per address, so the LDS atomic (fire and forget,
-// no read-add-write chain in the wave) gives the same bits as a plain update, in a fixed order.
-__device__ __forceinline__ void tiled_reduce(double *__restrict__ ytile, const double *__restrict__ sprod,
-                                             const unsigned *__restrict__ spk, int tc, int n, int lcol_bits)
-{
-#pragma unroll
-  for (int q = 0; q < kTiledPer; ++q) {
-    const int pos = q * kTiledProd + tc;
-    if (pos < n) {
-      const unsigned lr = spk[pos + 1] >> lcol_bits;
-      if ((spk[pos] >> lcol_bits) != lr) {  // previous entry is another row (or the item's start): run head
-        double sum = sprod[pos];
-        int k = pos + 1;
-        while ((spk[k + 1] >> lcol_bits) == lr) { sum += sprod[k]; ++k; }
-        __hip_atomic_fetch_add(&ytile[lr], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-}
-
-// ONE 1024-thread workgroup per CU and row panel.  Waves 0-7 are producers: they stream the panel's
-// entries, gather x inside the current column band and park products in one of two LDS stage buffers.
-// Waves 8-15 are consumers: they reduce the other stage buffer into the y slice.  One barrier per item
-// separates the roles' phases, so the LDS reduction of item k-1 overlaps the memory work of items k..k+3.
-// Producer software pipeline: four register sets rotate by name (a register copy would force in-flight
-// loads to complete); while item k is staged, the gathers of k+1 and k+2 and the entry loads of k+3 are in
-// flight.  Inside a phase the loads of k+3 are issued before the gathers of k+2: vmcnt retires in order
-// and the loads are needed one phase earlier than the gathers issued with them.
-template <bool VALUED, bool NT, bool DEBUG = false>
-__global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
-    const int *__restrict__ panel_row, int W, int lcol_bits, const int4 *__restrict__ items,
-    const int *__restrict__ item_ptr, const unsigned *__restrict__ pk, const double *__restrict__ vals,
-    const double *__restrict__ x, double *__restrict__ y, int xs, int ys, long long *__restrict__ dbg_time = nullptr,
-    int *__restrict__ dbg_xcc = nullptr)
-{
-  __shared__ double ytile[kTiledRowsMax];
-  __shared__ double sprod[2][kTiledItem];
-  __shared__ unsigned spk[2][kTiledItem + 2];
-  const int t = threadIdx.x;
-  const bool producer = t < kTiledProd;      // wave-uniform: waves 0-7
-  const int tr = producer ? t : t - kTiledProd;  // index inside the role
-  const int p = blockIdx.x;
-  const int row0 = panel_row[p];
-  const int nr = panel_row[p + 1] - row0;
-  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
-  const unsigned cmask = (1u << lcol_bits) - 1u;
-  const int it0 = item_ptr[p], it1 = item_ptr[p + 1];
-  const int4 none = make_int4(0, 0, 0, 0);
-  // descriptor reads outside the panel are clamped to its items (an empty panel reads the item in front of it; the
-  // array always holds at least one) ...
-  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
-  const int itf = it1 > it0 ? it0 : itl;
-  auto item_at = [&](int i) {
-    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
-    if (i < it0 || i >= it1) d.y = 0;          // ... and emptied: one entry is loaded and gathered, nothing is staged
-    return d;
-  };
-#define FS_ITEM(i) item_at(i)
-  if (DEBUG && t == 0) {  // diagnostic build only: which XCD runs this panel, and when each item starts
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    dbg_xcc[p] = (int)(xcc & 0xf);
-  }
-  // There is no separate prologue: the sweep starts three phases early on empty items with zeroed register sets
-  // (local column 0 of band 0 is a valid address), so the pipeline fills through the same code that keeps it full
-  // and the compiler sees one steady state of loads in flight at the loop's back edge.
-  int4 dA = none, dB = none, dC = none, dD = none;
-  unsigned wA[kTiledPer] = {}, wB[kTiledPer] = {}, wC[kTiledPer] = {}, wD[kTiledPer] = {};
-  double vA[kTiledPer] = {}, vB[kTiledPer] = {}, vC[kTiledPer] = {}, vD[kTiledPer] = {};
-  double xA[kTiledPer] = {}, xB[kTiledPer] = {}, xC[kTiledPer] = {}, xD[kTiledPer] = {};
-  __syncthreads();  // ytile zeroed
-  // phase IT: producers stage item IT (register set 0) into buffer IT&1, then issue the loads of IT+3
-  // (set 3) and the gathers of IT+2 (set 2); consumers reduce item IT-1 from the other buffer.
-#define FS_PHASE(IT, D0, W0, V0, X0, D2, W2, X2, D3, W3, V3)                                   \
-  if (producer) {                                                                              \
-    if (DEBUG && t == 0 && (IT) >= it0 && (IT) < it1) dbg_time[(IT)] = (long long)wall_clock64(); \
-    if ((IT) >= it0 && (IT) < it1) tiled_stage<VALUED>(sprod[(IT) & 1], spk[(IT) & 1], tr, D0.y, W0, V0, X0); \
-    D3 = FS_ITEM((IT) + 3);                                                                    \
-    tiled_load<VALUED, NT>(D3, tr, pk, vals, W3, V3);                                          \
-    tiled_gather<VALUED>(D2, W, cmask, x, xs, W2, X2);                                         \
-  } else if ((IT) > it0 && (IT) <= it1) {                                                      \
-    tiled_reduce(ytile, sprod[((IT) - 1) & 1], spk[((IT) - 1) & 1], tr, items[(IT) - 1].y, lcol_bits); \
-  }                                                                                            \
-  __syncthreads();
-  // whole rounds of four phases (no early exit: a loop body with one way through is what lets the compiler count
-  // the loads in flight); phases past the last item stage and reduce nothing
-  for (int it = it0 - 3; it <= it1; it += 4) {
-    FS_PHASE(it, dA, wA, vA, xA, dC, wC, xC, dD, wD, vD)
-    FS_PHASE(it + 1, dB, wB, vB, xB, dD, wD, xD, dA, wA, vA)
-    FS_PHASE(it + 2, dC, wC, vC, xC, dA, wA, xA, dB, wB, vB)
-    FS_PHASE(it + 3, dD, wD, vD, xD, dB, wB, xB, dC, wC, vC)
-  }
-#undef FS_ITEM
-#undef FS_PHASE
-  for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
-}
-
-// ------------------------------------------------------------------------------------------
-// y = A x on a tiled copy whose bands are narrow enough for the band's slice of x to live in LDS
-// (W <= kLdsxCols): the north_star's "LDS staging of the dense x tile".  For matrices whose tiles are
-// dense enough (config 3: 10 M x 1 M, 64 per row -> 1 700 entries per 13 021 x 2 048 tile) loading the
-// slice costs less than gathering from L2 entry by entry: a slice is 128 full lines from L2, the tile's
-// gathers would be 1 700 separate requests.
-//
-// ONE 1024-thread workgroup per CU and row panel, y slice (<= 120 KiB) and two x slices in LDS, all 16
-// waves in the same role.  Phase IT = work item IT (<= 2048 entries of one tile, 2 per thread): gather x from
-// the LDS slice of the item's band, multiply, ds_add_f64 into the y slice.  Memory runs three phases ahead
-// in registers (four register sets rotating by name): in phase IT the entries and the x slice of item IT+3
-// are requested, the slice of item IT+1 is copied from registers to the other LDS buffer, and one barrier
-// ends the phase.  Sum order: band-major, inside an item by LDS atomics in arrival order (see the two-pass
-// kernels above for what that means).  Because the order inside an item is free, the format builder arranges every
-// item so that the 32 lanes of a half-wave add into 32 different LDS bank pairs (local row mod 32, round-robin over
-// the residue classes): ds_add_f64 on random rows runs at 2.97 lanes per clock, conflict-free at 6.9, and the adds
-// are the largest share of the LDS time (config 3: 1.07 -> 0.87 ms with perfectly conflict-free rows).
-// ------------------------------------------------------------------------------------------
-// s_waitcnt immediate of gfx9: vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8
-#define FS_WAIT_IMM(VM, LGKM) (((VM) & 0xF) | (0x7 << 4) | (((LGKM) & 0xF) << 8) | (((VM) >> 4) << 14))
-
-// The panel's slice of y leaves LDS.  A workgroup that owns its rows stores them.  Chunks that share a panel add theirs into the
-// (zeroed) output with HBM atomics -- in arrival order, or, for fixed-order sums (`ordered`), one chunk after the other in the
-// order of their ordinals inside the panel: *ticket says whose turn it is.  Chunks of one panel are launched in ascending
-// ordinal order and workgroups are dispatched in index order, so the chunk waited for is running or done; the wait is bounded
-// all the same (a chunk that gives up adds out of turn: a wrong ORDER, never a hang).
-__device__ __forceinline__ void ldsx_store_slice(const double *__restrict__ ytile, int nr, int row0, double *__restrict__ y, int ys, bool shared,
-                                                 bool ordered, int *__restrict__ ticket, int ord)
-{
-  const int t = threadIdx.x;
-  if (!shared) {
-    for (int i = t; i < nr; i += kTiledBlock) y[(int64_t)(row0 + i) * ys] = ytile[i];
-    return;
-  }
-  // (the adds are device-scope atomics, performed at the memory side, and the ticket is read and written there too: relaxed
-  // accesses and a wait for this chunk's atomics to be acknowledged order the chunks' adds -- no cache flush is involved, which an
-  // acquire / release pair would cost on every chunk)
-  if (ordered) {
-    if (t == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ord && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-  }
-  for (int i = t; i < nr; i += kTiledBlock) unsafeAtomicAdd(&y[(int64_t)(row0 + i) * ys], ytile[i]);
-  if (ordered) {
-    __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));   // this thread's adds are acknowledged ...
-    __syncthreads();                                 // ... and everybody's: the next chunk may start its own
-    if (t == 0) __hip_atomic_store(ticket, ord + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-constexpr int kLdsxSets = 4;                          // register sets = items in flight (8 measured no faster: 0.92 vs
-                                                      // 0.89 ms on config 3, 1.87 vs 1.84 ms on its transpose)
-constexpr int kLdsxPer = kTiledItem / kTiledBlock;    // entries per thread and item (2)
-constexpr int kLdsxXPer = kLdsxCols / kTiledBlock;    // x values per thread and slice (2)
-
-// Every load of a phase is unconditional and its result is not touched before the phase that needs it (addresses
-// are clamped here, lanes outside the slice are masked when the slice is published): a load under a branch, or a
-// select on its result, makes the compiler wait for it on the spot and the pipeline collapses.
-template <bool VALUED, bool NT>
-__device__ __forceinline__ void ldsx_load(const int4 d, int t, int W, int ncol, const unsigned *__restrict__ pk,
-                                          const double *__restrict__ vals, const double *__restrict__ x, int xs,
-                                          unsigned (&w)[kLdsxPer], double (&v)[kLdsxPer], double (&xr)[kLdsxXPer])
-{
-  // the slice first: it is needed one phase before the entries and vmcnt retires in order
-  const int c0 = d.z * W;
-#pragma unroll
-  for (int q = 0; q < kLdsxXPer; ++q) {
-    const int lc = q * kTiledBlock + t;
-    const int c = c0 + lc;
-    xr[q] = x[(int64_t)(c < ncol ? c : ncol - 1) * xs];
-  }
-  const int last = d.y > 0 ? d.y - 1 : 0;
-#pragma unroll
-  for (int q = 0; q < kLdsxPer; ++q) {
-    const int pos = q * kTiledBlock + t;
-    const int64_t e = (int64_t)d.x + (pos < last ? pos : last);
-    w[q] = stream_load<NT>(pk + e);
-    if (VALUED) v[q] = stream_load<NT>(vals + e);
-  }
-}
-
-// The fused y = A'A x of bcsr_AA_mul_B (csr.h:305-319) on the LDS-staged copy (fs_ata_mul, option ata_kernel = 2; opt-in: measured
-// slower than the two products it replaces).  A workgroup takes one chunk = one whole panel (the launcher checks).  Sweep 1 is the
-// LDS-staged product in its first, simplest form -- phase IT gathers x from the slice of item IT and adds into the y slice, memory
-// NSETS - 1 phases ahead in registers -- and leaves t = (A x) of the panel's rows in LDS; sweep 2 walks the same work items again
-// and scatters t back through the tiles, y[col] += t[row], accumulating a band's slice of y in LDS (the buffer the x slices
-// used) and adding it to y in HBM with atomics whenever the sweep moves to another band.  One pass over A's copy per sweep, no
-// copy of A'.  Needs a zeroed y.
-template <bool VALUED, bool NT, int NSETS>
-__global__ __launch_bounds__(kTiledBlock) void ata_ldsx_kernel(
-    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
-    const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
-    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys)
-{
-  __shared__ double ytile[kLdsxRows];
-  __shared__ double xsl[2][kLdsxCols];
-  const int t = threadIdx.x;
-  const int p = chunk_panel[blockIdx.x] & 0x7fffffff;
-  const int row0 = panel_row[p];
-  const int nr = panel_row[p + 1] - row0;
-  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
-  const unsigned cmask = (1u << lcol_bits) - 1u;
-  const int it0 = chunk_item[2 * blockIdx.x], it1 = chunk_item[2 * blockIdx.x + 1];   // [first, last) work item of the chunk
-  // descriptor reads outside the chunk are clamped to its items (an empty chunk reads the item in front of it; the
-  // array always holds at least one) ...
-  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
-  const int itf = it1 > it0 ? it0 : itl;
-  auto item = [&](int i) {
-    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
-    if (i < it0 || i >= it1) d.y = 0;           // ... and emptied: loads one entry and one slice, contributes nothing
-    return d;
-  };
-  // NSETS register sets hold the items in flight (set k % NSETS belongs to item k; all indices below are constants
-  // after unrolling, so the sets are registers).  No separate prologue: the sweep starts NSETS-1 phases early on empty
-  // items (see spmv_tiled_kernel).
-  int4 dset[NSETS];
-  unsigned w[NSETS][kLdsxPer];
-  double v[NSETS][kLdsxPer];
-  double xr[NSETS][kLdsxXPer];
-#pragma unroll
-  for (int k = 0; k < NSETS; ++k) {
-    dset[k] = item(it0 - 1);                     // an empty descriptor with valid addresses
-#pragma unroll
-    for (int q = 0; q < kLdsxPer; ++q) { w[k][q] = 0; v[k][q] = 0.0; }
-#pragma unroll
-    for (int q = 0; q < kLdsxXPer; ++q) xr[k][q] = 0.0;
-  }
-  const int first = it0 - (NSETS - 1);
-  int4 dN = item(first + NSETS - 1);              // descriptor of the item the first phase requests
-  __syncthreads();   // ytile zeroed
-  // phase IT (IT = it + ph, ph constant): request item IT+NSETS-1 into the set item IT-1 has just left (its
-  // descriptor was fetched a phase ago) and fetch the descriptor after it; consume item IT from slice buffer IT&1;
-  // publish the slice of item IT+1 in the other buffer.  Whole rounds of NSETS phases, no early exit (phases past the
-  // last item add nothing: their items are empty).  Buffer parity: `first` may be odd, so it is carried explicitly.
-  for (int it = first; it < it1; it += NSETS) {
-#pragma unroll
-    for (int ph = 0; ph < NSETS; ++ph) {
-      const int IT = it + ph;
-      const int s0 = ph, s1 = (ph + 1) % NSETS, sl = (ph + NSETS - 1) % NSETS;
-      dset[sl] = dN;
-      dN = item(IT + NSETS);
-      ldsx_load<VALUED, NT>(dset[sl], t, W, ncol, pk, vals, x, xs, w[sl], v[sl], xr[sl]);
-      const int buf = IT & 1;
-#pragma unroll
-      for (int q = 0; q < kLdsxPer; ++q) {
-        const int pos = q * kTiledBlock + t;
-        if (pos < dset[s0].y) {
-          double pr = xsl[buf][w[s0][q] & cmask];
-          if (VALUED) pr *= v[s0][q];
-          __hip_atomic_fetch_add(&ytile[w[s0][q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < kLdsxXPer; ++q) {
-        const int lc = q * kTiledBlock + t;
-        xsl[buf ^ 1][lc] = (lc < W && dset[s1].z * W + lc < ncol) ? xr[s1][q] : 0.0;
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  double *yb = xsl[0];                              // the band's slice of y (W <= kLdsxCols doubles)
-  for (int i = t; i < kLdsxCols; i += kTiledBlock) yb[i] = 0.0;
-  int band = it0 < it1 ? items[it0].z : 0;
-  __syncthreads();
-  for (int it = it0; it < it1; ++it) {
-    const int4 d = items[it];
-    if (d.z != band) {                              // wave-uniform: the sweep leaves the band, its slice goes to HBM
-      __syncthreads();
-      for (int lc = t; lc < W; lc += kTiledBlock) {
-        const double v = yb[lc];
-        if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
-        yb[lc] = 0.0;
-      }
-      band = d.z;
-      __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < kLdsxPer; ++q) {
-      const int pos = q * kTiledBlock + t;
-      if (pos < d.y) {
-        const unsigned wq = pk[(int64_t)d.x + pos];
-        double pr = ytile[wq >> lcol_bits];
-        if (VALUED) pr *= vals[(int64_t)d.x + pos];
-        __hip_atomic_fetch_add(&yb[wq & cmask], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-  __syncthreads();
-  for (int lc = t; lc < W; lc += kTiledBlock) {
-    const double v = yb[lc];
-    if (v != 0.0) unsafeAtomicAdd(&y[(int64_t)band * W + lc], v);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// y = A'A x, fused, on the plain CSR: one wave per row adds up xv = sum x[cols] and scatters it back,
-// y[cols] += xv, with HBM atomics (the loop nest of bcsr_AA_mul_B, csr.h:305-319, rows in parallel like
-// parallel_bcsr_AA_mul_B csr.h:323-355, whose per-thread replicas of y become atomics).  The general form of the
-// fused product: any matrix, no copy at all; y must be zeroed first.
-// ------------------------------------------------------------------------------------------
-template <bool VALUED>
-__global__ __launch_bounds__(kBlock) void ata_csr_kernel(int nrow, const int *__restrict__ row_ptr, const int *__restrict__ cols,
-                                                        const double *__restrict__ vals, const double *__restrict__ x,
-                                                        double *__restrict__ y)
-{
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (row >= nrow) return;
-  const int a = row_ptr[row], b = row_ptr[row + 1];
-  double acc = 0.0;
-  for (int64_t i = (int64_t)a + lane; i < b; i += 64) {
-    const double xv = x[cols[i]];
-    acc += VALUED ? xv * vals[i] : xv;
-  }
-  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
-  for (int64_t i = (int64_t)a + lane; i < b; i += 64) unsafeAtomicAdd(&y[cols[i]], VALUED ? acc * vals[i] : acc);
-}
-
-// The same sweep with (1) the LDS work of consecutive items overlapped and (2) half as many vector-memory instructions.
-//
-// (1) In the first version (what ata_ldsx_kernel's first sweep still is) a phase is a dependency chain per wave -- gather, wait, add, gather, wait, add, publish, drain,
-// barrier -- that all 16 waves walk in step.  Here item k's slice is published in phase k-2, its x values are gathered in
-// phase k-1 and added in phase k: nothing inside a phase waits for anything issued in it.  Costs a third slice buffer
-// (panels of <= 14336 rows) and two more register sets.  Worth 2 % (A) to 8 % (A') on config 3.
-// (2) What the kernel was really bound by (ablation, gpurun_out/r2n: without its global loads 0.52 ms, with them 0.88 ms,
-// while dropping the atomics, the gathers or the slice writes gained 4-5 % each and deeper pipelines nothing): the number
-// of vector-memory INSTRUCTIONS.  A wave64 memory instruction occupies the CU's address unit for ~16 cycles whatever its
-// width, and a phase issued 64 of them (two 4-byte entry loads and two 8-byte slice loads per thread): ~1000 of the
-// phase's ~1400 cycles.  Now a thread loads its two entries -- adjacent ones, the builder arranges the items for that
-// (ldsx_reorder_kernel) -- with ONE 8-byte load and its two slice values with ONE 16-byte load.
-typedef unsigned v2u_a4 __attribute__((ext_vector_type(2), aligned(4)));
-typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
-
-template <bool XS1>
-__device__ __forceinline__ void ldsx_load2_slice(const int4 d, int t, int W, int ncol, const double *__restrict__ x, int xs,
-                                                 double (&xr)[2])
-{
-  const int c0 = d.z * W + 2 * t;
-  // the pair clamped into the vector: past the end it is (ncol-2, ncol-1), so the LAST column arrives in the second value
-  // when c0 == ncol - 1; which value is which is sorted out when the slice is published -- no select next to the load
-  const int cc = c0 + 1 < ncol ? c0 : (ncol >= 2 ? ncol - 2 : 0);
-  if (XS1) {
-    const v2d_a8 p = *reinterpret_cast<const v2d_a8 *>(x + cc);
-    xr[0] = p.x; xr[1] = p.y;
-  } else {
-    xr[0] = x[(int64_t)cc * xs];
-    xr[1] = x[(int64_t)(cc + 1 < ncol ? cc + 1 : cc) * xs];
-  }
-}
-
-template <bool VALUED, bool NT>
-__device__ __forceinline__ void ldsx_load2_entries(const int4 d, int t, const unsigned *__restrict__ pk,
-                                                   const double *__restrict__ vals, unsigned (&w)[2], double (&v)[2])
-{
-  // entries 2t, 2t+1 of the item; threads wholly past its end re-read its first pair (masked at the add), the thread
-  // on an odd end reads one entry of the next item (or of the slack behind the array), masked too
-  const int64_t e = (int64_t)d.x + (2 * t < d.y ? 2 * t : 0);
-  // (the pair types carry the alignment of ONE element: spelled out here, a template would deduce the plain vector type)
-  const v2u_a4 *pp = reinterpret_cast<const v2u_a4 *>(pk + e);
-  const v2u_a4 pw = NT ? __builtin_nontemporal_load(pp) : *pp;
-  w[0] = pw.x; w[1] = pw.y;
-  if (VALUED) {
-    const v2d_a8 *vp = reinterpret_cast<const v2d_a8 *>(vals + e);
-    const v2d_a8 pv = NT ? __builtin_nontemporal_load(vp) : *vp;
-    v[0] = pv.x; v[1] = pv.y;
-  }
-}
-
-#ifndef FS_PIPE_SETS
-#define FS_PIPE_SETS 6
-#endif
-constexpr int kLdsxPipeSets = FS_PIPE_SETS;       // item k requested in phase k-5, its slice needed in phase k-2
-
-template <bool VALUED, bool NT, bool XS1, int NSETS>
-__global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_pipe_kernel(
-    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
-    const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
-    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int xs, int ys, int ordered,
-    const int *__restrict__ chunk_ord, int *__restrict__ ticket)
-{
-  static_assert(kLdsxPer == 2 && kLdsxXPer == 2, "pair loads assume two entries and two slice values per thread");
-  __shared__ double ytile[kLdsxRows];
-  __shared__ __attribute__((aligned(16))) double xsl[3][kLdsxCols];
-  const int t = threadIdx.x;
-  const int cp = chunk_panel[blockIdx.x];
-  const int p = cp & 0x7fffffff;
-  const bool shared = cp < 0;
-  const int row0 = panel_row[p];
-  const int nr = panel_row[p + 1] - row0;
-  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
-  const unsigned cmask = (1u << lcol_bits) - 1u;
-  const int it0 = chunk_item[2 * blockIdx.x], it1 = chunk_item[2 * blockIdx.x + 1];
-  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
-  const int itf = it1 > it0 ? it0 : itl;
-  auto item = [&](int i) {
-    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
-    if (i < it0 || i >= it1) d.y = 0;
-    return d;
-  };
-  int4 dset[NSETS];
-  unsigned w[NSETS][2];
-  double v[NSETS][2];
-  double xr[NSETS][2];
-#pragma unroll
-  for (int k = 0; k < NSETS; ++k) {
-    dset[k] = item(it0 - 1);
-    w[k][0] = w[k][1] = 0;
-    v[k][0] = v[k][1] = 0.0;
-    xr[k][0] = xr[k][1] = 0.0;
-  }
-  double gcur[2] = {0.0, 0.0};
-  const int first = it0 - (NSETS - 1);
-  int4 dN = item(first + NSETS - 1);
-  int bi = 0;                                     // slice buffer of item IT: (IT - first) % 3
-  __syncthreads();
-  // phase IT: request item IT+NSETS-1; gather item IT+1 (slice published a phase ago); add item IT (values gathered a
-  // phase ago); publish the slice of item IT+2; barrier
-  for (int it = first; it < it1; it += NSETS) {
-#pragma unroll
-    for (int ph = 0; ph < NSETS; ++ph) {
-      const int IT = it + ph;
-      const int s0 = ph, s1 = (ph + 1) % NSETS, s2 = (ph + 2) % NSETS, sl = (ph + NSETS - 1) % NSETS;
-      dset[sl] = dN;
-      dN = item(IT + NSETS);
-      // the phase's memory instructions are spread between its LDS work (slice first: needed a phase before the
-      // entries, and vmcnt retires in order): issued in one burst at the top, the 32 wave-instructions of a phase queue up
-      // in front of the address unit and the waves stall at issue while the LDS array idles
-      const int b1 = bi == 2 ? 0 : bi + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-      double gnew[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) gnew[q] = xsl[b1][w[s1][q] & cmask];
-      ldsx_load2_slice<XS1>(dset[sl], t, W, ncol, x, xs, xr[sl]);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (2 * t + q < dset[s0].y) {
-          double pr = gcur[q];
-          if (VALUED) pr *= v[s0][q];
-          __hip_atomic_fetch_add(&ytile[w[s0][q] >> lcol_bits], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
-      {
-        const int lc = 2 * t, c = dset[s2].z * W + lc;
-        v2d sv;
-        sv.x = (lc < W && c < ncol) ? ((c + 1 == ncol && ncol >= 2) ? xr[s2][1] : xr[s2][0]) : 0.0;   // see ldsx_load2
-        sv.y = (lc + 1 < W && c + 1 < ncol) ? xr[s2][1] : 0.0;
-        *reinterpret_cast<v2d *>(&xsl[b2][lc]) = sv;
-      }
-      __syncthreads();
-      gcur[0] = gnew[0]; gcur[1] = gnew[1];
-      bi = b1;
-    }
-  }
-  __syncthreads();
-  // (every phase ends in __syncthreads, which waits for the phase's adds: with the builder's row-per-wave items the sums of this
-  // kernel are in a fixed order as they are; `ordered` only matters for chunks that share a panel)
-  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ordered != 0, ticket + p, shared ? chunk_ord[blockIdx.x] : 0);
-}
-
-// y[r * ys] = v[r] (output of a product that went through a contiguous scratch vector)
-__global__ __launch_bounds__(kBlock) void strided_copy_kernel(int n, const double *__restrict__ v, double *__restrict__ y, int ys)
-{
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r < n) y[r * ys] = v[r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1024,950 +453,14 @@ __global__ __launch_bounds__(kBlock) void cbcsr_kernel(int nrow, int ncol, int n
   if (r < nrow) y[r] = 0.0 + tot;
 }
 
-// The pipelined sweep with the x slices sent STRAIGHT from global memory into LDS (global_load_lds_dwordx4: 16 bytes per
-// lane land at M0 + 16 * lane, so a wave fills 1 KiB of a slice with one instruction): no pass through the registers, no
-// ds_write of the slice, four VGPRs fewer per register set.  The default of the LDS-staged copy when x has unit stride, is
-// 16-byte aligned and has an even number of columns (a pair load at the end of an odd vector would read past it);
-// spmv_ldsx_pipe_kernel otherwise and with tiled_flags bit 2.  Config 3: A 0.745 -> 0.70 ms, A' 0.826 -> 0.775 ms.
-//   phase IT:  gather item IT+1 (its slice landed a phase ago) | start the DMA of item IT+3's slice into the buffer item IT
-//   used (free since the barrier) | wait for the gathers | add item IT | request the entries of item IT+NSETS-1 | wait until
-//   this wave's DMA of item IT+2 has landed | barrier.
-// The slice buffers are three separate LDS objects: the compiler tracks an LDS DMA per object and would otherwise make
-// every gather wait for the DMA still under way into another buffer.  Even so it makes each LDS instruction it knows about
-// wait for every LDS DMA under way (vmcnt(0) in front of every ds_add_f64, and again before the barrier), which would end
-// the prefetch of the entries as well -- vmcnt retires in order.  So inside the loop every LDS access is inline assembly,
-// the barrier is the bare s_barrier, and the waits are placed by hand:
-//   after the gathers and the DMA   lgkmcnt(0): the gathered values are in their registers (an empty asm that takes them
-//                        as in/out operands keeps the compiler from giving those registers to anything else before this
-//                        point -- the hardware writes them some time after the ds_read was issued) and their buffer may
-//                        be refilled once every wave is past the barrier.  The adds go out AFTER this wait and are not
-//                        waited for: nothing but the end of the kernel reads the y slice.
-//   before the barrier   vmcnt(n): this wave's DMA of item IT+2 has landed; the n operations issued after it stay in
-//                        flight (the entries requested behind it a phase ago, this phase's DMA and entries: n = 2 * loads
-//                        per entry pair + 1), so the order "DMA, then entries" inside a phase is pinned by scheduling
-//                        barriers.  tests/test_isa_guards.py checks n against the compiled code.
-#ifndef FS_DMA_SETS
-#define FS_DMA_SETS 6
-#endif
-constexpr int kLdsxDmaSets = FS_DMA_SETS;
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
-
-#ifdef FS_LAB   // tools/build_variants.py only: the instrumented copy of this kernel (ablations, phase clocks) takes its place
-#include "experiments/ldsx_dma_lab.inc"
-#else
-// ORDERED (fixed-order sums): the builder has put all entries of a row inside one work item with ONE wave (TiledCsr::orderable),
-// whose LDS adds execute in program order; here the adds of a phase are additionally waited for before the phase's barrier, so
-// that adds of different phases -- which may come from different waves -- reach a y slot in phase order.
-template <bool VALUED, bool NT, int NSETS, bool ORDERED>
-__global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
-    const int *__restrict__ panel_row, int W, int lcol_bits, int ncol, const int4 *__restrict__ items,
-    const int *__restrict__ chunk_panel, const int *__restrict__ chunk_item, const unsigned *__restrict__ pk,
-    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int ys,
-    const int *__restrict__ chunk_ord, int *__restrict__ ticket)
-{
-  static_assert(NSETS % 3 == 0, "the slice buffer of a phase is a compile-time constant");
-  static_assert(NSETS >= 4, "the sweep starts NSETS - 1 phases early and the DMA of an item is sent three phases before it");
-  __shared__ double ytile[kLdsxRows];
-  __shared__ __attribute__((aligned(16))) double xs0[kLdsxCols];
-  __shared__ __attribute__((aligned(16))) double xs1[kLdsxCols];
-  __shared__ __attribute__((aligned(16))) double xs2[kLdsxCols];
-  const int t = threadIdx.x;
-  const int cp = chunk_panel[blockIdx.x];
-  const int p = cp & 0x7fffffff;
-  const bool shared = cp < 0;
-  const int row0 = panel_row[p];
-  const int nr = panel_row[p + 1] - row0;
-  for (int i = t; i < nr; i += kTiledBlock) ytile[i] = 0.0;
-  const unsigned cmask = (1u << lcol_bits) - 1u;
-  const int it0 = chunk_item[2 * blockIdx.x], it1 = chunk_item[2 * blockIdx.x + 1];
-  const int itl = it1 > it0 ? it1 - 1 : (it0 > 0 ? it0 - 1 : 0);
-  const int itf = it1 > it0 ? it0 : itl;
-  auto item = [&](int i) {
-    int4 d = items[i < itf ? itf : (i < itl ? i : itl)];
-    if (i < it0 || i >= it1) d.y = 0;
-    return d;
-  };
-  int4 dset[NSETS];
-  unsigned w[NSETS][2];
-  double v[NSETS][2];
-#pragma unroll
-  for (int k = 0; k < NSETS; ++k) {
-    dset[k] = item(it0 - 1);
-    w[k][0] = w[k][1] = 0;
-    v[k][0] = v[k][1] = 0.0;
-  }
-  double gcur[2] = {0.0, 0.0};
-  const int first = it0 - (NSETS - 1);
-  int4 dN = item(first + NSETS - 1);
-  int4 dS = item(first + 3);                      // descriptor of the item whose slice this phase sends for
-  const int wave_cols = 2 * (t & ~63);            // first column (inside the slice) of this wave's 1 KiB
-  const unsigned ybase = lds_addr(ytile);
-  const unsigned xbase[3] = {lds_addr(xs0), lds_addr(xs1), lds_addr(xs2)};
-  __syncthreads();
-  for (int it = first; it < it1; it += NSETS) {
-#pragma unroll
-    for (int ph = 0; ph < NSETS; ++ph) {
-      const int IT = it + ph;
-      const int s0 = ph, s1 = (ph + 1) % NSETS, sl = (ph + NSETS - 1) % NSETS;
-      dset[sl] = dN;
-      dN = item(IT + NSETS);
-      // buffers: item j lives in buffer (j - first) % 3; NSETS is a multiple of 3, so these are constants per unrolled phase
-      double *const bfree = ph % 3 == 0 ? xs0 : (ph % 3 == 1 ? xs1 : xs2);               // item IT's: refilled for IT+3
-      double gnew[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned a = xbase[(ph + 1) % 3] + ((w[s1][q] & cmask) << 3);                // item IT+1: gathered now
-        asm volatile("ds_read_b64 %0, %1" : "=v"(gnew[q]) : "v"(a) : "memory");
-      }
-      {
-        const int c0 = dS.z * W + 2 * t;
-        const int cc = c0 + 1 < ncol ? c0 : ncol - 2;            // ncol is even and >= 2 here
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(x + cc),
-                                         (void __attribute__((address_space(3))) *)(bfree + wave_cols), 16, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      dS = item(IT + 4);
-      // the gathers (and the descriptor loads) have returned: their buffer may be refilled once every wave is past the
-      // barrier.  The adds go out AFTER this wait and (unless ORDERED) are not waited for: nothing but the end of the kernel
-      // reads the y slice, so they drain under the barrier and the next phase instead of holding it up
-      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(63, 0));
-      // the gathered values are written by the hardware some time after the ds_read was issued: tell the compiler they are
-      // live up to here, whatever uses them later, so that it can never hand their registers to something else in between
-      asm volatile("" : "+v"(gnew[0]), "+v"(gnew[1]));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (2 * t + q < dset[s0].y) {
-          double pr = gcur[q];
-          if (VALUED) pr *= v[s0][q];
-          const unsigned a = ybase + ((w[s0][q] >> lcol_bits) << 3);
-          asm volatile("ds_add_f64 %0, %1" : : "v"(a), "v"(pr) : "memory");
-        }
-      }
-      // (the entries after the adds: requested right behind the DMA, 0.70 -> 0.74 ms -- memory instructions issued in a
-      // burst queue up in front of the address unit)
-      ldsx_load2_entries<VALUED, NT>(dset[sl], t, pk, vals, w[sl], v[sl]);
-      __builtin_amdgcn_sched_barrier(0);
-      // this wave's DMA of item IT+2 has landed (the operations issued behind it stay in flight); ORDERED: and its adds are done
-      __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(VALUED ? 5 : 3, ORDERED ? 0 : 15));
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      gcur[0] = gnew[0]; gcur[1] = gnew[1];
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));
-  __syncthreads();
-  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ORDERED, ticket + p, shared ? chunk_ord[blockIdx.x] : 0);
-}
-#endif   // FS_LAB
-
 // ------------------------------------------------------------------------------------------
-// y = A x in two streaming passes (BinnedCsr in fs_common.h).  Same callers as the kernels above.
-//
-// Why: with 16 entries per row and a vector x of tens of MB, a gather kernel is bound by the rate at which
-// L2 answers 8-byte requests (measured 240 G/s when every request hits, 53 G/s when every one goes to HBM),
-// not by bytes.  Here every random access is an LDS access: pass 1 gathers x from a 128 KiB band held in LDS,
-// pass 2 scatters into a 128 KiB slice of y held in LDS, and what travels between them is a sequential stream
-// of products laid out so that each pass reads and writes whole lines.  20.5 bytes per entry at stream speed
-// beat 4 bytes per entry at gather speed.
-//
-// Sum order: a row's terms are added band by band, and inside a band by LDS atomics in no fixed order --
-// the result is exact for pattern matrices with integer-valued x and within the usual rounding bound
-// otherwise; strict_order keeps the chunk-streaming kernel.
-// ------------------------------------------------------------------------------------------
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-
-// pass 1: persistent workgroups, one per CU; workgroup w streams the w-th equal share of the (band, panel)-ordered
-// groups and reloads its x band when the share crosses into the next band (every band is loaded once, plus once
-// per share boundary: cutting bands into many small workgroups instead re-reads x several times over)
-// xband: BC + 8 doubles of LDS; slot BC is the zero the padding entries point at.  The share is groups [g0, g1).
-template <bool VALUED, int U, bool NTLD, bool NTST, int BC>
-__device__ __forceinline__ void expand_share(double *__restrict__ xband, int ncol, int B, const unsigned *__restrict__ band_ptr,
-                                             const uint16_t *__restrict__ lcol, const double *__restrict__ vals,
-                                             const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
-                                             double *__restrict__ prod, unsigned g0, unsigned g1)
-{
-  const int t = threadIdx.x;
-  if (g0 >= g1) return;
-  // band of the first group: last b with band_ptr[b] <= g0
-  int b;
-  {
-    int lo = 0, hi = B - 1;
-    while (lo < hi) {
-      const int mid = lo + ((hi - lo + 1) >> 1);
-      if (band_ptr[mid] <= g0) lo = mid; else hi = mid - 1;
-    }
-    b = lo;
-  }
-  for (unsigned g = g0; g < g1; ++b) {
-    const unsigned gb = band_ptr[b + 1] < g1 ? band_ptr[b + 1] : g1;   // end of this band's part of the share
-    if (gb <= g) continue;                                               // empty band
-    const int c0 = b * BC;
-    const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
-    __syncthreads();                                                     // everyone is done with the previous band
-    {
-      // 16 loads per thread in flight together (clamped addresses, masking afterwards: a select next to the load
-      // would make every one of them wait for itself); slots BC .. BC+7 are the zero padding points at
-      double r[BC / kBinBlock];
-#pragma unroll
-      for (int j = 0; j < BC / kBinBlock; ++j) {
-        const int i = j * kBinBlock + t;
-        r[j] = __builtin_nontemporal_load(x + (int64_t)(c0 + (i < w ? i : w - 1)) * xs);
-      }
-#pragma unroll
-      for (int j = 0; j < BC / kBinBlock; ++j) {
-        const int i = j * kBinBlock + t;
-        xband[i] = (i < w) ? r[j] : 0.0;
-      }
-      if (t < 8) xband[BC + t] = 0.0;
-    }
-    __syncthreads();
-    const int64_t e0 = (int64_t)g * kBinGroup, e1 = (int64_t)gb * kBinGroup;
-    // a lane takes 2 consecutive entries per step, so a wave's stores are 1 KiB of consecutive products; U steps in
-    // flight.  Whole rounds (every step of every lane inside the segment) are straight-line code: all loads, a
-    // scheduling barrier, then gathers and stores -- with a guard anywhere in it the compiler sinks the loads of a
-    // step behind that step's guard and the steps run one after the other.  The last, partial round is guarded.
-    constexpr int64_t kRound = 2 * U * kBinBlock;
-    int64_t o = e0 + 2 * t;
-    for (; o - 2 * t + kRound <= e1; o += kRound) {
-      unsigned a[U], d[U];
-      v2d v[U];
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int64_t e = o + (int64_t)k * 2 * kBinBlock;
-        a[k] = stream_load<NTLD>((const unsigned *)(lcol + e));
-        d[k] = stream_load<NTLD>(gdst + (e >> kBinGroupLog));
-        if (VALUED) v[k] = stream_load<NTLD>((const v2d *)(vals + e));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int64_t e = o + (int64_t)k * 2 * kBinBlock;
-        v2d p = {xband[a[k] & 0xffffu], xband[a[k] >> 16]};
-        if (VALUED) { p.x *= v[k].x; p.y *= v[k].y; }
-        stream_store<NTST>(p, (v2d *)(prod + (int64_t)d[k] * kBinGroup + (e & (kBinGroup - 1))));
-      }
-    }
-    for (; o < e1; o += 2 * kBinBlock) {
-      const unsigned a = stream_load<NTLD>((const unsigned *)(lcol + o));
-      const unsigned d = stream_load<NTLD>(gdst + (o >> kBinGroupLog));
-      v2d p = {xband[a & 0xffffu], xband[a >> 16]};
-      if (VALUED) {
-        const v2d v = stream_load<NTLD>((const v2d *)(vals + o));
-        p.x *= v.x; p.y *= v.y;
-      }
-      stream_store<NTST>(p, (v2d *)(prod + (int64_t)d * kBinGroup + (o & (kBinGroup - 1))));
-    }
-    g = gb;
-  }
-}
-
-template <bool VALUED, int U, bool NTLD, bool NTST, int BC = kBinCols>
-__global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
-    int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
-    const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ x, int xs,
-    double *__restrict__ prod, unsigned gbeg, unsigned gend)
-{
-  __shared__ double xband[BC + 8];
-  // this launch covers the groups gbeg .. gend (everything, or the bands whose part of x has arrived: fs_spmv_host)
-  const uint64_t groups = gend - gbeg;
-  const unsigned g0 = gbeg + (unsigned)(groups * blockIdx.x / gridDim.x), g1 = gbeg + (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
-  expand_share<VALUED, U, NTLD, NTST, BC>(xband, ncol, B, band_ptr, lcol, vals, gdst, x, xs, prod, g0, g1);
-}
-
-// pass 2: workgroup = one row panel; its products are contiguous.  ytile: the panel's slice of y in LDS.
-template <bool NTLD>
-__device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int panel, const unsigned *__restrict__ bin_ptr,
-                                             const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-                                             const double *__restrict__ prod, double *__restrict__ y, int ys)
-{
-  const int t = threadIdx.x;
-  const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
-  for (int i = t; i < nr; i += kBinBlock) ytile[i] = 0.0;
-  __syncthreads();
-  const int64_t e0 = (int64_t)bin_ptr[panel] * kBinGroup, e1 = (int64_t)bin_ptr[panel + 1] * kBinGroup;
-  // 8 entries (64 bytes of products) per lane and step, two steps in flight in whole rounds (straight-line code:
-  // see expand_share); the last, partial round is guarded
-#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define FS_ADD8(A, P)                                                  \
-  FS_ADD(A.x & 0xffffu, P[0].x); FS_ADD(A.x >> 16, P[0].y);            \
-  FS_ADD(A.y & 0xffffu, P[1].x); FS_ADD(A.y >> 16, P[1].y);            \
-  FS_ADD(A.z & 0xffffu, P[2].x); FS_ADD(A.z >> 16, P[2].y);            \
-  FS_ADD(A.w & 0xffffu, P[3].x); FS_ADD(A.w >> 16, P[3].y);
-  constexpr int64_t kRound = 16 * kBinBlock;
-  int64_t e = e0 + 8 * t;
-  for (; e - 8 * t + kRound <= e1; e += kRound) {
-    v4u a[2];
-    v2d p[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int64_t ek = e + (int64_t)k * 8 * kBinBlock;
-      a[k] = stream_load<NTLD>((const v4u *)(lrow + ek));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ek + 2 * j));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    FS_ADD8(a[0], p[0])
-    FS_ADD8(a[1], p[1])
-  }
-  for (; e < e1; e += 8 * kBinBlock) {
-    const v4u a = stream_load<NTLD>((const v4u *)(lrow + e));
-    v2d p[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = stream_load<NTLD>((const v2d *)(prod + e + 2 * j));
-    FS_ADD8(a, p)
-  }
-#undef FS_ADD8
-#undef FS_ADD
-  __syncthreads();
-  for (int i = t; i < nr; i += kBinBlock) y[(int64_t)(r0 + i) * ys] = ytile[i];
-}
-
-template <bool NTLD, int RM = kBinRowsMax>
-__global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
-    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
-{
-  __shared__ double ytile[RM];
-  reduce_panel<NTLD>(ytile, pbase + blockIdx.x, bin_ptr, panel_row, lrow, prod, y, ys);
-}
-
-// pass 2 with a FIXED order of additions: ONE wave per panel walks the panel's products in stream order, 512 entries per step
-// (eight per lane, as above).  A wave's LDS instructions execute in program order, so every y slot receives its addends in the
-// order of the stream (band by band, inside a band in CSR order; lanes of one instruction that hit the same slot are
-// serialised by the LDS in a fixed order): the result is bit-identical run to run, which the sixteen-wave kernel above -- whose
-// waves add into the same slots concurrently -- is not.  One wave can do it because the pass is a stream: DEPTH steps of loads
-// (80 bytes per lane each) stay in flight in registers, and eight ds_add_f64 per 512 entries are far below what one wave may
-// issue.
-#ifndef FS_ORDERED_DEPTH
-#define FS_ORDERED_DEPTH 16   // steps of loads in flight (config 2: 4 / 6 / 8 / 12 / 16 / 20 -> +13 / +7 / +6 / +4.3 / +3.5 / +3 % over the 16-wave pass)
-#endif
-template <bool NTLD, int RM, int DEPTH>
-__global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
-    const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
-{
-  __shared__ __attribute__((aligned(16))) double ytile[RM];
-  const int t = threadIdx.x;
-  const int panel = pbase + blockIdx.x;
-  const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
-  for (int i = 2 * t; i < nr; i += 128) *reinterpret_cast<v2d *>(&ytile[i]) = v2d{0.0, 0.0};   // (RM is even: a pair past nr stays inside)
-  const int64_t e0 = (int64_t)bin_ptr[panel] * kBinGroup, e1 = (int64_t)bin_ptr[panel + 1] * kBinGroup;
-#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define FS_ADD8(A, P)                                                  \
-  FS_ADD(A.x & 0xffffu, P[0].x); FS_ADD(A.x >> 16, P[0].y);            \
-  FS_ADD(A.y & 0xffffu, P[1].x); FS_ADD(A.y >> 16, P[1].y);            \
-  FS_ADD(A.z & 0xffffu, P[2].x); FS_ADD(A.z >> 16, P[2].y);            \
-  FS_ADD(A.w & 0xffffu, P[3].x); FS_ADD(A.w >> 16, P[3].y);
-  constexpr int64_t kStep = 8 * 64;
-  v4u a[DEPTH];
-  v2d p[DEPTH][4];
-  // steps past the end re-read the segment's last eight entries (their adds are skipped): every load is unconditional
-  auto fetch = [&](int k, int64_t e) {
-    const int64_t ec = (e + 8 <= e1) ? e : (e1 - e0 >= 8 ? e1 - 8 : e0);
-    a[k] = stream_load<NTLD>((const v4u *)(lrow + ec));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ec + 2 * j));
-  };
-  if (e1 > e0) {
-    int64_t e = e0 + 8 * t;
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) fetch(k, e + (int64_t)k * kStep);
-    for (; e - 8 * t < e1; e += (int64_t)DEPTH * kStep) {
-#pragma unroll
-      for (int k = 0; k < DEPTH; ++k) {
-        const int64_t ek = e + (int64_t)k * kStep;
-        const v4u ak = a[k];
-        v2d pk[4] = {p[k][0], p[k][1], p[k][2], p[k][3]};
-        fetch(k, ek + (int64_t)DEPTH * kStep);
-        if (ek + 8 <= e1) { FS_ADD8(ak, pk) }
-      }
-    }
-  }
-#undef FS_ADD8
-#undef FS_ADD
-  __syncthreads();
-  for (int i = t; i < nr; i += 64) y[(int64_t)(r0 + i) * ys] = ytile[i];
-}
-
-// ------------------------------------------------------------------------------------------
-// The longest rows of a heavy-tailed matrix in ONE pass (LongRows, fs_common.h): persistent workgroups stream equal shares of
-// the (band, long row)-ordered entries; the band of x (128 KiB) AND one accumulator per long row (<= 24 KiB) sit in LDS.
-// A lane takes two consecutive entries; entries are sorted by row inside a band, so a wave adds up the products of equal rows
-// with a segmented scan over its lanes (a row of 10^6 entries has ~160 of them per band: 64 lanes hammering one LDS
-// address would serialise) and only the last lane of every run adds to the accumulator (ds_add_f64).  At the end of its
-// share a workgroup adds its accumulators to ylong in HBM (one atomic per row it touched).  10 bytes per entry where the
-// two-pass pair moves 28.
-// ORDERED (fixed-order sums: option "reproducible", the solvers): every long row belongs to ONE wave of the workgroup and the
-// builder keeps an owner's entries of a band in one contiguous segment (seg_ptr); wave w walks ITS segments, so an accumulator
-// only ever sees the LDS instructions of one wave, which execute in program order -- the same sum, bit for bit, every run.
-// The workgroups' sums go to ypart and are added up in workgroup order by longrows_combine_kernel instead of with atomics.
-// ------------------------------------------------------------------------------------------
-template <bool VALUED, int BC, int NACC, bool ORDERED>
-__global__ __launch_bounds__(kBinBlock) void spmv_longrows_kernel(
-    int ncol, int B, int nlong, const int64_t *__restrict__ band_ptr, const unsigned *__restrict__ seg_ptr,
-    const uint16_t *__restrict__ lcol, const uint16_t *__restrict__ lrow, const double *__restrict__ vals,
-    const double *__restrict__ x, int xs, double *__restrict__ ylong, double *__restrict__ ypart)
-{
-  __shared__ double xband[BC + 8];
-  __shared__ double acc[NACC];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < nlong; i += kBinBlock) acc[i] = 0.0;
-  const int64_t pairs = band_ptr[B] >> 1;                         // every segment holds an even number of entries
-  const int64_t e_beg = 2 * (pairs * blockIdx.x / gridDim.x), e_end = 2 * (pairs * (blockIdx.x + 1) / gridDim.x);
-  if (e_beg < e_end) {
-    int b;
-    {
-      int lo = 0, hi = B - 1;
-      while (lo < hi) {
-        const int mid = lo + ((hi - lo + 1) >> 1);
-        if (band_ptr[mid] <= e_beg) lo = mid; else hi = mid - 1;
-      }
-      b = lo;
-    }
-    // a band holds few entries here (config-5 shard: 16 K per 64 KiB of x), so the band of x is requested one band AHEAD into
-    // registers and only copied to LDS at the band switch: its latency hides under the entries of the band before
-    double rn[BC / kBinBlock];
-    int have = -1;                                                   // band whose x is in rn
-    auto request = [&](int bb) {
-      const int cb = bb * BC;
-      const int wb = (ncol - cb < BC) ? ncol - cb : BC;
-#pragma unroll
-      for (int j = 0; j < BC / kBinBlock; ++j) {
-        const int i = j * kBinBlock + t;
-        rn[j] = __builtin_nontemporal_load(x + (int64_t)(cb + (i < wb ? i : wb - 1)) * xs);
-      }
-      have = bb;
-    };
-    // 128 entries of one wave: products, run sums by a segmented scan over the lanes, one LDS add per run
-    auto wave_step = [&](int64_t o, bool live, int64_t oc) {
-      const unsigned a = *reinterpret_cast<const unsigned *>(lcol + oc);
-      const unsigned rr = *reinterpret_cast<const unsigned *>(lrow + oc);
-      v2d p = {xband[a & 0xffffu], xband[a >> 16]};
-      if (VALUED) { const v2d v = *reinterpret_cast<const v2d *>(vals + oc); p.x *= v.x; p.y *= v.y; }
-      unsigned key = 0xffffffffu;
-      double sum = 0.0;
-      if (live) {
-        const unsigned r0 = rr & 0xffffu, r1 = rr >> 16;
-        if (r0 == r1) { key = r0; sum = p.x + p.y; }
-        else { __hip_atomic_fetch_add(&acc[r0], p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); key = r1; sum = p.y; }
-      }
-      // segmented inclusive scan over the wave: keys are sorted, so an equal key d lanes down means one run
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned ku = __shfl_up(key, d);
-        const double su = __shfl_up(sum, d);
-        if (lane >= d && ku == key) sum += su;
-      }
-      const unsigned kn = __shfl_down(key, 1);
-      if (live && (lane == 63 || kn != key))
-        __hip_atomic_fetch_add(&acc[key], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      (void)o;
-    };
-    for (int64_t e = e_beg; e < e_end; ++b) {
-      const int64_t eb = band_ptr[b + 1] < e_end ? band_ptr[b + 1] : e_end;
-      if (eb <= e) continue;
-      const int c0 = b * BC;
-      const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
-      if (have != b) request(b);                                     // the first band of the share (or after empty bands)
-      __syncthreads();                                               // everyone is done with the previous band
-#pragma unroll
-      for (int j = 0; j < BC / kBinBlock; ++j) {
-        const int i = j * kBinBlock + t;
-        xband[i] = (i < w) ? rn[j] : 0.0;
-      }
-      if (t < 8) xband[BC + t] = 0.0;
-      __syncthreads();
-      if (b + 1 < B && eb < e_end) request(b + 1);
-      if (ORDERED) {
-        // this wave's segment of the band, clipped to the share: nobody else touches the accumulators of its rows
-        const int64_t s0 = band_ptr[b] + seg_ptr[b * (kLongOwners + 1) + wave], s1 = band_ptr[b] + seg_ptr[b * (kLongOwners + 1) + wave + 1];
-        const int64_t lo = s0 > e ? s0 : e, hi = s1 < eb ? s1 : eb;
-        for (int64_t o0 = lo; o0 < hi; o0 += 128) {
-          const int64_t o = o0 + 2 * lane;
-          const bool live = o < hi;
-          wave_step(o, live, live ? o : lo);
-        }
-      } else {
-        // whole rounds of the workgroup (2048 entries); lanes past the end of the segment carry a sentinel key and add nothing
-        for (int64_t o0 = e; o0 < eb; o0 += 2 * kBinBlock) {
-          const int64_t o = o0 + 2 * t;
-          const bool live = o < eb;
-          wave_step(o, live, live ? o : e);                          // clamped address, masked inside
-        }
-      }
-      e = eb;
-    }
-  }
-  __syncthreads();
-  if (ORDERED) {
-    double *__restrict__ mine = ypart + (int64_t)blockIdx.x * nlong;
-    for (int i = t; i < nlong; i += kBinBlock) mine[i] = acc[i];
-  } else {
-    for (int i = t; i < nlong; i += kBinBlock) {
-      const double v = acc[i];
-      if (v != 0.0) unsafeAtomicAdd(ylong + i, v);
-    }
-  }
-}
-
-// ylong[i] = the workgroups' sums of long row i, added in workgroup order
-__global__ __launch_bounds__(kBlock) void longrows_combine_kernel(int nlong, int nwg, const double *__restrict__ ypart, double *__restrict__ ylong)
-{
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nlong) return;
-  double acc = 0.0;
-  for (int w = 0; w < nwg; ++w) acc += ypart[(int64_t)w * nlong + i];
-  ylong[i] = acc;
-}
-
-// y[row[i]] = ylong[i] for the long rows inside [row0, row1): the two-pass pair wrote 0 there (their entries are not in it)
-__global__ __launch_bounds__(kBlock) void longrows_scatter_kernel(int nlong, const int *__restrict__ row, const double *__restrict__ ylong,
-                                                                 double *__restrict__ y, int ys, int row0, int row1)
-{
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nlong) return;
-  const int r = row[i];
-  if (r >= row0 && r < row1) y[(int64_t)r * ys] = 0.0 + ylong[i];
-}
-
-static int launch_longrows(const DeviceCsr &A, const LongRows &L, const double *x, int xs, hipStream_t s)
-{
-  const bool ordered = reproducible_now();
-  if (!ordered || L.n == 0 || L.nwg == 0) FS_HIP(hipMemsetAsync(L.ylong, 0, sizeof(double) * (size_t)L.nlong, s));
-  if (L.n == 0 || L.nwg == 0) return FS_OK;
-#define FS_LONG(V, BC, NA, ORD)                                                                                              \
-  hipLaunchKernelGGL((spmv_longrows_kernel<V, BC, NA, ORD>), dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, \
-                     L.seg_ptr, L.lcol, L.lrow, L.vals, x, xs, L.ylong, L.ypart)
-#define FS_LONG2(V, BC, NA) do { if (ordered) FS_LONG(V, BC, NA, true); else FS_LONG(V, BC, NA, false); } while (0)
-  if (L.bcols == kLongBandB) { if (A.vals) FS_LONG2(true, kLongBandB, kLongRowsB); else FS_LONG2(false, kLongBandB, kLongRowsB); }
-  else                       { if (A.vals) FS_LONG2(true, kLongBandA, kLongRowsA); else FS_LONG2(false, kLongBandA, kLongRowsA); }
-#undef FS_LONG2
-#undef FS_LONG
-  FS_HIP(hipGetLastError());
-  if (ordered) {
-    hipLaunchKernelGGL(longrows_combine_kernel, dim3((unsigned)((L.nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, L.nlong, L.nwg, L.ypart,
-                       L.ylong);
-    FS_HIP(hipGetLastError());
-  }
-  return FS_OK;
-}
-
-// (Both passes in ONE persistent launch behind a device-wide arrival counter were built and measured in round 3 and withdrawn:
-// on config 2 the single launch took 1.13 ms against 0.857 ms for the pair -- every wave's agent-scope release is a
-// buffer_wbl2 over the XCD's whole L2 -- and the kernel trace shows there is nothing to win: pass 2 starts 0.0 us after pass 1
-// ends, the next product 9 us after that (profiles/r03_gap_probe.jsonl, r03_kernel_gaps.txt).)
-
-// ------------------------------------------------------------------------------------------
-// Y = A X for K = 2 or 4 row-major right-hand sides in ONE sweep of a two-pass copy built with bands of
-// kBinCols / K columns (BinnedCsr::kw == K): the north_star's "LDS-tiled dense B panel".
-//   replaces bcsr_A_mul_B2 / _B4 (csr.h:164-202), bsbm_A_mul_B2 / _B4 (sparse.h:276-315), csr_A_mul_Bn /
-//   bcsr_A_mul_Bn / bsbm_A_mul_Bn with ncol = 2, 4 (csr.h:441-465, 257-280, sparse.h:318-336) and the two
-//   products of every bsbm_cg2 iteration (cg.h:134-135).
-// Pass 1 keeps a band of X -- kBinCols / K rows of K doubles, 128 KiB -- in LDS; an entry is read once (2-byte
-// local column, value) and gives K products, written as one 128-byte line per group of kBinGroup / K entries to
-// the place of its run in (panel, band) order.  Pass 2 keeps the K-column Y slice of a panel (<= kBinRowsMax / K
-// rows) in LDS and adds the products up.  Per entry: 2 + 8 + 8K written + 8K read + 2 bytes, against K times
-// 28.25 for K sweeps of the single-vector pair.  Sum order as the single-vector pair (band-major, LDS atomics).
-// ------------------------------------------------------------------------------------------
-template <bool VALUED, int K, int U>
-__global__ __launch_bounds__(kBinBlock) void spmm_expand_kernel(
-    int ncol, int B, const unsigned *__restrict__ band_ptr, const uint16_t *__restrict__ lcol,
-    const double *__restrict__ vals, const unsigned *__restrict__ gdst, const double *__restrict__ X, int xs,
-    double *__restrict__ prod)
-{
-  constexpr int BC = kBinCols / K;       // columns per band
-  constexpr int GE = kBinGroup / K;      // entries per group
-  constexpr int LP = K / 2;              // lanes per entry: every lane owns two neighbouring products (one 16-byte store)
-  constexpr int EPS = kBinBlock / LP;    // entries per step of the workgroup
-  __shared__ __attribute__((aligned(16))) double xband[kBinCols + 8];  // [BC][K]; row BC is the zero row the padding entries point at
-  const int t = threadIdx.x;
-  const int le = t / LP, h = t % LP;
-  const uint64_t groups = band_ptr[B];
-  const unsigned g0 = (unsigned)(groups * blockIdx.x / gridDim.x), g1 = (unsigned)(groups * (blockIdx.x + 1) / gridDim.x);
-  if (g0 >= g1) return;
-  int b;
-  {
-    int lo = 0, hi = B - 1;
-    while (lo < hi) {
-      const int mid = lo + ((hi - lo + 1) >> 1);
-      if (band_ptr[mid] <= g0) lo = mid; else hi = mid - 1;
-    }
-    b = lo;
-  }
-  for (unsigned g = g0; g < g1; ++b) {
-    const unsigned gb = band_ptr[b + 1] < g1 ? band_ptr[b + 1] : g1;
-    if (gb <= g) continue;
-    const int c0 = b * BC;
-    const int w = (ncol - c0 < BC) ? ncol - c0 : BC;
-    __syncthreads();
-    {
-      // the band: rows c0 .. c0+w of X, K doubles each (contiguous when xs == K); 16 loads per thread in flight
-      double r[kBinCols / kBinBlock];
-#pragma unroll
-      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
-        const int f = j * kBinBlock + t, i = f / K, q = f % K;
-        r[j] = __builtin_nontemporal_load(X + (int64_t)(c0 + (i < w ? i : w - 1)) * xs + q);
-      }
-#pragma unroll
-      for (int j = 0; j < kBinCols / kBinBlock; ++j) {
-        const int f = j * kBinBlock + t;
-        xband[f] = (f / K < w) ? r[j] : 0.0;
-      }
-      if (t < 8) xband[kBinCols + t] = 0.0;
-    }
-    __syncthreads();
-    const int64_t e0 = (int64_t)g * GE, e1 = (int64_t)gb * GE;
-    constexpr int64_t kRound = (int64_t)U * EPS;
-    int64_t o = e0 + le;
-    for (; o - le + kRound <= e1; o += kRound) {
-      unsigned a[U], d[U];
-      double v[U];
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int64_t e = o + (int64_t)k * EPS;
-        a[k] = lcol[e];
-        d[k] = gdst[e / GE];
-        if (VALUED) v[k] = vals[e];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int64_t e = o + (int64_t)k * EPS;
-        v2d p = *reinterpret_cast<const v2d *>(&xband[a[k] * K + 2 * h]);
-        if (VALUED) { p.x *= v[k]; p.y *= v[k]; }
-        __builtin_nontemporal_store(p, (v2d *)(prod + ((int64_t)d[k] * GE + (e % GE)) * K + 2 * h));
-      }
-    }
-    for (; o < e1; o += EPS) {
-      const unsigned a = lcol[o];
-      const unsigned d = gdst[o / GE];
-      v2d p = *reinterpret_cast<const v2d *>(&xband[a * K + 2 * h]);
-      if (VALUED) { const double v = vals[o]; p.x *= v; p.y *= v; }
-      __builtin_nontemporal_store(p, (v2d *)(prod + ((int64_t)d * GE + (o % GE)) * K + 2 * h));
-    }
-    g = gb;
-  }
-}
-
-template <int K>
-__global__ __launch_bounds__(kBinBlock) void spmm_reduce_kernel(
-    const unsigned *__restrict__ bin_ptr_all, const int *__restrict__ panel_row_all, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ Y, int ys, int pbase)
-{
-  const unsigned *__restrict__ bin_ptr = bin_ptr_all + pbase;          // this launch covers the panels pbase .. pbase + gridDim.x
-  const int *__restrict__ panel_row = panel_row_all + pbase;
-  constexpr int GE = kBinGroup / K;
-  constexpr int EPL = 8 / K;             // entries per lane and step: 64 bytes of products
-  __shared__ double ytile[kBinRowsMax];  // [rows of the panel][K]
-  const int t = threadIdx.x;
-  const int r0 = panel_row[blockIdx.x], nr = panel_row[blockIdx.x + 1] - r0;
-  for (int i = t; i < nr * K; i += kBinBlock) ytile[i] = 0.0;
-  __syncthreads();
-  const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * GE, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * GE;
-  typedef uint16_t rows_t __attribute__((ext_vector_type(EPL)));
-#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-  auto add8 = [&](const rows_t a, const v2d (&p)[4]) {
-#pragma unroll
-    for (int q = 0; q < EPL; ++q) {
-      const int base = (int)a[q] * K;
-#pragma unroll
-      for (int j = 0; j < K; j += 2) {
-        FS_ADD(base + j, p[(q * K + j) / 2].x);
-        FS_ADD(base + j + 1, p[(q * K + j) / 2].y);
-      }
-    }
-  };
-  constexpr int64_t kStep = (int64_t)EPL * kBinBlock;
-  constexpr int64_t kRound = 2 * kStep;
-  int64_t e = e0 + (int64_t)EPL * t;
-  for (; e - EPL * t + kRound <= e1; e += kRound) {
-    rows_t a[2];
-    v2d p[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int64_t ek = e + k * kStep;
-      a[k] = *reinterpret_cast<const rows_t *>(lrow + ek);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) p[k][j] = *reinterpret_cast<const v2d *>(prod + ek * K + 2 * j);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    add8(a[0], p[0]);
-    add8(a[1], p[1]);
-  }
-  for (; e < e1; e += kStep) {
-    const rows_t a = *reinterpret_cast<const rows_t *>(lrow + e);
-    v2d p[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const v2d *>(prod + e * K + 2 * j);
-    add8(a, p);
-  }
-#undef FS_ADD
-  __syncthreads();
-  for (int i = t; i < nr * K; i += kBinBlock) Y[(int64_t)(r0 + i / K) * ys + (i % K)] = ytile[i];
-}
-
-// the same pass with a fixed order of additions: one wave per panel, stream order (see spmv_reduce_ordered_kernel)
-template <int K, int DEPTH>
-__global__ __launch_bounds__(64) void spmm_reduce_ordered_kernel(
-    const unsigned *__restrict__ bin_ptr_all, const int *__restrict__ panel_row_all, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ Y, int ys, int pbase)
-{
-  const unsigned *__restrict__ bin_ptr = bin_ptr_all + pbase;
-  const int *__restrict__ panel_row = panel_row_all + pbase;
-  constexpr int GE = kBinGroup / K;
-  constexpr int EPL = 8 / K;             // entries per lane and step: 64 bytes of products
-  __shared__ double ytile[kBinRowsMax];  // [rows of the panel][K]
-  const int t = threadIdx.x;
-  const int r0 = panel_row[blockIdx.x], nr = panel_row[blockIdx.x + 1] - r0;
-  for (int i = t; i < nr * K; i += 64) ytile[i] = 0.0;
-  const int64_t e0 = (int64_t)bin_ptr[blockIdx.x] * GE, e1 = (int64_t)bin_ptr[blockIdx.x + 1] * GE;
-  typedef uint16_t rows_t __attribute__((ext_vector_type(EPL)));
-#define FS_ADD(idx, val) __hip_atomic_fetch_add(&ytile[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-  auto add8 = [&](const rows_t a, const v2d (&p)[4]) {
-#pragma unroll
-    for (int q = 0; q < EPL; ++q) {
-      const int base = (int)a[q] * K;
-#pragma unroll
-      for (int j = 0; j < K; j += 2) {
-        FS_ADD(base + j, p[(q * K + j) / 2].x);
-        FS_ADD(base + j + 1, p[(q * K + j) / 2].y);
-      }
-    }
-  };
-  constexpr int64_t kStep = (int64_t)EPL * 64;
-  rows_t a[DEPTH];
-  v2d p[DEPTH][4];
-  auto fetch = [&](int k, int64_t e) {   // steps past the end re-read the segment's last entries (their adds are skipped)
-    const int64_t ec = (e + EPL <= e1) ? e : (e1 - e0 >= EPL ? e1 - EPL : e0);
-    a[k] = *reinterpret_cast<const rows_t *>(lrow + ec);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[k][j] = *reinterpret_cast<const v2d *>(prod + ec * K + 2 * j);
-  };
-  if (e1 > e0) {
-    int64_t e = e0 + (int64_t)EPL * t;
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) fetch(k, e + (int64_t)k * kStep);
-    for (; e - EPL * t < e1; e += (int64_t)DEPTH * kStep) {
-#pragma unroll
-      for (int k = 0; k < DEPTH; ++k) {
-        const int64_t ek = e + (int64_t)k * kStep;
-        const rows_t ak = a[k];
-        const v2d pk[4] = {p[k][0], p[k][1], p[k][2], p[k][3]};
-        fetch(k, ek + (int64_t)DEPTH * kStep);
-        if (ek + EPL <= e1) add8(ak, pk);
-      }
-    }
-  }
-#undef FS_ADD
-  __syncthreads();
-  for (int i = t; i < nr * K; i += 64) Y[(int64_t)(r0 + i / K) * ys + (i % K)] = ytile[i];
-}
-
-// Y[r, 0:K] = sum of the virtual rows of row r, in storage order (yv holds K doubles per virtual row)
-template <int K>
-__global__ __launch_bounds__(kBlock) void tiled_combine_k_kernel(int nrow, const int *__restrict__ vfirst,
-                                                                const double *__restrict__ yv, double *__restrict__ Y, int ys,
-                                                                int row0 = 0)
-{
-  const int64_t i = (int64_t)row0 * K + (int64_t)blockIdx.x * kBlock + threadIdx.x;   // rows row0 .. nrow of this launch
-  const int64_t r = i / K;
-  const int j = (int)(i % K);
-  if (r >= nrow) return;
-  const int a = vfirst[r], b = vfirst[r + 1];
-  double acc = yv[(int64_t)a * K + j];
-  for (int v = a + 1; v < b; ++v) acc += yv[(int64_t)v * K + j];
-  Y[r * ys + j] = acc;
-}
-
-// ------------------------------------------------------------------------------------------
-// launchers
+// launchers (those of the tiled kernels: fs_kernels_tiled.hip; of the two-pass kernels: fs_kernels_twopass.hip)
 // ------------------------------------------------------------------------------------------
 static int ceil_log2(int v)
 {
   int lg = 0;
   while ((1 << lg) < v) ++lg;
   return lg;
-}
-
-// y[r] = sum of the virtual rows of row r (rows that were not cut: a copy).  Up to 32 pieces: one thread, in storage
-// order.  Longer rows (a power-law matrix has rows of 10^5..10^6 entries = thousands of pieces) are summed by the whole
-// wave, 64 pieces per step and a butterfly at the end -- a fixed order, so still reproducible run to run; one thread
-// walking 3 900 dependent loads made this pass 0.49 ms of a 2.9 ms product on a config-5 shard
-// (profiles/r02_c5_pmc_summary.csv).
-__global__ __launch_bounds__(kBlock) void tiled_combine_kernel(int nrow, const int *__restrict__ vfirst,
-                                                              const double *__restrict__ yv, double *__restrict__ y, int ys,
-                                                              int row0 = 0)
-{
-  const int64_t r = (int64_t)row0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;   // rows row0 .. nrow of this launch
-  const int lane = threadIdx.x & 63;
-  int a = 0, b = 0;
-  if (r < nrow) { a = vfirst[r]; b = vfirst[r + 1]; }
-  const bool long_row = b - a > 32;
-  if (r < nrow && !long_row) {
-    double acc = yv[a];
-    for (int v = a + 1; v < b; ++v) acc += yv[v];
-    y[r * ys] = acc;
-  }
-  unsigned long long todo = __ballot(long_row);
-  while (todo) {                                   // wave-uniform
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const int ra = __shfl(a, src), rb = __shfl(b, src);
-    double acc = 0.0;
-    for (int v = ra + lane; v < rb; v += 64) acc += yv[v];
-    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
-    if (lane == src) y[r * ys] = acc;
-  }
-}
-
-// c0 .. c1: the workgroups of this launch (chunks of the LDS-staged kernel, panels of the L2-tiled one); c1 < 0 = all.
-// A part launch needs every workgroup to own its rows (no chunks sharing a panel, no cut rows): spmv_host_vectors
-int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const double *x, hipStream_t s, int xs, int ys,
-                      int c0, int c1)
-{
-  const bool nt = !(options().tiled_flags & 1);  // bit 0: cached (not nt) entry loads
-  double *out = T.split ? T.yv : y;              // cut rows: virtual sums first, combined below
-  const int os = T.split ? 1 : ys;
-  const bool part = c1 >= 0;
-  if (part && T.split) { set_error("launch_spmv_tiled: a copy with cut rows cannot be launched in parts"); return FS_ERR_ARG; }
-  if (!part) { c0 = 0; c1 = T.ldsx ? T.nchunks : T.P; }
-  if (c1 <= c0) return FS_OK;
-  if (T.ldsx) {
-    // chunks of one panel add into the same rows: the output then goes through the zeroed scratch vector (a part launch
-    // adds into T.yv as it is and leaves the copy to y to its caller, who zeroed T.yv before the first part)
-    // fixed-order sums: the chunks of a panel take turns (a ticket per panel, zeroed here) -- see ldsx_store_slice
-    const bool ordered = reproducible_now() && T.orderable;
-    if (T.shared) {
-      if (!part) FS_HIP(hipMemsetAsync(T.yv, 0, sizeof(double) * (size_t)A.nrow, s));
-      if (!part && ordered) FS_HIP(hipMemsetAsync(T.ticket, 0, sizeof(int) * (size_t)T.P, s));
-      out = T.yv;
-    }
-    const int ost = T.shared ? 1 : ys;
-    if (T.nchunks > 0) {
-#define FS_LDSXP(V, N, X1)                                                                                         \
-  hipLaunchKernelGGL((spmv_ldsx_pipe_kernel<V, N, X1, kLdsxPipeSets>), dim3(c1 - c0), dim3(kTiledBlock), 0, s,       \
-                     T.panel_row, T.W, T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, \
-                     out, xs, ost, (int)ordered, T.chunk_ord + c0, T.ticket)
-      // slices by LDS DMA: unit-stride x, 16-byte aligned, an even number of columns (bit 2 of tiled_flags turns it off)
-      if (!(options().tiled_flags & 4) && xs == 1 && A.ncol >= 2 && (A.ncol & 1) == 0 &&
-          (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
-#define FS_LDSXD(V, N, O)                                                                                           \
-  hipLaunchKernelGGL((spmv_ldsx_dma_kernel<V, N, kLdsxDmaSets, O>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row, T.W, \
-                     T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, ost,    \
-                     T.chunk_ord + c0, T.ticket)
-#define FS_LDSXD2(V, N) do { if (ordered) FS_LDSXD(V, N, true); else FS_LDSXD(V, N, false); } while (0)
-        if (A.vals) { if (nt) FS_LDSXD2(true, true); else FS_LDSXD2(true, false); }
-        else        { if (nt) FS_LDSXD2(false, true); else FS_LDSXD2(false, false); }
-#undef FS_LDSXD2
-#undef FS_LDSXD
-      } else if (xs == 1 && A.ncol >= 2) {
-        if (A.vals) { if (nt) FS_LDSXP(true, true, true); else FS_LDSXP(true, false, true); }
-        else        { if (nt) FS_LDSXP(false, true, true); else FS_LDSXP(false, false, true); }
-      } else {                                     // one column of a row-major X: strided slice loads
-        if (A.vals) FS_LDSXP(true, true, false); else FS_LDSXP(false, true, false);
-      }
-#undef FS_LDSXP
-      FS_HIP(hipGetLastError());
-    }
-    if (T.shared && !part) {
-      hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                         A.nrow, T.yv, y, ys);
-      FS_HIP(hipGetLastError());
-    }
-    return FS_OK;   // rows are never cut for this kernel: no combine pass
-  } else {
-#define FS_TILED(V, N)                                                                                         \
-  hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row + c0, T.W, T.lcol_bits, \
-                     T.items, T.item_ptr + c0, T.pk, T.vals, x, out, xs, os)
-    if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
-    else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
-#undef FS_TILED
-  }
-  FS_HIP(hipGetLastError());
-  if (T.split) {
-    hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       A.nrow, T.vfirst, T.yv, y, ys);
-    FS_HIP(hipGetLastError());
-  }
-  return FS_OK;
-}
-
-// p0 .. p1: the panels pass 2 covers in this launch (p1 < 0: all of them); pass 1 runs when p0 == 0.  With cut rows the
-// combine pass covers rows row0 .. row1 (the rows whose last piece lies in a panel below p1: see spmv_part_bounds).
-int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys, int p0, int p1, int row0,
-                       int row1)
-{
-  const BinnedCsr &N = *A.binned;
-  double *out = N.split ? N.yv : y;              // cut rows: virtual sums first, combined below
-  const int os = N.split ? 1 : ys;
-  const bool part = p1 >= 0;
-  if (!part) { p0 = 0; p1 = N.P; row0 = 0; row1 = A.nrow; }
-  const int nwg1 = (options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1;
-  if (nwg1 > 0 && p0 == 0) {
-    // tuning switches (A/B runs): bits 0-1 pass-1 unroll (1: 8, 2: 2 steps; default 4), bit 2 pass-2 loads
-    // non-temporal, bit 3 pass-1 stores plain, bit 4 pass-1 loads non-temporal.  Defaults, measured on config 2
-    // (valued / pattern-only, ms per product): plain loads in both passes and non-temporal stores 0.95 / 0.69;
-    // non-temporal loads in pass 1 0.98 / 0.73, in pass 2 as well 1.09 / 0.84; plain stores 1.01 / 0.75
-    const int flags = options().bin_flags;
-#define FS_EXPAND4(V, U)                                                                                          \
-  do {                                                                                                            \
-    if (flags & 16) { if (flags & 8) FS_EXPAND(V, U, true, false);  else FS_EXPAND(V, U, true, true); }           \
-    else            { if (flags & 8) FS_EXPAND(V, U, false, false); else FS_EXPAND(V, U, false, true); }          \
-  } while (0)
-#define FS_EXPAND(V, U, NL, NS)                                                                                    \
-  hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
-                     N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog))
-    if (N.bcols == kBinColsBig) {                // the large-band copy: default switches only
-      if (A.vals)
-        hipLaunchKernelGGL((spmv_expand_kernel<true, 4, false, true, kBinColsBig>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B,
-                           N.band_ptr, N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog));
-      else
-        hipLaunchKernelGGL((spmv_expand_kernel<false, 4, false, true, kBinColsBig>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B,
-                           N.band_ptr, N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog));
-    } else
-    if (A.vals) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
-    else        { if ((flags & 3) == 1) FS_EXPAND4(false, 8); else if ((flags & 3) == 2) FS_EXPAND4(false, 2); else FS_EXPAND4(false, 4); }
-#undef FS_EXPAND4
-#undef FS_EXPAND
-    FS_HIP(hipGetLastError());
-  }
-  if (N.lr && p0 == 0)          // behind pass 1, in front of pass 2: HBM-bound like both
-    if (int rc = launch_longrows(A, *N.lr, x, xs, s)) return rc;
-  if (p1 > p0) {
-    // "reproducible" (or bit 5 of bin_flags): one wave per panel, additions in stream order, bit-identical run to run
-    const bool ordered = reproducible_now() || (options().bin_flags & 32);
-    if (N.bcols == kBinColsBig && ordered)
-      hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsBig, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
-                         N.panel_row, N.lrow, N.prod, out, os, p0);
-    else if (N.bcols == kBinColsBig)
-      hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row,
-                         N.lrow, N.prod, out, os, p0);
-    else if (ordered)
-      hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsMax, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
-                         N.panel_row, N.lrow, N.prod, out, os, p0);
-    else if (options().bin_flags & 4)
-      hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
-                         out, os, p0);
-    else
-      hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
-                         out, os, p0);
-    FS_HIP(hipGetLastError());
-  }
-  if (N.split && row1 > row0) {
-    hipLaunchKernelGGL(tiled_combine_kernel, dim3((unsigned)(((int64_t)(row1 - row0) + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       row1, N.vfirst, N.yv, y, ys, row0);
-    FS_HIP(hipGetLastError());
-  }
-  if (N.lr && row1 > row0) {   // the long rows of this range: their sums were left in ylong by the launch behind pass 1
-    hipLaunchKernelGGL(longrows_scatter_kernel, dim3((unsigned)((N.lr->nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, N.lr->nlong,
-                       N.lr->row, N.lr->ylong, y, ys, row0, row1);
-    FS_HIP(hipGetLastError());
-  }
-  return FS_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2092,88 +585,6 @@ int launch_spmv_part(DeviceCsr &A, double *y, const double *x, int part, int npa
   if (kind == 7) return launch_spmv_binned(A, y, x, s, 1, 1, units[part], units[part + 1], rows[part], rows[part + 1]);
   if (units[part + 1] <= units[part]) return FS_OK;
   return launch_spmv_tiled(A, kind == 8 ? *A.tiledx : *A.tiled, y, x, s, 1, 1, units[part], units[part + 1]);
-}
-
-// one sweep of a k-column two-pass copy: Y[:, 0:kw] = A X[:, 0:kw]; X / Y rows are xs / ys doubles apart
-// p0 .. p1 / row0 .. row1: as launch_spmv_binned (p1 < 0: the whole sweep)
-int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const double *X, hipStream_t s, int xs, int ys, int p0,
-                       int p1, int row0, int row1)
-{
-  const int K = N.kw;
-  double *out = N.split ? N.yv : Y;
-  const int os = N.split ? K : ys;
-  if (p1 < 0) { p0 = 0; p1 = N.P; row0 = 0; row1 = A.nrow; }
-  const int nwg1 = (p0 != 0) ? 0 : ((options().bin_wgs > 0 && options().bin_wgs < N.nwg1) ? options().bin_wgs : N.nwg1);
-#define FS_XP(V, KK)                                                                                                  \
-  hipLaunchKernelGGL((spmm_expand_kernel<V, KK, 4>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol, \
-                     N.vals, N.gdst, X, xs, N.prod)
-  if (nwg1 > 0) {
-    if (K == 2) { if (A.vals) FS_XP(true, 2); else FS_XP(false, 2); }
-    else        { if (A.vals) FS_XP(true, 4); else FS_XP(false, 4); }
-    FS_HIP(hipGetLastError());
-  }
-#undef FS_XP
-  if (p1 > p0) {
-    const bool ordered = reproducible_now() || (options().bin_flags & 32);   // one wave per panel, stream order
-    if (K == 2 && ordered)
-      hipLaunchKernelGGL((spmm_reduce_ordered_kernel<2, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
-    else if (ordered)
-      hipLaunchKernelGGL((spmm_reduce_ordered_kernel<4, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
-    else if (K == 2)
-      hipLaunchKernelGGL(spmm_reduce_kernel<2>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
-    else
-      hipLaunchKernelGGL(spmm_reduce_kernel<4>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, out, os, p0);
-    FS_HIP(hipGetLastError());
-  }
-  if (N.split && row1 > row0) {
-    const unsigned grid = (unsigned)(((int64_t)(row1 - row0) * K + kBlock - 1) / kBlock);
-    if (K == 2)
-      hipLaunchKernelGGL(tiled_combine_k_kernel<2>, dim3(grid), dim3(kBlock), 0, s, row1, N.vfirst, N.yv, Y, ys, row0);
-    else
-      hipLaunchKernelGGL(tiled_combine_k_kernel<4>, dim3(grid), dim3(kBlock), 0, s, row1, N.vfirst, N.yv, Y, ys, row0);
-    FS_HIP(hipGetLastError());
-  }
-  return FS_OK;
-}
-
-// y = A'A x in one kernel (fs_ata_mul, option ata_kernel = 2): on the LDS-staged copy when the matrix has one with
-// one chunk per panel, else on the plain CSR.  y is zeroed here.
-int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t s)
-{
-  if (A.ncol == 0) return FS_OK;
-  FS_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)A.ncol, s));
-  if (A.nrow == 0 || A.nnz == 0) return FS_OK;
-  const TiledCsr *T = A.tiledx;
-  if (T && T->built && !T->shared && T->nchunks > 0) {
-#define FS_ATA(V)                                                                                                        \
-  hipLaunchKernelGGL((ata_ldsx_kernel<V, true, kLdsxSets>), dim3(T->nchunks), dim3(kTiledBlock), 0, s, T->panel_row, \
-                     T->W, T->lcol_bits, A.ncol, T->items, T->chunk_panel, T->chunk_item, T->pk, T->vals, x, y, 1, 1)
-    if (A.vals) FS_ATA(true); else FS_ATA(false);
-#undef FS_ATA
-  } else {
-    const unsigned grid = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
-    if (A.vals) hipLaunchKernelGGL(ata_csr_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.row_ptr, A.cols, A.vals, x, y);
-    else        hipLaunchKernelGGL(ata_csr_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.row_ptr, A.cols, A.vals, x, y);
-  }
-  FS_HIP(hipGetLastError());
-  return FS_OK;
-}
-
-// diagnostic: one launch of the tiled kernel that also records, per work item, the start time
-// (100 MHz wall clock) and, per panel, the XCD that ran it
-int launch_spmv_tiled_trace(const DeviceCsr &A, double *y, const double *x, long long *times_dev, int *xcc_dev,
-                            hipStream_t s)
-{
-  const TiledCsr &T = *A.tiled;
-  double *out = T.split ? T.yv : y;
-  if (A.vals)
-    hipLaunchKernelGGL((spmv_tiled_kernel<true, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, out, 1, 1, times_dev, xcc_dev);
-  else
-    hipLaunchKernelGGL((spmv_tiled_kernel<false, true, true>), dim3(T.P), dim3(kTiledBlock), 0, s, T.panel_row, T.W,
-                       T.lcol_bits, T.items, T.item_ptr, T.pk, T.vals, x, out, 1, 1, times_dev, xcc_dev);
-  FS_HIP(hipGetLastError());
-  return FS_OK;
 }
 
 // which kernel a single-vector product on A runs under the options o: 7 two-pass, 8 LDS-staged, 6 L2-tiled, 2 lanes per
@@ -2376,9 +787,7 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
         if (int rc = launch_spmv_tiled(A, M, H.sy, H.sx, H.stream, 1, 1, w0, w1)) return rc;
         w0 = w1;
       }
-      hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)(((int64_t)A.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, H.stream,
-                         A.nrow, M.yv, H.sy, 1);
-      FS_HIP(hipGetLastError());
+      if (int rc = launch_strided_copy(A.nrow, M.yv, H.sy, 1, H.stream)) return rc;
       FS_HIP(hipStreamSynchronize(H.stream));
       if (trace) fprintf(stderr, "[host] %.3f ms: kernels done\n", now_ms());
       FS_HIP(hipMemcpy(y_host, H.sy, sizeof(double) * ny, hipMemcpyDeviceToHost));
@@ -2457,25 +866,13 @@ int spmv_host_vectors(const DeviceCsr &A, HostPipe &H, double *y_host, const dou
     int wgs = nwg1;
     const int64_t cap = ((int64_t)(g1 - g0) * kBinGroup + kBinShareMin - 1) / kBinShareMin;
     if (cap < wgs) wgs = (int)(cap < 1 ? 1 : cap);
-#define FS_XH(V, BC)                                                                                                    \
-  hipLaunchKernelGGL((spmv_expand_kernel<V, 4, false, true, BC>), dim3(wgs), dim3(kBinBlock), 0, H.stream, A.ncol, N.B, \
-                     N.band_ptr, N.lcol, N.vals, N.gdst, H.sx, 1, N.prod, g0, g1)
-    if (N.bcols == kBinColsBig) { if (A.vals) FS_XH(true, kBinColsBig); else FS_XH(false, kBinColsBig); }
-    else                        { if (A.vals) FS_XH(true, kBinCols); else FS_XH(false, kBinCols); }
-#undef FS_XH
-    FS_HIP(hipGetLastError());
+    if (int rc = launch_expand_groups(A, H.sx, g0, g1, wgs, H.stream)) return rc;
   }
   // pass 2, panel range by panel range, an event behind each
   const int c2 = want_chunks < N.P ? want_chunks : N.P;
   for (int j = 0; j < c2; ++j) {
     const int p0 = (int)((int64_t)N.P * j / c2), p1 = (int)((int64_t)N.P * (j + 1) / c2);
-    if (N.bcols == kBinColsBig)
-      hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, H.stream, N.bin_ptr,
-                         N.panel_row, N.lrow, N.prod, H.sy, 1, p0);
-    else
-      hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, H.stream, N.bin_ptr, N.panel_row, N.lrow,
-                         N.prod, H.sy, 1, p0);
-    FS_HIP(hipGetLastError());
+    if (int rc = launch_reduce_panels(A, H.sy, p0, p1, H.stream)) return rc;
     FS_HIP(hipEventRecord(H.ev[j], H.stream));
   }
   for (int j = 0; j < c2; ++j) {

@@ -23,10 +23,10 @@ def _hipcc():
 
 @pytest.mark.skipif(_hipcc() is None, reason="hipcc not available")
 def test_dma_kernel_waits_match_the_compiled_memory_operations(tmp_path):
-    out = tmp_path / "fs_kernels.s"
+    out = tmp_path / "fs_kernels_tiled.s"
     subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "--cuda-device-only", "-S",
-                    os.path.join(CSRC, "fs_kernels.hip"), "-o", str(out)], check=True, capture_output=True)
+                    os.path.join(CSRC, "fs_kernels_tiled.hip"), "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
     found = 0
     for m in re.finditer(r"^(_ZN2fs20spmv_ldsx_dma_kernelILb([01])ELb[01]ELi(\d+)ELb([01])EEE[^:\n]*):", text, re.M):

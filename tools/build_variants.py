@@ -1,4 +1,4 @@
-"""Experiment builds of the library next to the product build: fs_kernels.hip (and fs_abi.hip, for the debug exports) compiled with
+"""Experiment builds of the library next to the product build: the kernel translation units (and fs_abi.hip, for the debug exports) compiled with
 extra -D flags, linked with the product build's other objects into libfastsparse_amd/build/variants/libfs_<name>.so; a tool then runs
 with FS_LIB_PATH=<that file>.  Several variants fit into ONE gpurun call, i.e. are timed on the same box.
     python tools/build_variants.py name=-DFS_DMA_ABL=3 other="-DFS_DMA_ABL=4 -DFS_DMA_SETS=9" ...
@@ -24,7 +24,7 @@ def one(spec):
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + _build.CSRC]
     objs = []
     for src in _build.HIP_SOURCES:
-        if src in ("fs_kernels.hip", "fs_abi.hip"):
+        if src in ("fs_kernels.hip", "fs_kernels_tiled.hip", "fs_kernels_twopass.hip", "fs_abi.hip"):
             o = os.path.join(out_dir, "%s_%s.o" % (name, src))
             subprocess.check_call([_build._hipcc(), "--offload-arch=" + _build.ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                                    "-Wall", "-Wno-unused-result"] + flags.split() + inc + ["-c", os.path.join(_build.CSRC, src), "-o", o])
