@@ -650,6 +650,13 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     u = prov.sin_vector(n_global, 11.0, -0.2)       # 2nd column of X2col, :145
     y = prov.empty(n_global)
     z = prov.empty(ncol)
+    # first contact: is the exchange inside the product sound on this fabric?  (it never ran on more than one RCCL rank before
+    # the driver's run; an operator whose overlapped and plain exchanges disagree falls back to the plain one, on every rank)
+    exchange_check = None
+    if _multi(world):
+        exchange_check = {"y": op_a.verify_overlap(y, x, nparts)}
+        if z_scheme == "gather":
+            exchange_check["z"] = op_t.verify_overlap(z, u, nparts)
 
     def step(ev=None, exchange=True):
         """N = 1: A x, A' u.  N > 1, the iterating consumer's order (cg.h:15-16): [A x in parts, the all-gather of the finished
@@ -799,6 +806,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         rec["roofline"].update(config2_bound(bytes_per_launch))
     if _multi(world):
         rec["config"].update({
+            "exchange_check": exchange_check,
             "exchange": {"y": "all-gather of the y shards, started part by part inside the product (%d parts)" % nparts,
                          "how": getattr(args, "exchange", "allgather"),
                          "z_scheme": z_scheme, "z_scheme_fallback_reason": z_err,
@@ -1123,6 +1131,12 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         if float(ok_t.item()) == 0.0 and opt is not None:
             opt, t_err = None, "another rank could not build its shard of A'"
 
+    exchange_check = None
+    if _multi(world):
+        exchange_check = {"y": op.verify_overlap(y, x, nparts)}
+        if opt is not None:
+            exchange_check["z"] = opt.verify_overlap(z, u, nparts)
+
     def step(ev=None, exchange=True, transpose=False):
         if not _multi(world):
             ev = None                  # one GPU: ONE event pair around the K steps (timed_steps)
@@ -1234,6 +1248,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
     if _multi(world):
         rec["config"]["rccl_status"] = "first contact: no multi-GPU machine was available to the builder"
+        rec["config"]["exchange_check"] = exchange_check
     if not _multi(world) and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
             rec["cpu_baseline"] = cpu_baseline_c5(lo, ncol, sample_rows=args.cpu_sample_rows or 1_000_000)

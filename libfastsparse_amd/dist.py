@@ -201,6 +201,32 @@ class ShardedOperator:
         self.max_rows = max(sizes)
         self._pad = None
         self._y_local = None
+        # conservative exchange: ONE whole-shard all-gather behind the finished local product instead of one per part under the
+        # later parts (FS_DIST_CONSERVATIVE=1, or after verify_overlap found the overlapped exchange unsound on this machine)
+        self.conservative = os.environ.get("FS_DIST_CONSERVATIVE", "") == "1"
+
+    def verify_overlap(self, y_full, x_full, nparts=4):
+        """First contact with a fabric the overlapped exchange has never run on (RCCL with more than one rank had not, when this
+        was written): the same product with the exchange INSIDE it and with the plain whole-shard all-gather behind it must give
+        the same vector on every rank (to rounding: the parts do not change a row's terms, only -- without fixed-order sums --
+        their order).  If any rank sees a difference, every rank switches this operator to the conservative exchange.  Collective.
+        Returns {"mode": "overlapped" | "conservative", "max_rel_diff": ...} (what bench.py puts into its record)."""
+        if _single(self.world) or self.parts is None or nparts <= 1 or self.conservative:
+            return {"mode": "conservative" if self.conservative else "overlapped", "checked": False}
+        yo = torch.empty_like(y_full)
+        self.apply_overlapped_async(yo, x_full, nparts).wait()
+        self.gather(y_full, self.local(y_full, x_full))
+        scale = float(y_full.abs().max().item())
+        diff = float((yo - y_full).abs().max().item()) / (scale if scale > 0 else 1.0)
+        bad = torch.tensor([0.0 if diff <= 1e-9 else 1.0, diff], dtype=torch.float64, device=y_full.device)
+        if _host_collective(bad, self.group):
+            h = bad.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            bad = h
+        else:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        self.conservative = bool(float(bad[0].item()) > 0.0)
+        return {"mode": "conservative" if self.conservative else "overlapped", "checked": True, "max_rel_diff": float(bad[1].item())}
 
     @property
     def nrow(self):
@@ -296,7 +322,7 @@ class ShardedOperator:
     def apply_overlapped_async(self, y_full, x_full, nparts=4):
         """local product in `nparts` parts; the all-gather of part p's rows is started as soon as part p is enqueued and
         runs under parts p + 1 ...; returns a handle whose wait() leaves y_full complete on the current stream"""
-        if _single(self.world) or self.parts is None or nparts <= 1:
+        if _single(self.world) or self.parts is None or nparts <= 1 or self.conservative:
             return self.gather_async(y_full, self.local(y_full, x_full))
         y_local = self._buffers(y_full)
         plan = self._part_plan(nparts, y_full)

@@ -178,6 +178,26 @@ def _cg_worker(rank, world, port, ret):
                         if not np.array_equal(y.numpy(), ref):
                             ok = False
                             why.append((name, k, "overlapped", how, nparts))
+                # (1b) first contact with a fabric: verify_overlap compares the exchange inside the product with the plain one on every
+                # rank (sound here: stays overlapped); an operator that one rank finds unsound goes conservative on ALL ranks --
+                # provoked by a local kernel that corrupts a part on the last rank only -- and then still gives the product
+                y = torch.full((N * k,), -1.0, dtype=torch.float64)
+                chk = op_a.verify_overlap(y, torch.from_numpy(X), 3)
+                if not (chk["mode"] == "overlapped" and chk["checked"] and chk["max_rel_diff"] == 0.0 and np.array_equal(y.numpy(), ref)):
+                    ok = False
+                    why.append((name, k, "verify_overlap", chk))
+
+                class _BadParts(fsd.EvenParts):
+                    def run(self, y_local, x_full, part, nparts):
+                        super().run(y_local, x_full, part, nparts)
+                        if rank == world - 1 and part == nparts - 1 and nparts > 1 and y_local.numel():
+                            y_local[-1] += 12345.0          # what a missing stream dependency would look like: a stale row
+                op_b = fsd.ShardedOperator(a_local, rb, parts=_BadParts(a_local, hi - lo), k=k)
+                chk = op_b.verify_overlap(y, torch.from_numpy(X), 3)
+                op_b.apply_overlapped(y, torch.from_numpy(X), 3)
+                if not (chk["mode"] == "conservative" and op_b.conservative and np.array_equal(y.numpy(), ref)):
+                    ok = False
+                    why.append((name, k, "verify_overlap did not fall back", chk))
                 # (2) the solvers
                 B = np.ascontiguousarray(np.stack([np.sin(0.37 * np.arange(F) + 1.0 + j) for j in range(k)], 1)).reshape(-1)
                 xref, itref = O.cg_normal(N, F, rows, cols, B.reshape(F, k) if k > 1 else B, 0.5, 1e-8, two=(k == 2))
