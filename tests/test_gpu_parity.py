@@ -887,8 +887,29 @@ def test_fuzz_every_forced_copy_small_shapes(hip):
                 assert np.all(np.abs(zh - zref) <= TOL * np.maximum(zs, 1e-300)), what
             else:
                 assert np.array_equal(yh, ref) and np.array_equal(zh, zref), what
+            # fixed-order sums on whatever copy was kept: non-integer vectors, three runs bit-identical, every
+            # element inside the row-scaled bar; a copy that cannot give them (an LDS-staged copy with a row too dense for one
+            # wave) must have handed the product to another kernel -- the results decide, not the kernel's name
+            xs_, us_ = S.x_sin(ncol), S.x_sin(nrow, 11.0, -0.2)
+            rs_, rt_ = O.csr_mul(nrow, rp, cc, vv, xs_), O.coo_tmul(ncol, rows, cc, vv, us_)
+            ss_ = np.maximum(O.csr_abs_scale(nrow, rp, cc, vv, xs_), 1e-300)
+            st_ = np.maximum(O.coo_tmul(ncol, rows, cc, None if vv is None else np.abs(vv), np.abs(us_)), 1e-300)
+            capi.set_option("reproducible", 1)
+            try:
+                runs = []
+                for _ in range(3):
+                    y.fill_(-1.0); z.fill_(-1.0)
+                    A.spmv(y, torch.from_numpy(xs_).cuda(), capi.current_stream())
+                    A.spmv(z, torch.from_numpy(us_).cuda(), capi.current_stream(), transposed=True)
+                    runs.append((y.cpu().numpy().copy(), z.cpu().numpy().copy()))
+                whatr = what + (A.kernel_name(), A.kernel_name(True))
+                assert all(np.array_equal(runs[0][0], r_[0]) and np.array_equal(runs[0][1], r_[1]) for r_ in runs[1:]), whatr
+                assert np.all(np.abs(runs[0][0] - rs_) <= TOL * ss_) and np.all(np.abs(runs[0][1] - rt_) <= TOL * st_), whatr
+            finally:
+                capi.set_option("reproducible", 0)
             del A
     finally:
+        capi.set_option("reproducible", 0)
         for k_ in ("tile_rows", "tile_cols", "bin_rows", "tile_split"):
             capi.set_option(k_, 0)
     assert {0, 1, 2} <= host_paths or int(os.environ.get("FS_FUZZ_TRIALS", "48")) < 48, host_paths
