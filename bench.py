@@ -1426,6 +1426,29 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     return recs
 
 
+_STDOUT_FD = None       # N > 1: the real stdout, kept aside while fd 1 points at stderr (see quiet_stdout)
+
+
+def quiet_stdout():
+    """N > 1: RCCL prints a version banner on STDOUT when a communicator is created (5 lines in front of the JSON line in round
+    3's rehearsals), and anything else a library prints there would land next to the one line the driver reads.  From here on
+    fd 1 is stderr; emit() writes the JSON line to the real stdout."""
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(rec):
+    line = (json.dumps(rec) + "\n").encode()
+    if _STDOUT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_STDOUT_FD, line)
+
+
 def budget_watchdog(seconds, rank, headline, recs, state):
     """The headline must survive whatever the sub-workloads do: a rank that dies inside a collective of config 5 would leave the
     others waiting for RCCL's own timeout, longer than the driver waits.  After `seconds` (FS_BENCH_BUDGET_S, default 480) every
@@ -1436,7 +1459,7 @@ def budget_watchdog(seconds, rank, headline, recs, state):
         if rank == 0 and headline is not None:
             rec = dict(headline)
             rec["also"] = list(recs) + [{"workload": state.get("current"), "error": "not finished within the %d s budget" % seconds}]
-            print(json.dumps(rec), flush=True)
+            emit(rec)
         os._exit(0 if headline is not None or rank != 0 else 1)
 
     t = threading.Timer(seconds, fire)
@@ -1507,6 +1530,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if _multi(world):
+        quiet_stdout()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "WORLD_SIZE" not in os.environ:      # FS_BENCH_FORCE_MULTI without a launcher: a one-rank group of its own
             os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
@@ -1539,7 +1563,7 @@ def main():
             raise SystemExit("--workload %s is a one-GPU workload" % args.workload)
         rec = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload](args, prov, world, rank, nccl)
     if rank == 0 and rec is not None:
-        print(json.dumps(rec), flush=True)
+        emit(rec)
     if _multi(world):
         dist.destroy_process_group()
 
