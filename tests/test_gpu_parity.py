@@ -2383,3 +2383,23 @@ def test_lds_staged_kernel_fixed_order_sums(hip, valued):
         xi = S.x_int(3, ncol)
         A.spmv(y, torch.from_numpy(xi).cuda(), st)
         assert np.array_equal(y.cpu().numpy(), O.csr_mul(nrow, rpn, ccn, None, xi))
+
+
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_plain_c_caller_of_the_multi_gpu_abi(hip, ranks, tmp_path):
+    """north_star: "host C dispatching through a thin C-ABI ... rows range-partitioned across the GPUs".  tests/c/dist_shards_caller.c
+    is a C99 program that includes only include/fastsparse_hip.h: per-rank shards in, A' built on the devices, both products
+    checked bit for bit against the reference's serial loops restated in it, bsbm_cg across the ranks checked by its residual."""
+    import shutil
+    import subprocess
+    from libfastsparse_amd import capi
+    capi.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "libfastsparse_amd")
+    exe = str(tmp_path / "dist_shards_caller")
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    subprocess.run([gcc, "-std=gnu99", "-O2", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "dist_shards_caller.c"),
+                    "-o", exe, "-L" + libdir, "-lfastsparse_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    p = subprocess.run([exe, str(ranks)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith("OK ranks=%d" % ranks), (p.stdout[-800:], p.stderr[-800:])
