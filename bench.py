@@ -567,7 +567,7 @@ def config2_bound(alg_bytes):
     measured NOT to overlap in a kernel with an LDS-resident y slice (probe_mix, DESIGN.md "gather ceiling"), but even perfectly
     overlapped the gathers alone bound the product; or (b) no gathers at all -- every random access in LDS, which costs a pass
     over an intermediate: 28 bytes per entry (the kept two-pass pair), 2.33 x the algorithmic bytes."""
-    gather_floor_ms = 0.61                      # 160 M L2-hit gathers, best of profiles/r01_probe_gather.jsonl ("tiled", 0.26 MB window)
+    gather_floor_ms = 0.606                     # 160 M L2-hit gathers, best of profiles/r04_probe_gather.jsonl ("tiled", 0.26 MB window; r01: 0.606)
     stream_floor_ms = 1.92e9 / (HBM_COPY_GBS * 1e9) * 1e3     # the 12-byte entry stream at the copy rate
     overlapped = max(gather_floor_ms, stream_floor_ms)
     two_pass_floor_ms = (28.0 * 160e6 + 2 * 8e7 + 4e7) / (HBM_COPY_GBS * 1e9) * 1e3
@@ -577,8 +577,10 @@ def config2_bound(alg_bytes):
             "gather_kernel_ceiling_if_not_overlapped_frac": alg_bytes / ((gather_floor_ms + stream_floor_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "two_pass_floor_ms": two_pass_floor_ms,
             "any_kernel_ceiling_frac": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "bound_sources": ["profiles/r01_probe_gather.jsonl (L2-hit gather rate)", "profiles/r01_probe_mix.jsonl (gathers + stream in one "
-                              "kernel: 0.79-0.98 ms, not overlapped)", "profiles/r02_probe_hybrid_cu_mask.jsonl (gather kernel and two-pass "
+            "gathers_plus_stream_measured_ms": 0.772,      # probe_mix: the gathers AND the 12-byte stream in one kernel, no y at all
+            "bound_sources": ["profiles/r04_probe_gather.jsonl, r01_probe_gather.jsonl (L2-hit gather rate: 0.606-0.69 ms for 160 M)",
+                              "profiles/r04_probe_mix.jsonl, r01_probe_mix.jsonl (gathers + stream in one kernel: 0.77-0.84 ms with small "
+                              "workgroups, 0.91-1.06 ms with the one-workgroup-per-CU shape an LDS-resident y slice forces: not overlapped)", "profiles/r02_probe_hybrid_cu_mask.jsonl (gather kernel and two-pass "
                               "pair side by side: no overlap)", "profiles/r01_probe_mall.jsonl (intermediate through the Infinity Cache: x 1.3 only)",
                               "MI355X_MICROARCH.md (6.29 TB/s copy rate)"],
             "bound_statement": "uniform-random columns over an 80 MB x: measured, this algorithm's ceiling (design_ceiling_frac) and the "
