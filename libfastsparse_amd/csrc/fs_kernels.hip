@@ -932,11 +932,12 @@ __global__ __launch_bounds__(kBlock) void columns_to_rows_kernel(int64_t n, int 
 //           2-column sweep and a single-vector sweep) -- needs the k-column copy, which prepare builds
 //   plan 3  one single-vector two-pass sweep per column (strided gathers and stores): k <= 3 without a k-column copy
 //   plan 5  a matrix on the LDS-staged copy (dense tiles: config 3's class): one unit-stride sweep per column on
-//           COLUMN-major copies of X and Y (two transposes; the handle's scratch, allocated by prepare or on first use);
+//           COLUMN-major copies of X and Y (two transposes; the handle's scratch, allocated by prepare ONLY: before it the strided
+//           sweeps, k = 2, or the row kernel serve);
 //           for k >= 3 prepare times this against the row kernel on the matrix and keeps the faster (neither wins
 //           everywhere: config 3's shape 0.77 ms per column against a row kernel bound by its X-row gathers at 51 G/s,
 //           12.5 ms for any k from 4 to 16; 10 M rows x 16 with X of 131 K rows, k = 8: 3.5 ms in sweeps, 2.05 ms on
-//           the row kernel, X in L2).  Unprepared: the sweeps (the kernel the builder kept this copy for)
+//           the row kernel, X in L2)
 //   plan 6 / 7  k <= 2 strided sweeps of the LDS-staged / L2-tiled kernel
 //   plan 4  the v_mfma_f64_16x16x4_f64 experiment (option spmm_kernel = 4)
 //   plan 1  the row kernel: k >= 5 on two-pass matrices, k > 16, strict_order / reproducible, small matrices
