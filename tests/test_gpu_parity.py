@@ -2456,3 +2456,9 @@ def test_the_references_own_bench_harness_runs_on_the_product_library(hip, tmp_p
             labels += ["[BlockCG2]\tniter:"]
         for label in labels:
             assert label in out, (flags, label, out[-2000:])
+    # bench_csr.c: the fused A'A x of parallel_bcsr_AA_mul_B (csr.h:323) on the fixture and on its transpose
+    exe = _ref_caller("bench_csr_hip")
+    if os.path.exists(exe):
+        for flags in ([], ["-t"]):
+            p = subprocess.run([exe, "-f", "data/sbm-100-50.data"] + flags, cwd=cwd, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0 and "[par B'B x]" in p.stdout, (flags, (p.stdout + p.stderr)[-2000:])
