@@ -580,8 +580,8 @@ def config2_bound(alg_bytes):
             "gathers_plus_stream_measured_ms": 0.772,      # probe_mix: the gathers AND the 12-byte stream in one kernel, no y at all
             "bound_sources": ["profiles/r04_probe_gather.jsonl, r01_probe_gather.jsonl (L2-hit gather rate: 0.606-0.69 ms for 160 M)",
                               "profiles/r04_probe_mix.jsonl, r01_probe_mix.jsonl (gathers + stream in one kernel: 0.77-0.84 ms with small "
-                              "workgroups, 0.91-1.06 ms with the one-workgroup-per-CU shape an LDS-resident y slice forces: not overlapped)", "profiles/r02_probe_hybrid_cu_mask.jsonl (gather kernel and two-pass "
-                              "pair side by side: no overlap)", "profiles/r01_probe_mall.jsonl (intermediate through the Infinity Cache: x 1.3 only)",
+                              "workgroups, 0.91-1.06 ms with the one-workgroup-per-CU shape an LDS-resident y slice forces: not overlapped)", "profiles/r02_probe_hybrid_cu_mask.jsonl, r04_probe_overlap.jsonl (gather role and "
+                              "stream role side by side, on disjoint CUs or in one launch: the SUM of their times, no overlap)", "profiles/r01_probe_mall.jsonl (intermediate through the Infinity Cache: x 1.3 only)",
                               "MI355X_MICROARCH.md (6.29 TB/s copy rate)"],
             "bound_statement": "uniform-random columns over an 80 MB x: measured, this algorithm's ceiling (design_ceiling_frac) and the "
                                "ceiling of any exact-fp64 kernel on this chip (any_kernel_ceiling_frac); the 0.60 target needs 364 G "
