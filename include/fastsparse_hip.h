@@ -271,6 +271,14 @@ int  fs_dist_swap_xy(fs_dist_matrix_t M);
  * option "cg_fixed_order" is 0.  b_host, x_host: ncol doubles; stops at ||r|| <= tol ||b||.
  * CLOBBERS fs_dist_x / fs_dist_y / fs_dist_z (they are the solver's work vectors): upload x again before the next resident product. */
 int  fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double lambda, double tol, int *out_iter);
+/* k row-major columns across the GPUs (csr_A_mul_Bn csr.h:441, bcsr_A_mul_Bn csr.h:257, bsbm_A_mul_Bn sparse.h:318): every device
+ * multiplies its shard with the k-column kernels of fs_spmm (prepared on the first call with a new k: synchronous) and the Y shards
+ * are all-gathered in one whole-shard exchange; host matrices Y[nrow, k], X[ncol, k] / Z[ncol, k], U[nrow, k]; k = 1 is fs_dist_spmv */
+int  fs_dist_spmm(fs_dist_matrix_t M, double *Y_host, const double *X_host, int k);
+int  fs_dist_spmm_t(fs_dist_matrix_t M, double *Z_host, const double *U_host, int k);
+/* (A'A + lambda I) X = B with two right-hand sides, row-major ncol x 2: bsbm_cg2 (cg.h:85-187) across the GPUs; the vector steps
+ * and the 2x2 algebra replicated on every device, convergence compared across all devices like fs_dist_cg */
+int  fs_dist_cg2(fs_dist_matrix_t M, double *X_host, const double *B_host, double lambda, double tol, int *out_iter);
 double *fs_dist_x(fs_dist_matrix_t M, int rank);
 double *fs_dist_y(fs_dist_matrix_t M, int rank);
 double *fs_dist_z(fs_dist_matrix_t M, int rank);

@@ -32,7 +32,7 @@ DEVICE_API = [
     "fs_dist_matrix_bounds", "fs_dist_matrix_shard_nnz", "fs_dist_spmv", "fs_dist_spmv_resident", "fs_dist_x", "fs_dist_y",
     "fs_dist_matrix_build_transpose", "fs_dist_matrix_has_transpose", "fs_dist_spmv_t", "fs_dist_spmv_t_resident", "fs_dist_swap_xy",
     "fs_dist_z", "fs_dist_cg", "fs_dist_is_conservative", "fs_dist_csr_create_from_shards", "fs_dist_matrix_build_transpose_device",
-    "fs_dist_matrix_bounds_t", "fs_dist_matrix_nnz", "fs_dist_matrix_shard",
+    "fs_dist_matrix_bounds_t", "fs_dist_matrix_nnz", "fs_dist_matrix_shard", "fs_dist_spmm", "fs_dist_spmm_t", "fs_dist_cg2",
 ]
 REFERENCE_API = [
     # sparse.h
@@ -162,6 +162,9 @@ def lib():
     L.fs_dist_matrix_shard.argtypes = [vp, C.c_int, C.c_int]
     L.fs_dist_matrix_shard.restype = vp
     L.fs_dist_cg.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    L.fs_dist_cg2.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    L.fs_dist_spmm.argtypes = [vp, vp, vp, C.c_int]
+    L.fs_dist_spmm_t.argtypes = [vp, vp, vp, C.c_int]
     for f in ("fs_dist_spmv_resident", "fs_dist_spmv_t_resident", "fs_dist_swap_xy"):
         getattr(L, f).argtypes = [vp]
     for f in ("fs_dist_x", "fs_dist_y", "fs_dist_z"):

@@ -419,6 +419,51 @@ int cg_dev_final(int mode, const double *partials, int count, double *red_out, d
   return FS_OK;
 }
 
+// ---- the same for two right-hand sides (fs_cg2, fs_dist_cg2).  cg2_dev_init is synchronous (two reductions go to the host: the
+// norms of B's columns scale the system, cg.h:105-125); norms[2] is returned for the final cg2_dev_finish
+int cg2_dev_init(int n, const double *B, double *X, double *R, double *P, double *part, double *red, double *st, double tol,
+                 double *norms, hipStream_t s)
+{
+  const dim3 g(kRedBlocks), blk(kRedThreads);
+  double h[3], RtR[3];
+  hipLaunchKernelGGL(cg2_dot_kernel, g, blk, 0, s, n, B, B, part);
+  hipLaunchKernelGGL(final_sum_kernel<3>, dim3(1), blk, 0, s, part, kRedBlocks, red);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  norms[0] = sqrt(h[0]); norms[1] = sqrt(h[1]);
+  hipLaunchKernelGGL(cg2_init_kernel, g, blk, 0, s, n, 1.0 / norms[0], 1.0 / norms[1], B, X, R, P, part);
+  hipLaunchKernelGGL(final_sum_kernel<3>, dim3(1), blk, 0, s, part, kRedBlocks, red);
+  FS_HIP(hipGetLastError());
+  FS_HIP(hipMemcpyAsync(RtR, red, sizeof(RtR), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  double st0[kStDoubles] = {0.0};
+  st0[kSt2RtR] = RtR[0]; st0[kSt2RtR + 1] = RtR[1]; st0[kSt2RtR + 2] = RtR[2]; st0[kSt2Tolsq] = tol * tol;
+  FS_HIP(hipMemcpyAsync(st, st0, sizeof(st0), hipMemcpyHostToDevice, s));
+  FS_HIP(hipStreamSynchronize(s));            // (st0 is on this stack frame)
+  return FS_OK;
+}
+
+// everything of a block-CG iteration behind Q = A'(A P): Q += lambda P, Alpha, X and R, the convergence test and Psi, the new P
+int cg2_dev_steps(int n, double lambda, double *X, double *R, double *P, double *Q, double *part, double *red, double *st, hipStream_t s)
+{
+  const dim3 g(kRedBlocks), blk(kRedThreads), one(1);
+  hipLaunchKernelGGL(cg2_shift_dot_dev_kernel, g, blk, 0, s, n, lambda, Q, P, part, st);
+  hipLaunchKernelGGL((final_step_kernel<3, 3>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // Alpha
+  hipLaunchKernelGGL(cg2_update_dev_kernel, g, blk, 0, s, n, X, R, P, Q, part, st);
+  hipLaunchKernelGGL((final_step_kernel<3, 4>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // converged? Psi
+  hipLaunchKernelGGL(cg2_direction_dev_kernel, g, blk, 0, s, n, P, R, st);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int cg2_dev_finish(int n, const double *norms, double *X, hipStream_t s)                          // X back in B's scale (cg.h:175-181)
+{
+  hipLaunchKernelGGL(cg2_scale_kernel, dim3(kRedBlocks), dim3(kRedThreads), 0, s, n, norms[0], norms[1], X);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int CgFlags::init()
 {
   FS_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4));
@@ -449,17 +494,6 @@ int CgFlags::after_iteration(int iter, const double *st, hipStream_t s, bool *st
 }  // namespace fs
 
 using namespace fs;
-
-// fetch NV reduced values: partials -> one workgroup -> host
-template <int NV>
-static int reduce_to_host(const double *part, double *red_dev, double *host, hipStream_t s)
-{
-  hipLaunchKernelGGL(final_sum_kernel<NV>, dim3(1), dim3(kRedThreads), 0, s, part, kRedBlocks, red_dev);
-  FS_HIP(hipGetLastError());
-  FS_HIP(hipMemcpyAsync(host, red_dev, sizeof(double) * NV, hipMemcpyDeviceToHost, s));
-  FS_HIP(hipStreamSynchronize(s));
-  return FS_OK;
-}
 
 extern "C" {
 
@@ -524,40 +558,22 @@ int fs_cg2(fs_matrix_t A, fs_matrix_t At, double *X, const double *B, double lam
   double *R = ws.get(2 * (size_t)F), *P = ws.get(2 * (size_t)F), *Q = ws.get(2 * (size_t)F), *tmp = ws.get(2 * (size_t)N);
   double *part = ws.get(kRedBlocks * 3), *red = ws.get(4);
   if (!R || !P || !Q || !tmp || !part || !red) { set_error("fs_cg2: out of device memory"); return FS_ERR_HIP; }
-  const dim3 g(kRedBlocks), blk(kRedThreads);
-  const double tolsq = tol * tol;
-  double h[3], norms[2];
-  hipLaunchKernelGGL(cg2_dot_kernel, g, blk, 0, s, F, B, B, part);
-  if (int rc = reduce_to_host<3>(part, red, h, s)) return rc;
-  norms[0] = sqrt(h[0]); norms[1] = sqrt(h[1]);
-  hipLaunchKernelGGL(cg2_init_kernel, g, blk, 0, s, F, 1.0 / norms[0], 1.0 / norms[1], B, X, R, P, part);
-  double RtR[3];
-  if (int rc = reduce_to_host<3>(part, red, RtR, s)) return rc;
-  // from here on the scalars live on the device (see the head of this file)
+  // the scalars live on the device from the first iteration on (see the head of this file)
   double *st = ws.get(kStDoubles);
   CgFlags fl;
   if (!st) { set_error("fs_cg2: out of device memory"); return FS_ERR_HIP; }
   if (int rc = fl.init()) return rc;
-  double st0[kStDoubles] = {0.0};
-  st0[kSt2RtR] = RtR[0]; st0[kSt2RtR + 1] = RtR[1]; st0[kSt2RtR + 2] = RtR[2]; st0[kSt2Tolsq] = tolsq;
-  FS_HIP(hipMemcpyAsync(st, st0, sizeof(st0), hipMemcpyHostToDevice, s));
-  FS_HIP(hipStreamSynchronize(s));            // (st0 is on this stack frame)
-  const dim3 one(1);
+  double norms[2];
+  if (int rc = cg2_dev_init(F, B, X, R, P, part, red, st, tol, norms, s)) return rc;
   for (int iter = 0; iter < F; iter++) {
     if (int rc = fs_spmm(A, tmp, P, 2, stream)) return rc;
     if (int rc = fs_spmm(At, Q, tmp, 2, stream)) return rc;
-    hipLaunchKernelGGL(cg2_shift_dot_dev_kernel, g, blk, 0, s, F, lambda, Q, P, part, st);
-    hipLaunchKernelGGL((final_step_kernel<3, 3>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // Alpha
-    hipLaunchKernelGGL(cg2_update_dev_kernel, g, blk, 0, s, F, X, R, P, Q, part, st);
-    hipLaunchKernelGGL((final_step_kernel<3, 4>), one, blk, 0, s, part, kRedBlocks, red, st, 0.0);   // converged? Psi
-    hipLaunchKernelGGL(cg2_direction_dev_kernel, g, blk, 0, s, F, P, R, st);
-    FS_HIP(hipGetLastError());
+    if (int rc = cg2_dev_steps(F, lambda, X, R, P, Q, part, red, st, s)) return rc;
     bool stop = false;
     if (int rc = fl.after_iteration(iter, st, s, &stop)) return rc;
     if (stop) break;
   }
-  hipLaunchKernelGGL(cg2_scale_kernel, g, blk, 0, s, F, norms[0], norms[1], X);
-  FS_HIP(hipGetLastError());
+  if (int rc = cg2_dev_finish(F, norms, X, s)) return rc;
   double fin[2] = {0.0, 0.0};
   FS_HIP(hipMemcpyAsync(fin, st + kStDone, sizeof(fin), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));

@@ -337,6 +337,11 @@ int cg_dev_init(int n, const double *b, double *x, double *r, double *p, double 
                 hipStream_t s);                                                // x = 0, r = p = b; b.b, the stopping threshold
 int cg_dev_steps(int n, double lambda, double *x, double *r, double *p, double *q, double *part, double *red, double *st,
                  hipStream_t s);                                               // everything of an iteration behind q = A'(A p)
+// two right-hand sides, row-major n x 2 (bsbm_cg2, cg.h:85-187): init is synchronous and returns the column norms of B for finish
+int cg2_dev_init(int n, const double *B, double *X, double *R, double *P, double *part, double *red, double *st, double tol,
+                 double *norms, hipStream_t s);
+int cg2_dev_steps(int n, double lambda, double *X, double *R, double *P, double *Q, double *part, double *red, double *st, hipStream_t s);
+int cg2_dev_finish(int n, const double *norms, double *X, hipStream_t s);
 // the same steps for a SLICE of the unknowns (fs_dist_cg, scheme "gather"): every step leaves this rank's partial dot in
 // *red_out; the partials of all ranks, gathered, go through cg_dev_final, which adds them in rank order and does the scalar step
 // `mode` of final_step_kernel (0 b.b and the threshold, 1 alpha, 2 convergence and beta)

@@ -148,6 +148,17 @@ struct CgWork {                       // vectors of fs_dist_cg, kept on the hand
   std::vector<double *> sol, r, b, p, q, part, red, redall, st;
 };
 
+// k row-major columns on the sharded matrix (fs_dist_spmm, fs_dist_cg2): the replicated X / Y / Z, the shards' local outputs, the
+// padded receive buffer, the unpack tables (offsets and counts times k) and the work vectors of the block solver, per rank
+struct KWork {
+  int k = 0;
+  bool with_t = false;
+  std::vector<double *> x, y, z, la, lt, pad;
+  std::vector<int64_t *> tab;           // [A side: dst, src, cnt][A' side: dst, src, cnt]
+  int nseg_a = 0, nseg_t = 0;
+  std::vector<double *> sol, r, b, part, red, st;
+};
+
 struct fs_dist_matrix_s {
   fs_dist_t D = nullptr;
   int nrow = 0, ncol = 0;
@@ -159,6 +170,7 @@ struct fs_dist_matrix_s {
   double *pin = nullptr;              // pinned staging of host vectors
   size_t pin_doubles = 0;
   CgWork cg;
+  KWork kw;
   std::mutex lock;                    // products on one matrix are serialised (x, y, z and the part buffers are per matrix)
 };
 
@@ -184,6 +196,17 @@ void free_cg(fs_dist_t D, CgWork &W)
       if (p) (void)hipFree(p);
   }
   W = CgWork();
+}
+
+void free_k(fs_dist_t D, KWork &W)
+{
+  for (size_t d = 0; d < W.x.size(); ++d) {
+    (void)hipSetDevice(D->dev[d]);
+    for (void *p : {(void *)W.x[d], (void *)W.y[d], (void *)W.z[d], (void *)W.la[d], (void *)W.lt[d], (void *)W.pad[d], (void *)W.tab[d], (void *)W.sol[d],
+                    (void *)W.r[d], (void *)W.b[d], (void *)W.part[d], (void *)W.red[d], (void *)W.st[d]})
+      if (p) (void)hipFree(p);
+  }
+  W = KWork();
 }
 
 // row cuts with (almost) equal numbers of non-zeros: bounds[r] = first row whose row_ptr is >= r/n of nnz -- the cut
@@ -549,6 +572,98 @@ int finish_transpose(fs_dist_matrix_t M)
   return rc;
 }
 
+// buffers, tables and prepared shards for products with k row-major columns (k >= 2); idempotent per (k, transposed side built)
+int ensure_k(fs_dist_matrix_t M, int k)
+{
+  fs_dist_t D = M->D;
+  const int n = D->n;
+  KWork &W = M->kw;
+  const bool with_t = M->t.built;
+  if (W.k == k && W.with_t == with_t && !W.x.empty()) return FS_OK;
+  if (int rc = dist_sync(D)) return rc;
+  free_k(D, W);
+  W.k = k; W.with_t = with_t;
+  for (auto *v : {&W.x, &W.y, &W.z, &W.la, &W.lt, &W.pad, &W.sol, &W.r, &W.b, &W.part, &W.red, &W.st}) v->assign((size_t)n, nullptr);
+  W.tab.assign((size_t)n, nullptr);
+  const int64_t mr = std::max<int64_t>(M->a.max_rows, with_t ? M->t.max_rows : 0);
+  std::vector<int64_t> tab;
+  auto side_table = [&](const DistSide &S, int *nseg) {
+    std::vector<int64_t> dst, src, cnt;
+    for (int r = 0; r < n; ++r) {
+      const int64_t c = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+      if (!c) continue;
+      dst.push_back((int64_t)S.bounds[(size_t)r] * k);
+      src.push_back((int64_t)r * S.max_rows * k);
+      cnt.push_back(c * k);
+    }
+    *nseg = (int)cnt.size();
+    tab.insert(tab.end(), dst.begin(), dst.end());
+    tab.insert(tab.end(), src.begin(), src.end());
+    tab.insert(tab.end(), cnt.begin(), cnt.end());
+  };
+  side_table(M->a, &W.nseg_a);
+  if (with_t) side_table(M->t, &W.nseg_t);
+  const size_t F = (size_t)(M->ncol ? M->ncol : 1) * k, N = (size_t)(M->nrow ? M->nrow : 1) * k;
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    FS_HIP(hipMalloc(&W.x[(size_t)r], sizeof(double) * F));
+    FS_HIP(hipMalloc(&W.y[(size_t)r], sizeof(double) * N));
+    FS_HIP(hipMalloc(&W.z[(size_t)r], sizeof(double) * F));
+    FS_HIP(hipMalloc(&W.la[(size_t)r], sizeof(double) * (size_t)(M->a.max_rows + 1) * k));
+    FS_HIP(hipMalloc(&W.lt[(size_t)r], sizeof(double) * (size_t)((with_t ? M->t.max_rows : 0) + 1) * k));
+    FS_HIP(hipMalloc(&W.pad[(size_t)r], sizeof(double) * (size_t)(n * mr + 1) * k));
+    FS_HIP(hipMalloc(&W.tab[(size_t)r], sizeof(int64_t) * (tab.size() + 1)));
+    if (!tab.empty()) FS_HIP(hipMemcpy(W.tab[(size_t)r], tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice));
+    FS_HIP(hipMalloc(&W.sol[(size_t)r], sizeof(double) * F));
+    FS_HIP(hipMalloc(&W.r[(size_t)r], sizeof(double) * F));
+    FS_HIP(hipMalloc(&W.b[(size_t)r], sizeof(double) * F));
+    FS_HIP(hipMalloc(&W.part[(size_t)r], sizeof(double) * fs::kCgPartDoubles));
+    FS_HIP(hipMalloc(&W.red[(size_t)r], sizeof(double) * 4));
+    FS_HIP(hipMalloc(&W.st[(size_t)r], sizeof(double) * fs::kCgStateDoubles));
+    // the k-column copies of the shards (fs_spmm itself never builds)
+    if (M->a.shard[(size_t)r])
+      if (int rc = fs_matrix_prepare(M->a.shard[(size_t)r], k, 0, D->stream[r])) return rc;
+    if (with_t && M->t.shard[(size_t)r])
+      if (int rc = fs_matrix_prepare(M->t.shard[(size_t)r], k, 0, D->stream[r])) return rc;
+  }
+  return FS_OK;
+}
+
+// out = M in for k row-major columns on every rank: the local product, then ONE whole-shard all-gather (the conservative form of
+// the exchange; the k-column product in parts, fs_spmm_part, is what the overlapped form would ride on)
+int dist_product_k(fs_dist_matrix_t M, bool transposed, const std::vector<double *> &in, const std::vector<double *> &out)
+{
+  fs_dist_t D = M->D;
+  const int n = D->n;
+  KWork &W = M->kw;
+  DistSide &S = transposed ? M->t : M->a;
+  const int k = W.k;
+  const std::vector<double *> &loc = transposed ? W.lt : W.la;
+  std::vector<const double *> send((size_t)n);
+  std::vector<hipEvent_t> ready((size_t)n);
+  for (int r = 0; r < n; ++r) {
+    const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+    FS_HIP(hipSetDevice(D->dev[r]));
+    if (nl > 0)
+      if (int rc = fs_spmm(S.shard[(size_t)r], loc[(size_t)r], in[(size_t)r], k, D->stream[r])) return rc;
+    FS_HIP(hipEventRecord(S.ev[(size_t)r][0], D->stream[r]));
+    FS_HIP(hipStreamWaitEvent(D->comm_stream[r], S.ev[(size_t)r][0], 0));
+    send[(size_t)r] = loc[(size_t)r];
+    ready[(size_t)r] = S.ev[(size_t)r][0];
+  }
+  // (the send window is max_rows * k doubles from the start of the local output; the buffer has that room)
+  if (int rc = exchange_equal(D, send, W.pad, (size_t)S.max_rows * (size_t)k, D->comm_stream, ready)) return rc;
+  const int nseg = transposed ? W.nseg_t : W.nseg_a;
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    const int64_t *tab = W.tab[(size_t)r] + (transposed ? 3 * (size_t)W.nseg_a : 0);
+    if (int rc = fs_copy_segments(nseg, tab, (int64_t)S.max_rows * k, W.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])) return rc;
+    FS_HIP(hipEventRecord(S.done[(size_t)r], D->comm_stream[r]));
+    FS_HIP(hipStreamWaitEvent(D->stream[r], S.done[(size_t)r], 0));
+  }
+  return FS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -621,6 +736,7 @@ void fs_dist_matrix_destroy(fs_dist_matrix_t M)
   free_side(M->D, M->a);
   free_side(M->D, M->t);
   free_cg(M->D, M->cg);
+  free_k(M->D, M->kw);
   for (size_t r = 0; r < (size_t)M->D->n; ++r) {
     (void)hipSetDevice(M->D->dev[r]);
     if (r < M->x.size() && M->x[r]) (void)hipFree(M->x[r]);
@@ -1106,6 +1222,109 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
         if (int rc = download_from(M, d, x_host + lo, W.sol[(size_t)d], (size_t)nl)) return rc;
     }
   }
+  if (int rc = dist_sync(D)) return rc;
+  if (out_iter) *out_iter = (int)fin[1];
+  return FS_OK;
+}
+
+// Y[nrow, k] = A X[ncol, k], row-major host matrices (csr_A_mul_Bn / bcsr_A_mul_Bn / bsbm_A_mul_Bn across the GPUs, csr.h:441,
+// 257; sparse.h:318): every device multiplies its shard (the k-column kernels of fs_spmm, prepared on first use of a k) and the
+// Y shards are all-gathered, one whole-shard exchange behind the local product.  fs_dist_spmm_t: Z[ncol, k] = A' U[nrow, k].
+int fs_dist_spmm(fs_dist_matrix_t M, double *Y_host, const double *X_host, int k)
+{
+  if (!M || !Y_host || !X_host || k < 1) { fs::set_error("fs_dist_spmm: bad argument"); return FS_ERR_ARG; }
+  if (k == 1) return fs_dist_spmv(M, Y_host, X_host);
+  std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
+  DeviceGuard guard;
+  if (int rc = ensure_k(M, k)) return rc;
+  if (int rc = upload_all(M, M->kw.x, X_host, (size_t)M->ncol * k)) return rc;
+  if (int rc = dist_product_k(M, false, M->kw.x, M->kw.y)) return rc;
+  if (int rc = download_from(M, 0, Y_host, M->kw.y[0], (size_t)M->nrow * k)) return rc;
+  return dist_sync(M->D);
+}
+
+int fs_dist_spmm_t(fs_dist_matrix_t M, double *Z_host, const double *U_host, int k)
+{
+  if (!M || !Z_host || !U_host || k < 1) { fs::set_error("fs_dist_spmm_t: bad argument"); return FS_ERR_ARG; }
+  if (!M->t.built) { fs::set_error("fs_dist_spmm_t: build the transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  if (k == 1) return fs_dist_spmv_t(M, Z_host, U_host);
+  std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
+  DeviceGuard guard;
+  if (int rc = ensure_k(M, k)) return rc;
+  if (int rc = upload_all(M, M->kw.y, U_host, (size_t)M->nrow * k)) return rc;
+  if (int rc = dist_product_k(M, true, M->kw.y, M->kw.z)) return rc;
+  if (int rc = download_from(M, 0, Z_host, M->kw.z[0], (size_t)M->ncol * k)) return rc;
+  return dist_sync(M->D);
+}
+
+// (A'A + lambda I) X = B for two right-hand sides, row-major ncol x 2: bsbm_cg2 (cg.h:85-187) across the GPUs, everything
+// resident.  Every device keeps whole X, R, P, Q and runs the same block-CG steps on them (identical inputs, identical kernels:
+// the 2x2 algebra needs no exchange); per iteration TMP = A P and Q = A' TMP as two-column products with their all-gathers.
+// Convergence is decided on every device and compared on the host like fs_dist_cg.  Products add in a fixed order unless
+// option "cg_fixed_order" is 0.
+int fs_dist_cg2(fs_dist_matrix_t M, double *X_host, const double *B_host, double lambda, double tol, int *out_iter)
+{
+  if (!M || !X_host || !B_host) { fs::set_error("fs_dist_cg2: NULL argument"); return FS_ERR_ARG; }
+  if (!M->t.built) { fs::set_error("fs_dist_cg2: build the transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  std::lock_guard<std::mutex> g(M->lock);
+  std::lock_guard<std::mutex> gd(M->D->lock);
+  DeviceGuard guard;
+  fs::FixedOrderScope fixed(fs::options().cg_fixed_order != 0);
+  fs_dist_t D = M->D;
+  const int n = D->n, F = M->ncol;
+  if (int rc = ensure_k(M, 2)) return rc;
+  KWork &W = M->kw;
+  if (int rc = upload_all(M, W.b, B_host, (size_t)F * 2)) return rc;
+  std::vector<fs::CgFlags> fl((size_t)n);
+  std::vector<double> norms(2 * (size_t)n, 0.0);
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    if (int rc = fl[(size_t)d].init()) return rc;
+    if (int rc = fs::cg2_dev_init(F, W.b[(size_t)d], W.sol[(size_t)d], W.r[(size_t)d], W.x[(size_t)d], W.part[(size_t)d], W.red[(size_t)d],
+                                  W.st[(size_t)d], tol, &norms[2 * (size_t)d], D->stream[d])) return rc;
+    if (norms[2 * (size_t)d] != norms[0] || norms[2 * (size_t)d + 1] != norms[1]) {
+      fs::set_error("fs_dist_cg2: the devices disagree about the norms of the right-hand sides");
+      return FS_ERR_HIP;
+    }
+  }
+  int rc_loop = FS_OK;
+  for (int iter = 0; iter < F; iter++) {
+    if (int rc = dist_product_k(M, false, W.x, W.y)) return rc;          // TMP = A P
+    if (int rc = dist_product_k(M, true, W.y, W.z)) return rc;           // Q = A' TMP
+    int stops = 0;
+    for (int d = 0; d < n; ++d) {
+      FS_HIP(hipSetDevice(D->dev[d]));
+      if (int rc = fs::cg2_dev_steps(F, lambda, W.sol[(size_t)d], W.r[(size_t)d], W.x[(size_t)d], W.z[(size_t)d], W.part[(size_t)d],
+                                     W.red[(size_t)d], W.st[(size_t)d], D->stream[d])) return rc;
+      bool stop = false;
+      if (int rc = fl[(size_t)d].after_iteration(iter, W.st[(size_t)d], D->stream[d], &stop)) return rc;
+      stops += stop ? 1 : 0;
+    }
+    if (stops != 0 && stops != n) {
+      fs::set_error("fs_dist_cg2: the devices disagree about convergence (a device or an exchange returned different bits)");
+      rc_loop = FS_ERR_HIP;
+      break;
+    }
+    if (stops == n) break;
+  }
+  for (int d = 0; d < n && rc_loop == FS_OK; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    if (int rc = fs::cg2_dev_finish(F, &norms[2 * (size_t)d], W.sol[(size_t)d], D->stream[d])) return rc;
+  }
+  if (int rc = dist_sync(D)) return rc;
+  if (rc_loop != FS_OK) return rc_loop;
+  std::vector<double> fin(2 * (size_t)n, 0.0);
+  for (int d = 0; d < n; ++d) {
+    FS_HIP(hipSetDevice(D->dev[d]));
+    FS_HIP(hipMemcpy(&fin[2 * (size_t)d], W.st[(size_t)d] + fs::kCgStateDone, sizeof(double) * 2, hipMemcpyDeviceToHost));
+    if (fin[2 * (size_t)d] != fin[0] || fin[2 * (size_t)d + 1] != fin[1]) {
+      fs::set_error("fs_dist_cg2: the devices finished in different states");
+      return FS_ERR_HIP;
+    }
+  }
+  if (int rc = download_from(M, 0, X_host, W.sol[0], (size_t)F * 2)) return rc;
   if (int rc = dist_sync(D)) return rc;
   if (out_iter) *out_iter = (int)fin[1];
   return FS_OK;

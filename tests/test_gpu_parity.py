@@ -2462,3 +2462,65 @@ def test_the_references_own_bench_harness_runs_on_the_product_library(hip, tmp_p
         for flags in ([], ["-t"]):
             p = subprocess.run([exe, "-f", "data/sbm-100-50.data"] + flags, cwd=cwd, capture_output=True, text=True, timeout=600)
             assert p.returncode == 0 and "[par B'B x]" in p.stdout, (flags, (p.stdout + p.stderr)[-2000:])
+
+
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_native_multi_gpu_k_column_products_and_block_cg(hip, ranks):
+    """the native multi-GPU path with k row-major columns: fs_dist_spmm / fs_dist_spmm_t (csr_A_mul_Bn, bsbm_A_mul_Bn across the
+    ranks) against the oracle -- pattern-only with integer X bit for bit, valued within the row-scaled bar -- and fs_dist_cg2
+    (bsbm_cg2, cg.h:85-187, across the ranks) against the oracle's block solver: iteration count within one on a well-conditioned
+    system, true residuals of both columns within 2 tol, two solves bit-identical (fixed-order products are the solvers' default)."""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    from oracle import pysynth
+    L = capi.lib()
+    nrow, ncol = 120_000, 80_000
+    rp, cc, vv = pysynth.powerlaw(nrow, ncol, 2.3, 8_000, 0xB10C)
+    rows_all = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+    D = L.fs_dist_create(ranks, (C.c_int * ranks)(*([0] * ranks)))
+    assert D
+    capi.set_option("binning", 2)
+    try:
+        for vals in (None, vv):
+            M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None if vals is None else vals.ctypes.data)
+            assert M, L.fs_last_error()
+            assert L.fs_dist_matrix_build_transpose_device(M) == 0, L.fs_last_error()
+            for k in (2, 3):
+                X = np.ascontiguousarray(np.stack([S.x_int(20 + j, ncol) for j in range(k)], 1)) if vals is None else S.X_sin(ncol, k)
+                Y = np.full((nrow, k), -1.0)
+                assert L.fs_dist_spmm(M, Y.ctypes.data, X.ctypes.data, k) == 0, L.fs_last_error()
+                ref = O.csr_mul_n(nrow, rp, cc, vals, X, k)
+                U = np.ascontiguousarray(np.stack([S.x_int(30 + j, nrow) for j in range(k)], 1)) if vals is None else \
+                    np.ascontiguousarray(np.stack([np.sin(11.0 * np.arange(nrow) - 0.2 + j) for j in range(k)], 1))
+                Z = np.full((ncol, k), -1.0)
+                assert L.fs_dist_spmm_t(M, Z.ctypes.data, U.ctypes.data, k) == 0, L.fs_last_error()
+                for j in range(k):
+                    zref = O.coo_tmul(ncol, rows_all, cc, vals, np.ascontiguousarray(U[:, j]))
+                    if vals is None:
+                        assert np.array_equal(Y[:, j], ref[:, j]) and np.array_equal(Z[:, j], zref), (k, j)
+                    else:
+                        sy = np.maximum(O.csr_abs_scale(nrow, rp, cc, vals, np.ascontiguousarray(X[:, j])), 1e-300)
+                        sz = np.maximum(O.coo_tmul(ncol, rows_all, cc, np.abs(vals), np.abs(np.ascontiguousarray(U[:, j]))), 1e-300)
+                        assert np.all(np.abs(Y[:, j] - ref[:, j]) <= TOL * sy) and np.all(np.abs(Z[:, j] - zref) <= TOL * sz), (k, j)
+            if vals is None:            # the reference's CG consumers run on pattern matrices (BlockedSBM)
+                B = np.ascontiguousarray(np.stack([np.sin(0.37 * np.arange(ncol) + 1.0), np.cos(0.23 * np.arange(ncol) + 0.7)], 1))
+                lam, tol = 5000.0, 1e-9          # well-conditioned: the count must agree within one (a 55-iteration solve at lambda =
+                Xref, itref = O.cg_normal(nrow, ncol, rows_all, cc, B, lam, tol, two=True)   # 300 moved by 3 with the shard cuts)
+                sols = []
+                for _ in range(2):
+                    Xs = np.full((ncol, 2), -1.0)
+                    it = C.c_int(-1)
+                    assert L.fs_dist_cg2(M, Xs.ctypes.data, B.ctypes.data, lam, tol, C.byref(it)) == 0, L.fs_last_error()
+                    sols.append((Xs, it.value))
+                res = [_normal_residual(nrow, ncol, rp, cc, rows_all, lam, np.ascontiguousarray(sols[0][0][:, j]), np.ascontiguousarray(B[:, j]))
+                       for j in range(2)]
+                rep = dict(ranks=ranks, iterations=[s_[1] for s_ in sols], oracle_iterations=itref, residuals=res,
+                           errinf=float(np.max(np.abs(sols[0][0] - Xref))), xmax=float(np.abs(Xref).max()))
+                print("fs_dist_cg2:", rep)
+                assert sols[0][1] == sols[1][1] and np.array_equal(sols[0][0], sols[1][0]), rep
+                assert abs(sols[0][1] - itref) <= 1 and max(res) <= 2 * tol, rep
+                assert rep["errinf"] <= 1e-6 * max(1e-300, rep["xmax"]), rep
+            L.fs_dist_matrix_destroy(M)
+    finally:
+        capi.set_option("binning", 1)
+        L.fs_dist_destroy(D)
