@@ -2365,6 +2365,20 @@ def test_lds_staged_kernel_fixed_order_sums(hip, valued):
         assert all(np.array_equal(ys[0], v_) for v_ in ys[1:]), "A x differs between runs under fixed-order sums"
         assert all(np.array_equal(zs[0], v_) for v_ in zs[1:]), "A' u differs between runs under fixed-order sums"
         assert np.all(np.abs(ys[0] - ref) <= TOL * sc) and np.all(np.abs(zs[0] - reft) <= TOL * sct)
+        # ... and across BUILDS: a second handle made from the same arrays arranges its work items the same way (the format
+        # builder is deterministic), so its fixed-order sums are the first handle's, bit for bit -- what "the same result in every
+        # run of the program" needs
+        capi.set_option("ldsx", 2)
+        try:
+            A2 = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv, borrow=True)
+            A2.build_transpose(st)
+        finally:
+            capi.set_option("ldsx", 1)
+        y.fill_(-1.0); z.fill_(-1.0)
+        A2.spmv(y, xd, st)
+        A2.spmv(z, ud, st, transposed=True)
+        assert np.array_equal(y.cpu().numpy(), ys[0]) and np.array_equal(z.cpu().numpy(), zs[0]), "a second build adds in another order"
+        del A2
         # the form without LDS DMA (x not 16-byte aligned): every phase ends in a full barrier, the same guarantee
         yo = []
         for _ in range(2):
