@@ -1358,6 +1358,11 @@ def test_longest_rows_outside_the_two_pass_copy(hip, valued, geometry):
                         runs.append(y.cpu().numpy().copy())
                     assert all(np.array_equal(runs[0], r_) for r_ in runs[1:]), "fixed-order long rows differ between runs"
                     assert np.all(np.abs(runs[0] - ref_s) <= TOL * np.maximum(sc_s, 1e-300))
+                    A2 = capi.Matrix.from_csr(nrow, ncol, rp, cc, vv)          # a second build: the same order of additions
+                    y.fill_(-1.0)
+                    A2.spmv(y, xsd, st)
+                    assert np.array_equal(y.cpu().numpy(), runs[0]), "a second build of the long-row copy adds in another order"
+                    del A2
                 finally:
                     capi.set_option("reproducible", 0)
                 y.fill_(-1.0)
