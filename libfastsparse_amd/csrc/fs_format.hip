@@ -887,11 +887,15 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
   __shared__ unsigned short size[32 * 32];     // entries of (class, bank)
   __shared__ unsigned short off[32 * 32];      // first entry of (class, bank) in lst
   __shared__ int owner[32];
-  // the repair: per class (entries of class c are indices off[c * 32] .. of these arrays, in round order)
-  __shared__ unsigned short cplace[kTiledItem];   // place in the sequence
-  __shared__ unsigned short crow[kTiledItem];     // local row
-  __shared__ unsigned short lead[kTiledItem];     // first index of the class with the same row
-  __shared__ unsigned char flag[kTiledItem];      // bit 0: a leader whose row has further entries; bit 1: placed for good
+  // the repair: per class (entries of class c are indices off[c * 32] .. of these arrays, in round order).  They live in the
+  // storage of segcnt, which is dead once lst is filled (with 14 KiB more LDS only two workgroups fit a CU instead of four, and
+  // the kernel took twice as long: 219 -> 458 ms on config 3)
+  static_assert(kReorderSegs * 32 * 32 >= 3 * kTiledItem + kTiledItem / 2, "the repair arrays are carved out of segcnt");
+  unsigned short *const cplace = &segcnt[0][0];                   // place in the sequence
+  unsigned short *const crow = &segcnt[0][0] + kTiledItem;        // local row
+  unsigned short *const lead = &segcnt[0][0] + 2 * kTiledItem;    // first index of the class with the same row
+  unsigned char *const flag = reinterpret_cast<unsigned char *>(&segcnt[0][0] + 3 * kTiledItem);   // bit 0: a leader whose row has
+                                                                  // further entries; bit 1: placed for good
   __shared__ unsigned short unres[kRepairMaxLeft]; // leaders of the rows the per-class pass could not bring together
   __shared__ unsigned short pmem[kRepairMaxBig];  // the entries of one such row
   __shared__ int nunres, ndup, wcount[32];
