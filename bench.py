@@ -721,6 +721,39 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         e[2].record()
         prov.synchronize()
         split = {"A_mul_B_ms": prov.elapsed_ms(e[0], e[1]) / 5, "At_mul_B_ms": prov.elapsed_ms(e[1], e[2]) / 5}
+        # SURVEY 8(d)'s timing protocol: every launch with its own event pair, min / median / mean of 20
+        per_launch = {}
+        for name, tr, yy, xx in (("A_mul_B", False, y, x), ("At_mul_B", True, z, u)):
+            pairs = [(prov.event(), prov.event()) for _ in range(20)]
+            for a, b in pairs:
+                a.record()
+                prov.spmv(A, yy, xx, transposed=tr)
+                b.record()
+            prov.synchronize()
+            ts = sorted(prov.elapsed_ms(a, b) for a, b in pairs)
+            per_launch[name] = {"min": ts[0], "median": 0.5 * (ts[9] + ts[10]), "mean": sum(ts) / len(ts), "max": ts[-1], "launches": 20}
+        split["per_launch_ms"] = per_launch
+        # the drop-in call as a reference caller makes it (csr_A_mul_B with malloc'ed vectors, csr.h:425): x goes up and y comes
+        # down over PCIe inside the call, overlapped with the kernels part by part.  Never `value`: the PCIe-inclusive rate.
+        if hasattr(A, "spmv_host"):
+            try:
+                import numpy as np
+                xh = x.cpu().numpy()
+                yh = np.empty(n_local, dtype=np.float64)
+                A.spmv_host(yh, xh)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    A.spmv_host(yh, xh)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ts.sort()
+                split["host_pointer_call"] = {
+                    "csr_A_mul_B_ms": ts[1], "effective_GBs_incl_pcie": bytes_a / (ts[1] * 1e-3) / 1e9,
+                    "max_abs_diff_vs_device_resident": float((torch.from_numpy(yh).to(dev) - y).abs().max()),
+                    "what": "median wall time of 3 calls with pageable host vectors (80 MB up, 80 MB down per call)"}
+                del xh, yh
+            except Exception as ex:
+                split["host_pointer_call"] = {"error": repr(ex)}
     else:
         split = {"A_mul_B_ms": sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs),
                  "At_mul_B_ms": sum(prov.elapsed_ms(e[2], e[3]) for e in evs) / len(evs)}
@@ -794,6 +827,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
                    "stream_read_GBs_measured": stream_gbs,
                    "pct_of_measured_stream_read": 100.0 * achieved / stream_gbs if stream_gbs else None,
                    "A_mul_B_ms": split["A_mul_B_ms"], "At_mul_B_ms": split["At_mul_B_ms"],
+                   "per_launch_ms": split.get("per_launch_ms"), "host_pointer_call": split.get("host_pointer_call"),
                    "self_check": self_check,
                    "kernel_A": kname, "kernel_At": kname_t,
                    "builder_timed_ms_A": prov.candidate_ms(A),
