@@ -145,6 +145,7 @@ struct DistSide {
 
 struct CgWork {                       // vectors of fs_dist_cg, kept on the handle between solves
   int F = 0;
+  bool ready = false;                 // every allocation below succeeded
   std::vector<double *> sol, r, b, p, q, part, red, redall, st;
 };
 
@@ -153,6 +154,7 @@ struct CgWork {                       // vectors of fs_dist_cg, kept on the hand
 struct KWork {
   int k = 0;
   bool with_t = false;
+  bool ready = false;                   // every allocation and prepare below succeeded
   std::vector<double *> x, y, z, la, lt, pad;
   std::vector<int64_t *> tab;           // [A side: dst, src, cnt][A' side: dst, src, cnt]
   int nseg_a = 0, nseg_t = 0;
@@ -385,8 +387,6 @@ int dist_gather(fs_dist_t D, DistSide &S, const std::vector<double *> &src, cons
     ready[(size_t)r] = S.ev[(size_t)r][0];
   }
   if (int rc = exchange_equal(D, send, S.pad, (size_t)S.max_rows, D->comm_stream, ready)) return rc;
-  const int64_t *skip = nullptr;
-  (void)skip;
   for (int r = 0; r < n; ++r) {
     FS_HIP(hipSetDevice(D->dev[r]));
     if (int rc = fs_copy_segments(S.nseg1, S.table[(size_t)r] + 3 * (size_t)S.nseg, S.max_rows, S.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])) return rc;
@@ -579,7 +579,7 @@ int ensure_k(fs_dist_matrix_t M, int k)
   const int n = D->n;
   KWork &W = M->kw;
   const bool with_t = M->t.built;
-  if (W.k == k && W.with_t == with_t && !W.x.empty()) return FS_OK;
+  if (W.ready && W.k == k && W.with_t == with_t) return FS_OK;
   if (int rc = dist_sync(D)) return rc;
   free_k(D, W);
   W.k = k; W.with_t = with_t;
@@ -626,6 +626,7 @@ int ensure_k(fs_dist_matrix_t M, int k)
     if (with_t && M->t.shard[(size_t)r])
       if (int rc = fs_matrix_prepare(M->t.shard[(size_t)r], k, 0, D->stream[r])) return rc;
   }
+  W.ready = true;      // (a failure above leaves ready = false: the next call frees what exists and starts over)
   return FS_OK;
 }
 
@@ -1091,7 +1092,7 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
   const bool gather = fs::options().dist_cg_scheme == 1 && n > 1;
   DistSide &T = M->t;
   CgWork &W = M->cg;
-  if (W.F != F || W.sol.empty()) {
+  if (!W.ready || W.F != F) {
     free_cg(D, W);
     for (auto *v : {&W.sol, &W.r, &W.b, &W.p, &W.q, &W.part, &W.red, &W.redall, &W.st}) v->assign((size_t)n, nullptr);
     W.F = F;
@@ -1108,6 +1109,7 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
       FS_HIP(hipMalloc(&W.redall[(size_t)d], sizeof(double) * (size_t)(n + 1)));
       FS_HIP(hipMalloc(&W.st[(size_t)d], sizeof(double) * fs::kCgStateDoubles));
     }
+    W.ready = true;
   }
   if (int rc = upload_all(M, W.b, b_host, (size_t)F)) return rc;
   // one set of host-visible flags per device
