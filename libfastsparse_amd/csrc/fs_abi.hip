@@ -403,6 +403,82 @@ int fs_debug_ldsx_orderable(fs_matrix_t A, int transposed)
   return a.tiledx->orderable ? 1 : 0;
 }
 
+// the two-pass copy of A (transposed != 0: of A'): device addresses of lcol, vals, gdst, lrow, prod, then n (padded entries), B, P
+// (tools/placement_probe.py: identical copies run at different speeds depending on where their arrays land)
+int fs_debug_two_pass_layout(fs_matrix_t A, int transposed, unsigned long long *out8)
+{
+  if (!A || !out8 || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.binned || !a.binned->built) { set_error("no two-pass copy"); return FS_ERR_ARG; }
+  const fs::BinnedCsr &N = *a.binned;
+  out8[0] = (unsigned long long)(uintptr_t)N.lcol; out8[1] = (unsigned long long)(uintptr_t)N.vals;
+  out8[2] = (unsigned long long)(uintptr_t)N.gdst; out8[3] = (unsigned long long)(uintptr_t)N.lrow;
+  out8[4] = (unsigned long long)(uintptr_t)N.prod; out8[5] = (unsigned long long)N.n; out8[6] = (unsigned long long)N.B;
+  out8[7] = (unsigned long long)N.P;
+  return FS_OK;
+}
+
+// one pass of the two-pass pair alone (which = 1: pass 1, x -> the product stream; 2: pass 2, the product stream -> y)
+int fs_debug_two_pass_run(fs_matrix_t A, int transposed, int which, double *y, const double *x, fs_stream_t stream)
+{
+  if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.binned || !a.binned->built || a.binned->split || a.binned->lr) { set_error("no plain two-pass copy"); return FS_ERR_ARG; }
+  const fs::BinnedCsr &N = *a.binned;
+  if (which == 1) return fs::launch_expand_groups(a, x, 0u, (unsigned)(N.n >> fs::kBinGroupLog), N.nwg1, (hipStream_t)stream);
+  return fs::launch_reduce_panels(a, y, 0, N.P, (hipStream_t)stream);
+}
+
+#ifdef FS_LAB
+// one array of the two-pass copy moved to a fresh allocation (which: 0 lcol, 1 vals, 2 gdst, 3 lrow, 4 prod), the old block
+// freed only afterwards so that the new one lands elsewhere -- tools/placement_probe.py
+int fs_debug_two_pass_realloc(fs_matrix_t A, int transposed, int which_and_flags)
+{
+  if (which_and_flags & 32) {     // all five arrays into ONE fresh block (the old blocks and earlier arenas are dropped, not freed)
+    if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+    fs::DeviceCsr &a0 = transposed ? A->at : A->a;
+    if (!a0.binned || !a0.binned->built) return FS_ERR_ARG;
+    fs::BinnedCsr &N0 = *a0.binned;
+    void **slots[5] = {(void **)&N0.lcol, (void **)&N0.vals, (void **)&N0.gdst, (void **)&N0.lrow, (void **)&N0.prod};
+    const size_t sizes[5] = {(size_t)N0.n * 2, N0.vals ? (size_t)N0.n * 8 : 0, ((size_t)N0.n >> fs::kBinGroupLog) * 4, (size_t)N0.n * 2,
+                             (size_t)N0.n * 8 * (size_t)N0.kw};
+    const int order_a[5] = {4, 1, 0, 3, 2}, order_b[5] = {1, 4, 3, 0, 2};
+    const int *order = (which_and_flags & 64) ? order_b : order_a;
+    const size_t al = (size_t)2 << 20;
+    size_t total = 0;
+    for (int i = 0; i < 5; ++i) total += (sizes[i] + al - 1) / al * al;
+    char *arena = nullptr;
+    FS_HIP(hipDeviceSynchronize());
+    FS_HIP(hipMalloc(&arena, total));
+    size_t off = 0;
+    for (int j = 0; j < 5; ++j) {
+      const int i = order[j];
+      if (!sizes[i]) continue;
+      FS_HIP(hipMemcpy(arena + off, *slots[i], sizes[i], hipMemcpyDeviceToDevice));
+      *slots[i] = arena + off;
+      off += (sizes[i] + al - 1) / al * al;
+    }
+    return FS_OK;
+  }
+  const int which = which_and_flags & 15;
+  const bool leak_old = (which_and_flags & 16) != 0;     // the probe keeps the old block allocated (distinct placements) and drops it
+  if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+  fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.binned || !a.binned->built) { set_error("no two-pass copy"); return FS_ERR_ARG; }
+  fs::BinnedCsr &N = *a.binned;
+  void **slot = which == 0 ? (void **)&N.lcol : which == 1 ? (void **)&N.vals : which == 2 ? (void **)&N.gdst : which == 3 ? (void **)&N.lrow : (void **)&N.prod;
+  const size_t bytes = which == 0 || which == 3 ? (size_t)N.n * 2 : which == 2 ? ((size_t)N.n >> fs::kBinGroupLog) * 4 : (size_t)N.n * 8 * (which == 4 ? (size_t)N.kw : 1);
+  if (!*slot) return FS_OK;
+  void *fresh = nullptr;
+  FS_HIP(hipDeviceSynchronize());
+  FS_HIP(hipMalloc(&fresh, bytes));
+  FS_HIP(hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice));
+  if (!leak_old) FS_HIP(hipFree(*slot));
+  *slot = fresh;
+  return FS_OK;
+}
+#endif
+
 int fs_debug_tiled_geometry(fs_matrix_t A, int *out6)
 {
   const bool hx = A && A->a.tiledx && A->a.tiledx->built;     // the LDS-staged copy when that is the one built
