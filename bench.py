@@ -1123,6 +1123,9 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     ncol = n_global
     parts = world if _multi(world) else 8
     mine = rank if _multi(world) else min(3, parts - 1)     # N = 1: the shard rank 3 of 8 owns
+    if not _multi(world) and os.environ.get("FS_C5_PARTS"):  # rehearsal: the shard a rank of an N = 2 / 4 run would hold, on one GPU
+        parts = int(os.environ["FS_C5_PARTS"])
+        mine = min(int(os.environ.get("FS_C5_RANK", "0")), parts - 1)
     nparts = max(1, args.parts)
     cdev = prov.dev if (nccl and _multi(world)) else "cpu"
     bounds, cum_nnz, total_nnz = c5_partition(prov, n_global, parts)
