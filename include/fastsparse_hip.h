@@ -209,8 +209,8 @@ int fs_cbcsr_spmv(fs_cbcsr_t A, double *y, const double *x, fs_stream_t stream);
  * in one group -- runs on a second stream under the later parts; one fs_copy_segments launch unpacks.  z = A' u is the same
  * scheme on row shards of A' (fs_dist_matrix_build_transpose), with u = the y of the last product in place.
  * librccl.so is loaded with dlopen when a context with more than one distinct device is created.
- * A C caller of csr_A_mul_B / bcsr_A_mul_B / csr_At_mul_B / bcsr_At_mul_B gets this path by setting FASTSPARSE_NGPU=N
- * (optionally FASTSPARSE_DEVICES=0,1,...) in the environment.
+ * A C caller of ANY product entry point of sparse.h / dsparse.h / csr.h / cbcsr.h / cg.h gets this path by setting
+ * FASTSPARSE_NGPU=N (optionally FASTSPARSE_DEVICES=0,1,...) in the environment (fs_dropin.hip, "several GPUs").
  * devices == NULL means devices 0 .. ndev-1; ndev < 1 means every visible device.  A device may be listed more than once
  * ("virtual ranks" on one GPU, for testing the sharding on a one-GPU machine): such a context exchanges the parts
  * with device-to-device copies, because RCCL refuses duplicate devices.  Products on one fs_dist_matrix_t are serialised
@@ -221,11 +221,22 @@ int  fs_dist_ndev(fs_dist_t D);
 int  fs_dist_uses_rccl(fs_dist_t D);
 /* 1 once the context exchanges conservatively: ONE whole-shard all-gather behind the finished local product instead of one per
  * part under the later parts.  Chosen with FS_DIST_PARTS=1, and taken for good when a group call of the overlapped mode returns an
- * error (the product that met the error is finished conservatively).  The overlapped mode is UNVERIFIED on more than one GPU. */
+ * error on VIRTUAL ranks (that product is finished conservatively).  With RCCL a failed group call aborts the communicators
+ * (ncclCommAbort): that product and every later one on the context return the error -- no second collective is attempted on a
+ * half-issued group.  The overlapped mode is UNVERIFIED on more than one GPU. */
 int  fs_dist_is_conservative(fs_dist_t D);
 /* host CSR arrays -> nnz-balanced row shards, one fs_matrix_t per device; vals == NULL: pattern-only */
 fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols,
                                     const double *vals);
+/* host COO arrays (vals == NULL: pattern-only) -> the same shards; the entries are bucketed stably by row first (new_csr / new_bcsr,
+ * csr.h:375-422, 30-67), so every row adds in the caller's entry order like the serial COO loops (sparse.h:58-65, dsparse.h:43-51):
+ * A_mul_B / sdm_A_mul_B / bsbm_* / bsdm_* across the GPUs.  At_mul_B passes (cols, rows). */
+fs_dist_matrix_t fs_dist_coo_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *rows, const int *cols, const double *vals);
+/* A and its transpose as the caller holds them -- TWO matrices, like bsbm_cg(x, B, Bt, ...) cg.h:25 -- as one handle for fs_dist_cg /
+ * fs_dist_cg2 / fs_dist_ata / the *_t products: direct side = A's, transposed side = At's direct side (a row of A' adds in the order
+ * the caller's own At stores it).  Shares the shards of both (no copy; they live until the last of the three handles is destroyed);
+ * own vectors and solver work space. */
+fs_dist_matrix_t fs_dist_matrix_pair(fs_dist_matrix_t A, fs_dist_matrix_t At);
 /* The matrix as per-rank shards -- no whole-matrix array anywhere, so the TOTAL may exceed 2^31 - 1 entries (every shard stays
  * below it: int row_ptr, csr.h:358-366); BASELINE config 5 (3.2 G entries, 8 shards) enters this way.  Shard r = the next
  * shard_rows[r] rows of A: a LOCAL row_ptr (shard_rows[r] + 1 ints from 0), GLOBAL column ids, optional values (vals == NULL or
@@ -250,11 +261,17 @@ int64_t fs_dist_matrix_nnz(fs_dist_matrix_t M);
 /* the handle of rank `rank`'s shard of A (transposed != 0: of A'), owned by M, on that rank's device: for inspection
  * (fs_matrix_download, fs_matrix_spmv_kernel, fs_matrix_device_bytes) */
 fs_matrix_t fs_dist_matrix_shard(fs_dist_matrix_t M, int rank, int transposed);
-/* y[nrow] = A x[ncol] / z[ncol] = A' u[nrow] with HOST vectors: the input goes to every device over its own PCIe link
- * through a pinned staging buffer (chunks, the host copy of the next under the uploads of the last), the output comes back
- * from device 0 */
-int  fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host);
-int  fs_dist_spmv_t(fs_dist_matrix_t M, double *z_host, const double *u_host);
+/* y[nrow] = A x[ncol] / z[ncol] = A' u[nrow]; synchronous.  The vectors may be in HOST memory -- the input goes to every device over
+ * its own PCIe link through a pinned staging buffer (chunks, the host copy of the next under the uploads of the last), the output
+ * comes back from device 0 -- or in HBM of any device (hipPointerGetAttributes decides, per vector): then nothing touches the host.
+ * The ranks on the input's device read it in place, the others receive it device to device; an output in HBM IS the gathered vector
+ * of the first rank on its device (the unpack launch writes it).  The caller's earlier work on the legacy default stream of those
+ * devices is waited for first.  The same holds for every fs_dist_* function below that takes vectors. */
+int  fs_dist_spmv(fs_dist_matrix_t M, double *y, const double *x);
+int  fs_dist_spmv_t(fs_dist_matrix_t M, double *z, const double *u);
+/* z[ncol] = A'(A x[ncol]) + lambda x: bcsr_AA_mul_B / parallel_bcsr_AA_mul_B (csr.h:305-355; lambda = 0) and bsbm_AtA (cg.h:9-22)
+ * across the GPUs; A x stays on the devices */
+int  fs_dist_ata(fs_dist_matrix_t M, double *z, const double *x, double lambda);
 /* device-resident forms for iterating callers: fill fs_dist_x(M, r) (ncol doubles on rank r's device) on every rank ONCE;
  * fs_dist_spmv_resident leaves y = A x in fs_dist_y(M, r) (nrow doubles, complete on every rank when the call returns),
  * fs_dist_spmv_t_resident leaves z = A' y in fs_dist_z(M, r) (y of the last product is u, in place), fs_dist_swap_xy makes y

@@ -33,6 +33,7 @@ DEVICE_API = [
     "fs_dist_matrix_build_transpose", "fs_dist_matrix_has_transpose", "fs_dist_spmv_t", "fs_dist_spmv_t_resident", "fs_dist_swap_xy",
     "fs_dist_z", "fs_dist_cg", "fs_dist_is_conservative", "fs_dist_csr_create_from_shards", "fs_dist_matrix_build_transpose_device",
     "fs_dist_matrix_bounds_t", "fs_dist_matrix_nnz", "fs_dist_matrix_shard", "fs_dist_spmm", "fs_dist_spmm_t", "fs_dist_cg2",
+    "fs_dist_coo_create", "fs_dist_matrix_pair", "fs_dist_ata",
 ]
 REFERENCE_API = [
     # sparse.h
@@ -163,6 +164,11 @@ def lib():
     L.fs_dist_matrix_shard.restype = vp
     L.fs_dist_cg.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_int)]
     L.fs_dist_cg2.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    L.fs_dist_coo_create.restype = vp
+    L.fs_dist_coo_create.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp, vp, vp]
+    L.fs_dist_matrix_pair.restype = vp
+    L.fs_dist_matrix_pair.argtypes = [vp, vp]
+    L.fs_dist_ata.argtypes = [vp, vp, vp, C.c_double]
     L.fs_dist_spmm.argtypes = [vp, vp, vp, C.c_int]
     L.fs_dist_spmm_t.argtypes = [vp, vp, vp, C.c_int]
     for f in ("fs_dist_spmv_resident", "fs_dist_spmv_t_resident", "fs_dist_swap_xy"):

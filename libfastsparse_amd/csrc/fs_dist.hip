@@ -36,12 +36,15 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
 
+#include "csr.h"
 #include "fs_common.h"
 
 namespace {
@@ -50,6 +53,7 @@ struct Rccl {
   void *lib = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
@@ -67,7 +71,7 @@ Rccl &rccl()
     }
     if (!q.lib) return q;
 #define FS_SYM(f) q.f = reinterpret_cast<decltype(q.f)>(dlsym(q.lib, "nccl" #f))
-    FS_SYM(CommInitAll); FS_SYM(CommDestroy); FS_SYM(GroupStart); FS_SYM(GroupEnd); FS_SYM(AllGather); FS_SYM(GetErrorString);
+    FS_SYM(CommInitAll); FS_SYM(CommDestroy); FS_SYM(CommAbort); FS_SYM(GroupStart); FS_SYM(GroupEnd); FS_SYM(AllGather); FS_SYM(GetErrorString);
 #undef FS_SYM
     q.ok = q.CommInitAll && q.CommDestroy && q.GroupStart && q.GroupEnd && q.AllGather && q.GetErrorString;
     return q;
@@ -87,6 +91,8 @@ struct DeviceGuard {
   DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
   ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
+
+std::atomic<long> g_products{0};     // sharded products launched by this process (fs_debug_dist_products: the tests' proof of the path taken)
 
 int env_parts()
 {
@@ -115,6 +121,7 @@ struct fs_dist_s {
   std::vector<hipStream_t> comm_stream;  // communication stream per rank
   bool use_rccl = false;
   bool conservative = false;          // one whole-shard all-gather behind the product (FS_DIST_PARTS=1, or after an error)
+  bool broken = false;                // an RCCL call failed: the communicators were aborted, every later product is an error return
   bool fail_injected = false;
   std::vector<ncclComm_t> comm;
   std::mutex lock;                    // the streams and communicators serve one product at a time (a communicator must not be
@@ -165,7 +172,11 @@ struct fs_dist_matrix_s {
   fs_dist_t D = nullptr;
   int nrow = 0, ncol = 0;
   int64_t nnz = 0;
-  DistSide a, t;                      // A (always), A' (fs_dist_matrix_build_transpose[_device])
+  // A (always) and A' (fs_dist_matrix_build_transpose[_device], or ANOTHER matrix's A side: fs_dist_matrix_pair).  The sides are
+  // shared, not copied, between a pair and the matrices it was made from; the last owner frees the shards (side_owner).
+  std::shared_ptr<DistSide> pa, pt;
+  DistSide &a, &t;
+  fs_dist_matrix_s(std::shared_ptr<DistSide> A, std::shared_ptr<DistSide> T) : pa(std::move(A)), pt(std::move(T)), a(*pa), t(*pt) {}
   // per rank: the whole x (ncol), y (nrow) and z (ncol) on its device.  u of z = A' u is y.
   std::vector<double *> x, y, z;
   // host copies of the CSR are NOT kept
@@ -326,21 +337,32 @@ int exchange_equal(fs_dist_t D, const std::vector<const double *> &send, const s
                    const std::vector<hipStream_t> &st, const std::vector<hipEvent_t> &ready, bool inject_failure = false)
 {
   const int n = D->n;
+  if (D->broken) { fs::set_error("fs_dist: this context is unusable after an RCCL error (its communicators were aborted)"); return FS_ERR_HIP; }
   if (!count) return FS_OK;
   if (D->use_rccl) {
     // every rank's call in one group; an error inside the group still closes it
     ncclResult_t first = rccl().GroupStart();
     if (first != ncclSuccess) return nccl_fail(first, "ncclGroupStart");
-    if (inject_failure) first = ncclInternalError;
-    for (int r = 0; r < n && first == ncclSuccess; ++r)
+    for (int r = 0; r < n && first == ncclSuccess; ++r) {
+      if (inject_failure && r == (n > 1 ? 1 : 0)) { first = ncclInternalError; break; }   // (tests: rank 0's call is already in the group)
       first = rccl().AllGather(send[(size_t)r], recv[(size_t)r], count, ncclDouble, D->comm[(size_t)r], st[(size_t)r]);
+    }
     const ncclResult_t end = rccl().GroupEnd();
-    if (first != ncclSuccess) return nccl_fail(first, "ncclAllGather");
-    if (end != ncclSuccess) return nccl_fail(end, "ncclGroupEnd");
-    return FS_OK;
+    if (first == ncclSuccess && end == ncclSuccess) return FS_OK;
+    // A group call that failed may have launched the collective on some ranks only: nothing issued on these communicators can be
+    // relied on to finish, and a new collective on them is undefined.  Abort them (that also ends what is in flight) and leave the
+    // context unusable: this product and every later one return the error.  (no second collective on a failed group.)
+    const int rc = first != ncclSuccess ? nccl_fail(first, "ncclAllGather") : nccl_fail(end, "ncclGroupEnd");
+    const std::string why = fs_last_error();
+    for (ncclComm_t &c : D->comm)
+      if (c) { if (rccl().CommAbort) (void)rccl().CommAbort(c); c = nullptr; }
+    D->broken = true;
+    fs::set_error(why + "; the RCCL communicators were aborted: create a new context");
+    return rc;
   }
-  if (inject_failure) { fs::set_error("injected failure of an exchange (FS_DIST_FAIL_PART)"); return FS_ERR_HIP; }
   for (int d = 0; d < n; ++d) {
+    // (tests: the failure comes with the first destination's copies already enqueued -- a half-issued exchange)
+    if (inject_failure && d == (n > 1 ? 1 : 0)) { fs::set_error("injected failure of an exchange (FS_DIST_FAIL_PART)"); return FS_ERR_HIP; }
     FS_HIP(hipSetDevice(D->dev[d]));
     for (int r = 0; r < n; ++r) {
       if (ready[(size_t)r]) FS_HIP(hipStreamWaitEvent(st[(size_t)d], ready[(size_t)r], 0));
@@ -402,6 +424,8 @@ int dist_gather(fs_dist_t D, DistSide &S, const std::vector<double *> &src, cons
 int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, const std::vector<double *> &out)
 {
   const int n = D->n;
+  if (D->broken) { fs::set_error("fs_dist: this context is unusable after an RCCL error (its communicators were aborted)"); return FS_ERR_HIP; }
+  ++g_products;
   if (int rc = replan_if_moved(D, S)) return rc;
   const int np = S.nparts;
   if (D->conservative || np == 1) {
@@ -433,12 +457,15 @@ int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, cons
     const bool inject = !D->fail_injected && env_fail_part() == p;
     if (inject) D->fail_injected = true;
     if (int rc = exchange_equal(D, send, recv, (size_t)S.maxc[(size_t)p], D->comm_stream, ready, inject)) {
-      // a failed group call: finish the local product, then ONE whole-shard all-gather -- and stay conservative from now on.
-      // (if that fails too, the error goes to the caller)
       static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
-      if (trace) fprintf(stderr, "[fastsparse] the exchange of part %d failed (%s): conservative mode from here on\n", p, fs_last_error());
-      (void)rc;
       D->conservative = true;
+      if (D->use_rccl) {            // exchange_equal aborted the communicators: nothing to finish this product with
+        if (trace) fprintf(stderr, "[fastsparse] the exchange of part %d failed (%s)\n", p, fs_last_error());
+        return rc;
+      }
+      // virtual ranks (device-to-device copies, one GPU): whatever was enqueued completes by itself, so the product can be finished
+      // with ONE whole-shard exchange behind the finished local product -- and the context stays conservative from now on
+      if (trace) fprintf(stderr, "[fastsparse] the exchange of part %d failed (%s): conservative mode from here on\n", p, fs_last_error());
       for (int q = p + 1; q < np; ++q)
         for (int r = 0; r < n; ++r) {
           if (S.bounds[(size_t)r + 1] == S.bounds[(size_t)r]) continue;
@@ -504,6 +531,71 @@ int download_from(fs_dist_matrix_t M, int rank, double *dst_host, const double *
   return FS_OK;
 }
 
+// ---- the caller's dense vectors: host memory or HBM of any device --------------------------------------------------------
+// where a caller's vector lives: the HIP device ordinal, or -1 for host memory
+int vector_device(const void *p)
+{
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }   // plain malloc memory: not known to HIP
+  return (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) ? a.device : -1;
+}
+
+// the caller's work on the legacy default stream of device d has to be done before the ranks' (non-blocking) streams touch its
+// vectors: the entry points are synchronous, like the single-GPU drop-in's
+int wait_for_caller(int d)
+{
+  FS_HIP(hipSetDevice(d));
+  FS_HIP(hipStreamSynchronize(nullptr));
+  return FS_OK;
+}
+
+// The input of a product on every rank: in[r].  Host memory goes up to own[r] through the pinned staging buffer (upload_all).  A
+// vector in HBM never touches the host: the ranks of ITS device read it in place (in_place), the others get it device to device
+// (xGMI) into own[r].
+int vec_in(fs_dist_matrix_t M, const std::vector<double *> &own, const double *src, size_t count, std::vector<double *> &in, bool in_place)
+{
+  fs_dist_t D = M->D;
+  in = own;
+  const int d = vector_device(src);
+  if (d < 0) return upload_all(M, own, src, count);
+  if (int rc = wait_for_caller(d)) return rc;
+  for (int r = 0; r < D->n; ++r) {
+    if (in_place && D->dev[r] == d) { in[(size_t)r] = const_cast<double *>(src); continue; }
+    FS_HIP(hipSetDevice(D->dev[r]));
+    if (count) FS_HIP(hipMemcpyPeerAsync(own[(size_t)r], D->dev[r], src, d, sizeof(double) * count, D->stream[r]));
+  }
+  return FS_OK;
+}
+
+// The output of a product: every rank ends up with the whole vector (out[r]).  A caller's vector in HBM IS the output vector of the
+// first rank on its device (*direct), so the unpack launch writes it and nothing is copied; otherwise out = own and vec_store
+// brings rank 0's copy to the caller.
+int vec_out(fs_dist_matrix_t M, const std::vector<double *> &own, double *dst, std::vector<double *> &out, int *direct)
+{
+  fs_dist_t D = M->D;
+  out = own;
+  *direct = -1;
+  const int d = vector_device(dst);
+  if (d < 0) return FS_OK;
+  if (int rc = wait_for_caller(d)) return rc;
+  for (int r = 0; r < D->n && *direct < 0; ++r)
+    if (D->dev[r] == d) { out[(size_t)r] = dst; *direct = r; }
+  return FS_OK;
+}
+
+// count doubles from rank `rank`'s device to the caller: device to host, or device to device when dst is in HBM.  Asynchronous on
+// the rank's stream (the caller's dist_sync finishes it).
+int vec_store(fs_dist_matrix_t M, int rank, double *dst, const double *src_dev, size_t count)
+{
+  fs_dist_t D = M->D;
+  if (!count) return FS_OK;
+  const int d = vector_device(dst);
+  if (d < 0) return download_from(M, rank, dst, src_dev, count);
+  FS_HIP(hipSetDevice(D->dev[rank]));
+  FS_HIP(hipMemcpyPeerAsync(dst, d, src_dev, D->dev[rank], sizeof(double) * count, D->stream[rank]));
+  return FS_OK;
+}
+
 // shards of one direction from host CSR arrays (row_ptr of the direction's matrix; rp may be 64-bit for A')
 template <typename RP>
 int make_shards(fs_dist_t D, DistSide &S, int nrow, int ncol, const RP *row_ptr, const int *cols, const double *vals)
@@ -528,9 +620,20 @@ int make_shards(fs_dist_t D, DistSide &S, int nrow, int ncol, const RP *row_ptr,
   return plan_side(D, S, env_parts());
 }
 
-fs_dist_matrix_t new_dist_matrix(fs_dist_t D, int nrow, int ncol)
+// a side whose last owner -- the matrix it was made for, or a pair that shares it (fs_dist_matrix_pair) -- frees its shards
+std::shared_ptr<DistSide> side_owner(fs_dist_t D)
 {
-  fs_dist_matrix_t M = new fs_dist_matrix_s();
+  return std::shared_ptr<DistSide>(new DistSide(), [D](DistSide *S) {
+    DeviceGuard guard;
+    (void)dist_sync(D);
+    free_side(D, *S);
+    delete S;
+  });
+}
+
+fs_dist_matrix_t new_dist_matrix(fs_dist_t D, int nrow, int ncol, std::shared_ptr<DistSide> A = nullptr, std::shared_ptr<DistSide> T = nullptr)
+{
+  fs_dist_matrix_t M = new fs_dist_matrix_s(A ? A : side_owner(D), T ? T : side_owner(D));
   M->D = D; M->nrow = nrow; M->ncol = ncol;
   const int n = D->n;
   M->x.assign((size_t)n, nullptr);
@@ -640,6 +743,7 @@ int dist_product_k(fs_dist_matrix_t M, bool transposed, const std::vector<double
   DistSide &S = transposed ? M->t : M->a;
   const int k = W.k;
   const std::vector<double *> &loc = transposed ? W.lt : W.la;
+  ++g_products;
   std::vector<const double *> send((size_t)n);
   std::vector<hipEvent_t> ready((size_t)n);
   for (int r = 0; r < n; ++r) {
@@ -725,6 +829,8 @@ void fs_dist_destroy(fs_dist_t D)
   delete D;
 }
 
+long fs_debug_dist_products(void) { return g_products.load(); }   // diagnostics, not in include/fastsparse_hip.h
+
 int fs_dist_ndev(fs_dist_t D) { return D ? D->n : FS_ERR_ARG; }
 int fs_dist_uses_rccl(fs_dist_t D) { return D ? (int)D->use_rccl : FS_ERR_ARG; }
 int fs_dist_is_conservative(fs_dist_t D) { return D ? (int)D->conservative : FS_ERR_ARG; }
@@ -734,8 +840,6 @@ void fs_dist_matrix_destroy(fs_dist_matrix_t M)
   if (!M) return;
   DeviceGuard guard;
   (void)dist_sync(M->D);
-  free_side(M->D, M->a);
-  free_side(M->D, M->t);
   free_cg(M->D, M->cg);
   free_k(M->D, M->kw);
   for (size_t r = 0; r < (size_t)M->D->n; ++r) {
@@ -745,7 +849,7 @@ void fs_dist_matrix_destroy(fs_dist_matrix_t M)
     if (r < M->z.size() && M->z[r]) (void)hipFree(M->z[r]);
   }
   if (M->pin) (void)hipHostFree(M->pin);
-  delete M;
+  delete M;          // the sides go with their last owner (side_owner)
 }
 
 fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *row_ptr, const int *cols,
@@ -757,6 +861,53 @@ fs_dist_matrix_t fs_dist_csr_create(fs_dist_t D, int nrow, int ncol, int64_t nnz
   M->nnz = nnz;
   const bool ok = make_shards(D, M->a, nrow, ncol, row_ptr, cols, vals) == FS_OK && alloc_xy(M);
   if (!ok) { fs_dist_matrix_destroy(M); return nullptr; }
+  return M;
+}
+
+// host COO arrays (optionally valued) -> the same row shards: the entries are bucketed stably by row first -- new_csr / new_bcsr
+// (csr.h:375-422, 30-67; on the device from 4 M entries, fs_bucket_coo) -- so every row keeps the caller's entry order, the order
+// the serial COO loops add in (sparse.h:58-65, dsparse.h:43-51): what fs_coo_create does on one GPU.  A_mul_B / sdm_A_mul_B /
+// bsbm_* / bsdm_* across the GPUs enter here; At_mul_B passes (cols, rows).
+fs_dist_matrix_t fs_dist_coo_create(fs_dist_t D, int nrow, int ncol, int64_t nnz, const int *rows, const int *cols, const double *vals)
+{
+  if (!D || nrow < 0 || ncol < 0 || nnz < 0 || nnz > 0x7fffffffll || (nnz > 0 && (!rows || !cols))) {
+    fs::set_error("fs_dist_coo_create: bad argument (0 .. 2^31-1 entries)");
+    return nullptr;
+  }
+  for (int64_t i = 0; i < nnz; ++i)
+    if ((unsigned)rows[i] >= (unsigned)nrow) { fs::set_error("fs_dist_coo_create: row out of range"); return nullptr; }
+  fs_dist_matrix_t M = nullptr;
+  if (vals) {
+    struct CSR c;
+    new_csr(&c, (long)nnz, nrow, ncol, const_cast<int *>(rows), const_cast<int *>(cols), const_cast<double *>(vals));
+    M = fs_dist_csr_create(D, nrow, ncol, nnz, c.row_ptr, c.cols, c.vals);
+    free(c.row_ptr); free(c.cols); free(c.vals);
+  } else {
+    struct BinaryCSR c;
+    new_bcsr(&c, (long)nnz, nrow, ncol, const_cast<int *>(rows), const_cast<int *>(cols));
+    M = fs_dist_csr_create(D, nrow, ncol, nnz, c.row_ptr, c.cols, nullptr);
+    free(c.row_ptr); free(c.cols);
+  }
+  return M;
+}
+
+// A and A' as the caller holds them -- two matrices (bsbm_cg(x, B, Bt, ...), cg.h:25: B and the blocked form of its transpose) --
+// as ONE handle for fs_dist_cg / fs_dist_cg2 / fs_dist_ata / the *_t products: its direct side is A's, its transposed side is At's
+// DIRECT side (so a row of A' adds in the order the caller's own At stores it, like the single-GPU solvers on two handles).
+// Nothing is copied: the shards are shared with A and At and live until the last of the three handles is destroyed.  The pair
+// has its own vectors and solver work space.
+fs_dist_matrix_t fs_dist_matrix_pair(fs_dist_matrix_t A, fs_dist_matrix_t At)
+{
+  if (!A || !At || A->D != At->D) { fs::set_error("fs_dist_matrix_pair: NULL handle, or handles of two contexts"); return nullptr; }
+  if (A->nrow != At->ncol || A->ncol != At->nrow) { fs::set_error("fs_dist_matrix_pair: the matrices are not each other's transposes in shape"); return nullptr; }
+  DeviceGuard guard;
+  std::lock_guard<std::mutex> ga(A->lock);
+  fs_dist_matrix_t M = new_dist_matrix(A->D, A->nrow, A->ncol, A->pa, At->pa);
+  M->nnz = A->nnz;
+  bool ok = alloc_xy(M);
+  for (int r = 0; ok && r < A->D->n; ++r)
+    ok = hipSetDevice(A->D->dev[r]) == hipSuccess && hipMalloc(&M->z[(size_t)r], sizeof(double) * (size_t)(M->ncol ? M->ncol : 1)) == hipSuccess;
+  if (!ok) { fs::set_error("fs_dist_matrix_pair: out of device memory for the vectors"); fs_dist_matrix_destroy(M); return nullptr; }
   return M;
 }
 
@@ -1006,28 +1157,60 @@ fs_matrix_t fs_dist_matrix_shard(fs_dist_matrix_t M, int rank, int transposed)
   return (transposed ? M->t : M->a).shard[(size_t)rank];
 }
 
-int fs_dist_spmv(fs_dist_matrix_t M, double *y_host, const double *x_host)
+// y = M x with the caller's vectors in host memory or in HBM (vec_in / vec_out): one direction of the matrix
+static int dist_apply(fs_dist_matrix_t M, bool transposed, double *y, const double *x)
 {
-  if (!M || !y_host || !x_host) { fs::set_error("fs_dist_spmv: NULL argument"); return FS_ERR_ARG; }
   std::lock_guard<std::mutex> g(M->lock);
   std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
-  if (int rc = upload_all(M, M->x, x_host, (size_t)M->ncol)) return rc;
-  if (int rc = dist_product(M->D, M->a, M->x, M->y)) return rc;
-  if (int rc = download_from(M, 0, y_host, M->y[0], (size_t)M->nrow)) return rc;
+  DistSide &S = transposed ? M->t : M->a;
+  // (u of z = A' u lives where y does: A then A' chains without a copy)
+  const std::vector<double *> &own_in = transposed ? M->y : M->x, &own_out = transposed ? M->z : M->y;
+  std::vector<double *> in, out;
+  int direct = -1;
+  if (int rc = vec_in(M, own_in, x, (size_t)S.ncol, in, true)) return rc;
+  if (int rc = vec_out(M, own_out, y, out, &direct)) return rc;
+  if (int rc = dist_product(M->D, S, in, out)) return rc;
+  if (direct < 0)
+    if (int rc = vec_store(M, 0, y, own_out[0], (size_t)S.nrow)) return rc;
   return dist_sync(M->D);
 }
 
-int fs_dist_spmv_t(fs_dist_matrix_t M, double *z_host, const double *u_host)
+int fs_dist_spmv(fs_dist_matrix_t M, double *y, const double *x)
 {
-  if (!M || !z_host || !u_host) { fs::set_error("fs_dist_spmv_t: NULL argument"); return FS_ERR_ARG; }
+  if (!M || !y || !x) { fs::set_error("fs_dist_spmv: NULL argument"); return FS_ERR_ARG; }
+  return dist_apply(M, false, y, x);
+}
+
+int fs_dist_spmv_t(fs_dist_matrix_t M, double *z, const double *u)
+{
+  if (!M || !z || !u) { fs::set_error("fs_dist_spmv_t: NULL argument"); return FS_ERR_ARG; }
   if (!M->t.built) { fs::set_error("fs_dist_spmv_t: call fs_dist_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
+  return dist_apply(M, true, z, u);
+}
+
+// z[ncol] = A'(A x[ncol]) + lambda x (bcsr_AA_mul_B, csr.h:305-319, with lambda = 0; bsbm_AtA, cg.h:9-22, across the GPUs): y = A x
+// stays on the devices and is the u of the second product in place; two exchanges and one axpy on the rank that holds the output
+int fs_dist_ata(fs_dist_matrix_t M, double *z, const double *x, double lambda)
+{
+  if (!M || !z || !x) { fs::set_error("fs_dist_ata: NULL argument"); return FS_ERR_ARG; }
+  if (!M->t.built) { fs::set_error("fs_dist_ata: call fs_dist_matrix_build_transpose first"); return FS_ERR_NO_TRANSPOSE; }
   std::lock_guard<std::mutex> g(M->lock);
   std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
-  if (int rc = upload_all(M, M->y, u_host, (size_t)M->nrow)) return rc;   // u lives where y does: A then A' chains without a copy
-  if (int rc = dist_product(M->D, M->t, M->y, M->z)) return rc;
-  if (int rc = download_from(M, 0, z_host, M->z[0], (size_t)M->ncol)) return rc;
+  std::vector<double *> in, out;
+  int direct = -1;
+  if (int rc = vec_in(M, M->x, x, (size_t)M->ncol, in, true)) return rc;
+  if (int rc = vec_out(M, M->z, z, out, &direct)) return rc;
+  if (int rc = dist_product(M->D, M->a, in, M->y)) return rc;
+  if (int rc = dist_product(M->D, M->t, M->y, out)) return rc;
+  if (lambda != 0.0) {
+    const int r = direct < 0 ? 0 : direct;
+    FS_HIP(hipSetDevice(M->D->dev[r]));
+    if (int rc = fs_axpy(M->ncol, lambda, in[(size_t)r], out[(size_t)r], M->D->stream[r])) return rc;
+  }
+  if (direct < 0)
+    if (int rc = vec_store(M, 0, z, M->z[0], (size_t)M->ncol)) return rc;
   return dist_sync(M->D);
 }
 
@@ -1111,7 +1294,10 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
     }
     W.ready = true;
   }
-  if (int rc = upload_all(M, W.b, b_host, (size_t)F)) return rc;
+  {
+    std::vector<double *> unused;
+    if (int rc = vec_in(M, W.b, b_host, (size_t)F, unused, false)) return rc;    // (host memory or HBM; always a copy: b is read all solve long)
+  }
   // one set of host-visible flags per device
   std::vector<fs::CgFlags> fl((size_t)n);
   for (int d = 0; d < n; ++d) {
@@ -1215,13 +1401,15 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
       return FS_ERR_HIP;
     }
   }
+  if (vector_device(x_host) >= 0)
+    if (int rc = wait_for_caller(vector_device(x_host))) return rc;
   if (!gather) {
-    if (int rc = download_from(M, 0, x_host, W.sol[0], (size_t)F)) return rc;
+    if (int rc = vec_store(M, 0, x_host, W.sol[0], (size_t)F)) return rc;
   } else {
     for (int d = 0; d < n; ++d) {
       const int lo = T.bounds[(size_t)d], nl = T.bounds[(size_t)d + 1] - lo;
       if (nl > 0)
-        if (int rc = download_from(M, d, x_host + lo, W.sol[(size_t)d], (size_t)nl)) return rc;
+        if (int rc = vec_store(M, d, x_host + lo, W.sol[(size_t)d], (size_t)nl)) return rc;
     }
   }
   if (int rc = dist_sync(D)) return rc;
@@ -1232,33 +1420,38 @@ int fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double 
 // Y[nrow, k] = A X[ncol, k], row-major host matrices (csr_A_mul_Bn / bcsr_A_mul_Bn / bsbm_A_mul_Bn across the GPUs, csr.h:441,
 // 257; sparse.h:318): every device multiplies its shard (the k-column kernels of fs_spmm, prepared on first use of a k) and the
 // Y shards are all-gathered, one whole-shard exchange behind the local product.  fs_dist_spmm_t: Z[ncol, k] = A' U[nrow, k].
-int fs_dist_spmm(fs_dist_matrix_t M, double *Y_host, const double *X_host, int k)
+static int dist_apply_k(fs_dist_matrix_t M, bool transposed, double *Y, const double *X, int k)
 {
-  if (!M || !Y_host || !X_host || k < 1) { fs::set_error("fs_dist_spmm: bad argument"); return FS_ERR_ARG; }
-  if (k == 1) return fs_dist_spmv(M, Y_host, X_host);
   std::lock_guard<std::mutex> g(M->lock);
   std::lock_guard<std::mutex> gd(M->D->lock);
   DeviceGuard guard;
   if (int rc = ensure_k(M, k)) return rc;
-  if (int rc = upload_all(M, M->kw.x, X_host, (size_t)M->ncol * k)) return rc;
-  if (int rc = dist_product_k(M, false, M->kw.x, M->kw.y)) return rc;
-  if (int rc = download_from(M, 0, Y_host, M->kw.y[0], (size_t)M->nrow * k)) return rc;
+  DistSide &S = transposed ? M->t : M->a;
+  KWork &W = M->kw;
+  const std::vector<double *> &own_in = transposed ? W.y : W.x, &own_out = transposed ? W.z : W.y;
+  std::vector<double *> in, out;
+  int direct = -1;
+  if (int rc = vec_in(M, own_in, X, (size_t)S.ncol * k, in, true)) return rc;
+  if (int rc = vec_out(M, own_out, Y, out, &direct)) return rc;
+  if (int rc = dist_product_k(M, transposed, in, out)) return rc;
+  if (direct < 0)
+    if (int rc = vec_store(M, 0, Y, own_out[0], (size_t)S.nrow * k)) return rc;
   return dist_sync(M->D);
 }
 
-int fs_dist_spmm_t(fs_dist_matrix_t M, double *Z_host, const double *U_host, int k)
+int fs_dist_spmm(fs_dist_matrix_t M, double *Y, const double *X, int k)
 {
-  if (!M || !Z_host || !U_host || k < 1) { fs::set_error("fs_dist_spmm_t: bad argument"); return FS_ERR_ARG; }
+  if (!M || !Y || !X || k < 1) { fs::set_error("fs_dist_spmm: bad argument"); return FS_ERR_ARG; }
+  if (k == 1) return fs_dist_spmv(M, Y, X);
+  return dist_apply_k(M, false, Y, X, k);
+}
+
+int fs_dist_spmm_t(fs_dist_matrix_t M, double *Z, const double *U, int k)
+{
+  if (!M || !Z || !U || k < 1) { fs::set_error("fs_dist_spmm_t: bad argument"); return FS_ERR_ARG; }
   if (!M->t.built) { fs::set_error("fs_dist_spmm_t: build the transpose first"); return FS_ERR_NO_TRANSPOSE; }
-  if (k == 1) return fs_dist_spmv_t(M, Z_host, U_host);
-  std::lock_guard<std::mutex> g(M->lock);
-  std::lock_guard<std::mutex> gd(M->D->lock);
-  DeviceGuard guard;
-  if (int rc = ensure_k(M, k)) return rc;
-  if (int rc = upload_all(M, M->kw.y, U_host, (size_t)M->nrow * k)) return rc;
-  if (int rc = dist_product_k(M, true, M->kw.y, M->kw.z)) return rc;
-  if (int rc = download_from(M, 0, Z_host, M->kw.z[0], (size_t)M->ncol * k)) return rc;
-  return dist_sync(M->D);
+  if (k == 1) return fs_dist_spmv_t(M, Z, U);
+  return dist_apply_k(M, true, Z, U, k);
 }
 
 // (A'A + lambda I) X = B for two right-hand sides, row-major ncol x 2: bsbm_cg2 (cg.h:85-187) across the GPUs, everything
@@ -1278,7 +1471,10 @@ int fs_dist_cg2(fs_dist_matrix_t M, double *X_host, const double *B_host, double
   const int n = D->n, F = M->ncol;
   if (int rc = ensure_k(M, 2)) return rc;
   KWork &W = M->kw;
-  if (int rc = upload_all(M, W.b, B_host, (size_t)F * 2)) return rc;
+  {
+    std::vector<double *> unused;
+    if (int rc = vec_in(M, W.b, B_host, (size_t)F * 2, unused, false)) return rc;
+  }
   std::vector<fs::CgFlags> fl((size_t)n);
   std::vector<double> norms(2 * (size_t)n, 0.0);
   for (int d = 0; d < n; ++d) {
@@ -1326,7 +1522,9 @@ int fs_dist_cg2(fs_dist_matrix_t M, double *X_host, const double *B_host, double
       return FS_ERR_HIP;
     }
   }
-  if (int rc = download_from(M, 0, X_host, W.sol[0], (size_t)F * 2)) return rc;
+  if (vector_device(X_host) >= 0)
+    if (int rc = wait_for_caller(vector_device(X_host))) return rc;
+  if (int rc = vec_store(M, 0, X_host, W.sol[0], (size_t)F * 2)) return rc;
   if (int rc = dist_sync(D)) return rc;
   if (out_iter) *out_iter = (int)fin[1];
   return FS_OK;

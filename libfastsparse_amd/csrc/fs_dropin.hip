@@ -29,6 +29,8 @@
 #include "fs_common.h"
 #include "sparse.h"
 
+extern "C" long fs_debug_dist_products(void);
+
 namespace {
 
 [[noreturn]] void die(const char *who)
@@ -256,12 +258,87 @@ void product(fs_matrix_t m, bool transposed, double *y, size_t ny, const double 
     return transposed ? fs_spmv_t(m, yd, xd, nullptr) : fs_spmv(m, yd, xd, nullptr); }, who);
 }
 
+// ---- fingerprints of the reference's containers (what an entry of the side table is compared by) -----------------------------
+uint64_t csr_print(int nrow, int ncol, long nnz, const int *row_ptr, const int *cols, const double *vals)
+{
+  const bool full = hash_in_full((int64_t)nnz * (vals ? 12 : 4) + 4 * ((int64_t)nrow + 1));
+  uint64_t h = mix(mix(mix(1, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
+  h = mix(mix(mix(h, (uint64_t)(uintptr_t)row_ptr), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
+  h = print_ints(h, row_ptr, (int64_t)nrow + 1, full);
+  h = print_ints(h, cols, nnz, full);
+  return print_doubles(h, vals, nnz, full);
+}
+
+uint64_t coo_print(int nrow, int ncol, long nnz, const int *rows, const int *cols, const double *vals)
+{
+  const bool full = hash_in_full((int64_t)nnz * (vals ? 16 : 8));
+  uint64_t h = mix(mix(mix(2, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
+  h = mix(mix(mix(h, (uint64_t)(uintptr_t)rows), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
+  return print_doubles(print_ints(print_ints(h, rows, nnz, full), cols, nnz, full), vals, nnz, full);
+}
+
+// per call: nothing here may cost O(nblocks) once the blocks run into the millions (block size 8 on 10 M rows)
+uint64_t blocked_print(int nrow, int ncol, int nblocks, const int *blk_nnz, int **brows, int **bcols, double **bvals)
+{
+  const bool few = nblocks <= (1 << 14);
+  int64_t nnz = 0;
+  if (few)
+    for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
+  const bool full = few && hash_in_full(nnz * (bvals ? 16 : 8));
+  uint64_t h = mix(mix(mix(3, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nblocks);
+  h = print_ints(h, blk_nnz, nblocks, few);
+  // sampled mode: the same budget as an unblocked matrix -- about 2048 samples per array in ALL, spread over at most 64
+  // blocks (2048 per array in EACH of 64 blocks cost 0.85 ms of host time per call on a 2 M x 200 K matrix of 1954 blocks,
+  // five times the product itself; the reference's bench loops over bsbm_A_mul_B)
+  const int stride = nblocks / 64 + 1, sampled = (nblocks + stride - 1) / stride;
+  const int per_block = 2048 / (sampled > 0 ? sampled : 1) + 1;     // nblocks == 0 (a matrix without rows): nothing to sample
+  const int pstride = full ? 1 : nblocks / 4096 + 1;              // array pointers: all of them up to 4096 blocks
+  for (int b = 0; b < nblocks; b += pstride) h = mix(mix(h, (uint64_t)(uintptr_t)brows[b]), (uint64_t)(uintptr_t)bcols[b]);
+  for (int b = 0; b < nblocks; b += full ? 1 : stride) {
+    h = print_ints(print_ints(h, brows[b], blk_nnz[b], full, per_block), bcols[b], blk_nnz[b], full, per_block);
+    if (bvals) h = print_doubles(h, bvals[b], blk_nnz[b], full, per_block);
+  }
+  return h;
+}
+
+// the per-block arrays of a row-blocked matrix laid end to end: one COO whose rows keep the order bsbm_A_mul_B (sparse.h:269-271)
+// adds them in (a row lives in exactly one block)
+struct BlockedAsCoo {
+  std::vector<int> r, c;
+  std::vector<double> v;
+  BlockedAsCoo(int nblocks, const int *blk_nnz, int **brows, int **bcols, double **bvals)
+  {
+    int64_t nnz = 0;
+    for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
+    r.resize((size_t)nnz); c.resize((size_t)nnz);
+    if (bvals) v.resize((size_t)nnz);
+    size_t o = 0;
+    for (int b = 0; b < nblocks; b++) {
+      const size_t m = (size_t)blk_nnz[b];
+      if (m) {
+        memcpy(r.data() + o, brows[b], sizeof(int) * m);
+        memcpy(c.data() + o, bcols[b], sizeof(int) * m);
+        if (bvals) memcpy(v.data() + o, bvals[b], sizeof(double) * m);
+      }
+      o += m;
+    }
+  }
+};
+
 // ---- several GPUs (FASTSPARSE_NGPU) ---------------------------------------------------------------------
-// csr_A_mul_B / bcsr_A_mul_B of a plain C caller across the GPUs of the node: FASTSPARSE_NGPU=N in the environment
-// (and optionally FASTSPARSE_DEVICES=0,1,...: the device of every rank).  One context for the process.
-enum { kDist = 2 };
+// EVERY product entry point of a plain C caller across the GPUs of the node: FASTSPARSE_NGPU=N in the environment (and optionally
+// FASTSPARSE_DEVICES=0,1,...: the device of every rank).  One context for the process.  Each container becomes the same CSR it
+// becomes on one GPU -- so every row keeps the reference's order of additions -- cut into row shards by non-zeros (fs_dist.hip):
+//   struct CSR / BinaryCSR            the arrays as they are; A' x: row shards of A' from the same arrays
+//   COO (sbm / sdm)                   stable bucketing by row (fs_dist_coo_create); At_mul_B: the COO of (cols, rows)
+//   BlockedSBM / BlockedSDM           the blocks end to end as one COO
+//   ColBinaryCSR                      a CSR whose rows hold their cells' entries block by block
+//   bsbm_cg / bsbm_cg2 / bsbm_AtA     the caller's A and At as a PAIR sharing both matrices' shards (fs_dist_matrix_pair)
+// x / y in host memory or in HBM; a vector in HBM never touches the host (fs_dist.hip: vec_in / vec_out).
+enum { kDist = 2, kDistT = 3, kDistPair = 4, kVariants = 5 };
 
 int dist_ranks() { static const int v = env_int("FASTSPARSE_NGPU", 1); return v; }
+bool dist_on() { return dist_ranks() > 1; }
 
 fs_dist_t dist_context(const char *who)
 {
@@ -283,36 +360,56 @@ fs_dist_t dist_context(const char *who)
   }
   D = fs_dist_create(n, devs.empty() ? nullptr : devs.data());
   if (!D) die(who);
+  if (env_int("FS_TRACE_DIST", 0))   // proof of the path taken for callers that cannot ask (the reference's own test program)
+    atexit([] { fprintf(stderr, "[fastsparse] %ld sharded products on %d ranks\n", fs_debug_dist_products(), dist_ranks()); });
   return D;
 }
 
-// y = A x on the node's GPUs: host vectors (device vectors are staged through the host: the multi-GPU entry point for
-// resident data is fs_dist_spmv_resident)
-void dist_csr_mul(double *y, const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols,
-                  const double *vals, double *x, const char *who, bool transposed = false)
+EntryP dist_csr_entry(const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols, const double *vals,
+                      bool need_t, const char *who)
 {
   fs_dist_t D = dist_context(who);
-  const bool full = hash_in_full((int64_t)nnz * (vals ? 12 : 4) + 4 * ((int64_t)nrow + 1));
-  uint64_t h = mix(mix(mix(5, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
-  h = mix(mix(mix(h, (uint64_t)(uintptr_t)row_ptr), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
-  h = print_doubles(print_ints(print_ints(h, row_ptr, (int64_t)nrow + 1, full), cols, nnz, full), vals, nnz, full);
-  EntryP e = lookup(host, kDist, h, [&](Entry &n) { n.dm = fs_dist_csr_create(D, nrow, ncol, nnz, row_ptr, cols, vals); }, who);
+  EntryP e = lookup(host, kDist, mix(5, csr_print(nrow, ncol, nnz, row_ptr, cols, vals)),
+                    [&](Entry &n) { n.dm = fs_dist_csr_create(D, nrow, ncol, nnz, row_ptr, cols, vals); }, who);
   // the transposed product: row shards of A' on the same devices, built from the same host arrays on first use
-  if (transposed) FS_MUST(fs_dist_matrix_build_transpose(e->dm, row_ptr, cols, vals), who);
-  const size_t nx = (size_t)(transposed ? nrow : ncol), ny = (size_t)(transposed ? ncol : nrow);
-  std::vector<double> xs, ys;
-  const double *xh = x;
-  double *yh = y;
-  if (on_device(x)) {
-    xs.resize(nx);
-    if (hipMemcpy(xs.data(), x, sizeof(double) * nx, hipMemcpyDeviceToHost) != hipSuccess) { fs::set_error("copy of x failed"); die(who); }
-    xh = xs.data();
-  }
-  if (on_device(y)) { ys.resize(ny); yh = ys.data(); }
-  FS_MUST(transposed ? fs_dist_spmv_t(e->dm, yh, xh) : fs_dist_spmv(e->dm, yh, xh), who);
-  if (yh != y && hipMemcpy(y, yh, sizeof(double) * ny, hipMemcpyHostToDevice) != hipSuccess) {
-    fs::set_error("copy of y failed"); die(who);
-  }
+  if (need_t) FS_MUST(fs_dist_matrix_build_transpose(e->dm, row_ptr, cols, vals), who);
+  return e;
+}
+
+EntryP dist_coo_entry(const void *host, int variant, int nrow, int ncol, long nnz, const int *rows, const int *cols,
+                      const double *vals, const char *who)
+{
+  fs_dist_t D = dist_context(who);
+  return lookup(host, variant, mix(5, coo_print(nrow, ncol, nnz, rows, cols, vals)), [&](Entry &n) {
+    n.dm = variant == kDist ? fs_dist_coo_create(D, nrow, ncol, nnz, rows, cols, vals)
+                            : fs_dist_coo_create(D, ncol, nrow, nnz, cols, rows, vals);
+  }, who);
+}
+
+EntryP dist_blocked_entry(const void *host, int nrow, int ncol, int nblocks, const int *blk_nnz, int **brows, int **bcols,
+                          double **bvals, const char *who)
+{
+  fs_dist_t D = dist_context(who);
+  return lookup(host, kDist, mix(5, blocked_print(nrow, ncol, nblocks, blk_nnz, brows, bcols, bvals)), [&](Entry &n) {
+    BlockedAsCoo coo(nblocks, blk_nnz, brows, bcols, bvals);
+    n.dm = fs_dist_coo_create(D, nrow, ncol, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), bvals ? coo.v.data() : nullptr);
+  }, who);
+}
+
+// A and At of bsbm_cg / bsbm_cg2 / bsbm_AtA (cg.h:9-187) as one handle: the pair shares the shards of the two matrices' own entries
+EntryP dist_pair_entry(struct BlockedSBM *A, struct BlockedSBM *At, const char *who)
+{
+  EntryP ea = dist_blocked_entry(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, who);
+  EntryP eat = dist_blocked_entry(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, who);
+  const uint64_t h = mix(mix(mix(6, ea->print), eat->print), (uint64_t)(uintptr_t)At);
+  return lookup(A, kDistPair, h, [&](Entry &n) { n.dm = fs_dist_matrix_pair(ea->dm, eat->dm); }, who);
+}
+
+// y = M x (transposed: M' x) for k row-major columns on the node's GPUs
+void dist_mul(fs_dist_matrix_t dm, bool transposed, double *y, double *x, int k, const char *who)
+{
+  if (k == 1) FS_MUST(transposed ? fs_dist_spmv_t(dm, y, x) : fs_dist_spmv(dm, y, x), who);
+  else FS_MUST(transposed ? fs_dist_spmm_t(dm, y, x, k) : fs_dist_spmm(dm, y, x, k), who);
 }
 
 // ---- one-time work of multi-column products ------------------------------------------------------------------
@@ -349,13 +446,7 @@ void prepare_listed(fs_matrix_t m, bool transposed_too, const char *who)
 EntryP csr_entry(const void *host, int nrow, int ncol, long nnz, const int *row_ptr, const int *cols,
                  const double *vals, bool need_t, const char *who)
 {
-  const bool full = hash_in_full((int64_t)nnz * (vals ? 12 : 4) + 4 * ((int64_t)nrow + 1));
-  uint64_t h = mix(mix(mix(1, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
-  h = mix(mix(mix(h, (uint64_t)(uintptr_t)row_ptr), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
-  h = print_ints(h, row_ptr, (int64_t)nrow + 1, full);
-  h = print_ints(h, cols, nnz, full);
-  h = print_doubles(h, vals, nnz, full);
-  EntryP e = lookup(host, kDirect, h, [&](Entry &n) {
+  EntryP e = lookup(host, kDirect, csr_print(nrow, ncol, nnz, row_ptr, cols, vals), [&](Entry &n) {
     n.m = fs_csr_create(nrow, ncol, nnz, row_ptr, cols, vals, FS_HOST, 0);
     if (n.m) prepare_listed(n.m, false, who);
   }, who);
@@ -371,11 +462,7 @@ EntryP csr_entry(const void *host, int nrow, int ncol, long nnz, const int *row_
 EntryP coo_entry(const void *host, int variant, int nrow, int ncol, long nnz, const int *rows, const int *cols,
                  const double *vals, const char *who)
 {
-  const bool full = hash_in_full((int64_t)nnz * (vals ? 16 : 8));
-  uint64_t h = mix(mix(mix(2, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nnz);
-  h = mix(mix(mix(h, (uint64_t)(uintptr_t)rows), (uint64_t)(uintptr_t)cols), (uint64_t)(uintptr_t)vals);
-  h = print_doubles(print_ints(print_ints(h, rows, nnz, full), cols, nnz, full), vals, nnz, full);
-  return lookup(host, variant, h, [&](Entry &n) {
+  return lookup(host, variant, coo_print(nrow, ncol, nnz, rows, cols, vals), [&](Entry &n) {
     n.m = variant == kDirect ? fs_coo_create(nrow, ncol, nnz, rows, cols, vals, FS_HOST)
                              : fs_coo_create(ncol, nrow, nnz, cols, rows, vals, FS_HOST);
     if (n.m) prepare_listed(n.m, false, who);
@@ -387,49 +474,19 @@ EntryP coo_entry(const void *host, int variant, int nrow, int ncol, long nnz, co
 EntryP blocked_entry(const void *host, int nrow, int ncol, int nblocks, const int *blk_nnz, int **brows,
                      int **bcols, double **bvals, const char *who)
 {
-  // per call: nothing here may cost O(nblocks) once the blocks run into the millions (block size 8 on 10 M rows)
-  const bool few = nblocks <= (1 << 14);
-  int64_t nnz = 0;
-  if (few)
-    for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
-  const bool full = few && hash_in_full(nnz * (bvals ? 16 : 8));
-  uint64_t h = mix(mix(mix(3, (uint64_t)nrow), (uint64_t)ncol), (uint64_t)nblocks);
-  h = print_ints(h, blk_nnz, nblocks, few);
-  // sampled mode: the same budget as an unblocked matrix -- about 2048 samples per array in ALL, spread over at most 64
-  // blocks (2048 per array in EACH of 64 blocks cost 0.85 ms of host time per call on a 2 M x 200 K matrix of 1954 blocks,
-  // five times the product itself; the reference's bench loops over bsbm_A_mul_B)
-  const int stride = nblocks / 64 + 1, sampled = (nblocks + stride - 1) / stride;
-  const int per_block = 2048 / (sampled > 0 ? sampled : 1) + 1;     // nblocks == 0 (a matrix without rows): nothing to sample
-  const int pstride = full ? 1 : nblocks / 4096 + 1;              // array pointers: all of them up to 4096 blocks
-  for (int b = 0; b < nblocks; b += pstride) h = mix(mix(h, (uint64_t)(uintptr_t)brows[b]), (uint64_t)(uintptr_t)bcols[b]);
-  for (int b = 0; b < nblocks; b += full ? 1 : stride) {
-    h = print_ints(print_ints(h, brows[b], blk_nnz[b], full, per_block), bcols[b], blk_nnz[b], full, per_block);
-    if (bvals) h = print_doubles(h, bvals[b], blk_nnz[b], full, per_block);
-  }
-  return lookup(host, kDirect, h, [&](Entry &n) {
-    if (!few) {
-      nnz = 0;
-      for (int b = 0; b < nblocks; b++) nnz += blk_nnz[b];
-    }
-    std::vector<int> r((size_t)nnz), c((size_t)nnz);
-    std::vector<double> v(bvals ? (size_t)nnz : 0);
-    size_t o = 0;
-    for (int b = 0; b < nblocks; b++) {
-      const size_t m = (size_t)blk_nnz[b];
-      if (m) {
-        memcpy(r.data() + o, brows[b], sizeof(int) * m);
-        memcpy(c.data() + o, bcols[b], sizeof(int) * m);
-        if (bvals) memcpy(v.data() + o, bvals[b], sizeof(double) * m);
-      }
-      o += m;
-    }
-    n.m = fs_coo_create(nrow, ncol, nnz, r.data(), c.data(), bvals ? v.data() : nullptr, FS_HOST);
+  return lookup(host, kDirect, blocked_print(nrow, ncol, nblocks, blk_nnz, brows, bcols, bvals), [&](Entry &n) {
+    BlockedAsCoo coo(nblocks, blk_nnz, brows, bcols, bvals);
+    n.m = fs_coo_create(nrow, ncol, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), bvals ? coo.v.data() : nullptr, FS_HOST);
     if (n.m) prepare_listed(n.m, false, who);
   }, who);
 }
 
 void bcsr_mul_k(double *Y, struct BinaryCSR *A, double *X, int k, const char *who)
 {
+  if (dist_on()) {
+    dist_mul(dist_csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, false, who)->dm, false, Y, X, k, who);
+    return;
+  }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, false, who);
   if (k == 1) { product(e->m, false, Y, A->nrow, X, A->ncol, who); return; }
   FS_MUST(fs_matrix_prepare(e->m, k, 0, nullptr), who);   // first product with this k: the one-time work; later: nothing
@@ -439,6 +496,10 @@ void bcsr_mul_k(double *Y, struct BinaryCSR *A, double *X, int k, const char *wh
 
 void bsbm_mul_k(double *Y, struct BlockedSBM *B, double *X, int k, const char *who)
 {
+  if (dist_on()) {
+    dist_mul(dist_blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, nullptr, who)->dm, false, Y, X, k, who);
+    return;
+  }
   EntryP e = blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, nullptr, who);
   if (k == 1) { product(e->m, false, Y, B->nrow, X, B->ncol, who); return; }
   FS_MUST(fs_matrix_prepare(e->m, k, 0, nullptr), who);
@@ -453,7 +514,7 @@ extern "C" {
 void fs_invalidate(const void *host_struct)
 {
   std::lock_guard<std::mutex> g(g_table_lock);
-  for (int v = 0; v < 3; v++) g_table.erase(Key{host_struct, v});   // a product still running on the copy keeps it alive
+  for (int v = 0; v < kVariants; v++) g_table.erase(Key{host_struct, v});   // a product still running on the copy keeps it alive
 }
 
 void fs_release_all(void)
@@ -475,12 +536,14 @@ int fs_cache_entries(void)
 // ---- sparse.h ----------------------------------------------------------------------------------------
 void A_mul_B(double *y, struct SparseBinaryMatrix *A, double *x)
 {
+  if (dist_on()) { dist_mul(dist_coo_entry(A, kDist, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "A_mul_B")->dm, false, y, x, 1, "A_mul_B"); return; }
   EntryP e = coo_entry(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "A_mul_B");
   product(e->m, false, y, A->nrow, x, A->ncol, "A_mul_B");
 }
 
 void At_mul_B(double *y, struct SparseBinaryMatrix *A, double *x)
 {
+  if (dist_on()) { dist_mul(dist_coo_entry(A, kDistT, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "At_mul_B")->dm, false, y, x, 1, "At_mul_B"); return; }
   EntryP e = coo_entry(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, nullptr, "At_mul_B");
   product(e->m, false, y, A->ncol, x, A->nrow, "At_mul_B");
 }
@@ -494,6 +557,7 @@ void bsbm_A_mul_Bn(double *y, struct BlockedSBM *B, double *x, int ncol) { bsbm_
 void bsbm_AtA(double *y, struct BlockedSBM *A, struct BlockedSBM *At, double *x, double *tmp, double lambda)
 {
   (void)tmp;  // host scratch of the CPU version; the intermediate A x stays in HBM here
+  if (dist_on()) { FS_MUST(fs_dist_ata(dist_pair_entry(A, At, "bsbm_AtA")->dm, y, x, lambda), "bsbm_AtA"); return; }
   EntryP ea = blocked_entry(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, "bsbm_AtA");
   EntryP eat = blocked_entry(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, "bsbm_AtA");
   fs_matrix_t a = ea->m, at = eat->m;
@@ -516,6 +580,13 @@ static void cg_common(double *x, struct BlockedSBM *A, struct BlockedSBM *At, do
   if (A->nrow != At->ncol || A->ncol != At->nrow) {  // cg.h:32-36
     printf("A (%d x %d) and At (%d x %d) must be transposes of each other.\n", A->nrow, A->ncol, At->nrow, At->ncol);
     exit(1);
+  }
+  if (dist_on()) {
+    fs_dist_matrix_t pair = dist_pair_entry(A, At, who)->dm;
+    int it = 0;
+    FS_MUST(k == 1 ? fs_dist_cg(pair, x, b, lambda, tol, &it) : fs_dist_cg2(pair, x, b, lambda, tol, &it), who);
+    if (out_iter) *out_iter = it;
+    return;
   }
   EntryP ea = blocked_entry(A, A->nrow, A->ncol, A->nblocks, A->nnz, A->rows, A->cols, nullptr, who);
   EntryP eat = blocked_entry(At, At->nrow, At->ncol, At->nblocks, At->nnz, At->rows, At->cols, nullptr, who);
@@ -541,18 +612,21 @@ void bsbm_cg2(double *X, struct BlockedSBM *A, struct BlockedSBM *At, double *B,
 // ---- dsparse.h ---------------------------------------------------------------------------------------
 void sdm_A_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)
 {
+  if (dist_on()) { dist_mul(dist_coo_entry(A, kDist, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_A_mul_B")->dm, false, y, x, 1, "sdm_A_mul_B"); return; }
   EntryP e = coo_entry(A, kDirect, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_A_mul_B");
   product(e->m, false, y, A->nrow, x, A->ncol, "sdm_A_mul_B");
 }
 
 void sdm_At_mul_B(double *y, struct SparseDoubleMatrix *A, double *x)
 {
+  if (dist_on()) { dist_mul(dist_coo_entry(A, kDistT, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_At_mul_B")->dm, false, y, x, 1, "sdm_At_mul_B"); return; }
   EntryP e = coo_entry(A, kTransposed, A->nrow, A->ncol, A->nnz, A->rows, A->cols, A->vals, "sdm_At_mul_B");
   product(e->m, false, y, A->ncol, x, A->nrow, "sdm_At_mul_B");
 }
 
 void bsdm_A_mul_B(double *y, struct BlockedSDM *B, double *x)
 {
+  if (dist_on()) { dist_mul(dist_blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, B->vals, "bsdm_A_mul_B")->dm, false, y, x, 1, "bsdm_A_mul_B"); return; }
   EntryP e = blocked_entry(B, B->nrow, B->ncol, B->nblocks, B->nnz, B->rows, B->cols, B->vals, "bsdm_A_mul_B");
   product(e->m, false, y, B->nrow, x, B->ncol, "bsdm_A_mul_B");
 }
@@ -575,7 +649,6 @@ void free_csr(struct CSR *csr)
 
 void bcsr_A_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
-  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, x, "bcsr_A_mul_B"); return; }
   bcsr_mul_k(y, A, x, 1, "bcsr_A_mul_B");
 }
 void bcsr_A_mul_B2(double *Y, struct BinaryCSR *A, double *X) { bcsr_mul_k(Y, A, X, 2, "bcsr_A_mul_B2"); }
@@ -595,6 +668,10 @@ void bcsr_A_mul_B32n(double *Y, struct BinaryCSR *A, double *X, const int ncol)
 
 void bcsr_AA_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
+  if (dist_on()) {
+    FS_MUST(fs_dist_ata(dist_csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_AA_mul_B")->dm, y, x, 0.0), "bcsr_AA_mul_B");
+    return;
+  }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_AA_mul_B");
   fs_matrix_t m = e->m;
   double *tmp = nullptr;
@@ -614,7 +691,7 @@ void parallel_bcsr_AA_mul_B(double *y, struct BinaryCSR *A, double *x, double *y
 
 void bcsr_At_mul_B(double *y, struct BinaryCSR *A, double *x)
 {
-  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, x, "bcsr_At_mul_B", true); return; }
+  if (dist_on()) { dist_mul(dist_csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_At_mul_B")->dm, true, y, x, 1, "bcsr_At_mul_B"); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, nullptr, true, "bcsr_At_mul_B");
   fs_matrix_t m = e->m;
   product(m, true, y, A->ncol, x, A->nrow, "bcsr_At_mul_B");
@@ -622,7 +699,7 @@ void bcsr_At_mul_B(double *y, struct BinaryCSR *A, double *x)
 
 void csr_A_mul_B(double *y, struct CSR *A, double *x)
 {
-  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, x, "csr_A_mul_B"); return; }
+  if (dist_on()) { dist_mul(dist_csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_B")->dm, false, y, x, 1, "csr_A_mul_B"); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_B");
   fs_matrix_t m = e->m;
   product(m, false, y, A->nrow, x, A->ncol, "csr_A_mul_B");
@@ -630,7 +707,7 @@ void csr_A_mul_B(double *y, struct CSR *A, double *x)
 
 void csr_At_mul_B(double *y, struct CSR *A, double *x)
 {
-  if (dist_ranks() > 1) { dist_csr_mul(y, A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, x, "csr_At_mul_B", true); return; }
+  if (dist_on()) { dist_mul(dist_csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, true, "csr_At_mul_B")->dm, true, y, x, 1, "csr_At_mul_B"); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, true, "csr_At_mul_B");
   fs_matrix_t m = e->m;
   product(m, true, y, A->ncol, x, A->nrow, "csr_At_mul_B");
@@ -638,6 +715,7 @@ void csr_At_mul_B(double *y, struct CSR *A, double *x)
 
 void csr_A_mul_Bn(double *Y, struct CSR *A, double *X, const int ncol)
 {
+  if (dist_on()) { dist_mul(dist_csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_Bn")->dm, false, Y, X, ncol, "csr_A_mul_Bn"); return; }
   EntryP e = csr_entry(A, A->nrow, A->ncol, A->nnz, A->row_ptr, A->cols, A->vals, false, "csr_A_mul_Bn");
   fs_matrix_t m = e->m;
   if (ncol > 1) FS_MUST(fs_matrix_prepare(m, ncol, 0, nullptr), "csr_A_mul_Bn");
@@ -653,6 +731,27 @@ void cbcsr_A_mul_B(double *y, struct ColBinaryCSR *A, double *x)
   uint64_t h = mix(mix(mix(4, (uint64_t)A->nrow), (uint64_t)A->ncol), (uint64_t)A->nnz);
   h = mix(mix(mix(h, (uint64_t)A->colblocksize), (uint64_t)(uintptr_t)A->row_ptr), (uint64_t)(uintptr_t)A->cols);
   h = print_ints(print_ints(h, A->row_ptr, ncell + 1, full), A->cols, A->nnz, full);
+  if (dist_on()) {
+    // across the GPUs: the same entries as a plain pattern-only CSR whose rows hold their cells' entries block by block (the order the
+    // single-GPU kernels add large column-blocked matrices in; cbcsr.h:88-103 itself adds per-thread partial vectors in schedule order)
+    fs_dist_t D = dist_context("cbcsr_A_mul_B");
+    EntryP e = lookup(A, kDist, mix(5, h), [&](Entry &n) {
+      std::vector<int> rp((size_t)A->nrow + 1, 0), cc((size_t)A->nnz);
+      for (int r = 0; r < A->nrow; ++r) {
+        int64_t o = rp[(size_t)r];
+        for (int b = 0; b < A->nblocks; ++b) {
+          const int64_t cell = (int64_t)b * A->nrow + r;
+          const int lo = A->row_ptr[cell], hi = A->row_ptr[cell + 1];
+          if (hi > lo) memcpy(cc.data() + o, A->cols + lo, sizeof(int) * (size_t)(hi - lo));
+          o += hi - lo;
+        }
+        rp[(size_t)r + 1] = (int)o;
+      }
+      n.dm = fs_dist_csr_create(D, A->nrow, A->ncol, A->nnz, rp.data(), cc.data(), nullptr);
+    }, "cbcsr_A_mul_B");
+    dist_mul(e->dm, false, y, x, 1, "cbcsr_A_mul_B");
+    return;
+  }
   EntryP e = lookup(A, kDirect, h, [&](Entry &n) {
     n.cb = fs_cbcsr_create(A->nrow, A->ncol, A->nblocks, A->colblocksize, A->row_ptr, A->cols, FS_HOST);
   }, "cbcsr_A_mul_B");

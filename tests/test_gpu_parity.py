@@ -1974,6 +1974,23 @@ print("OK")
         assert p.returncode == 0 and "OK" in p.stdout, (mode, p.stdout[-1500:] + p.stderr[-1500:])
 
 
+_NGPU3 = {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}
+
+
+@pytest.mark.parametrize("mode", ["golden", "resident"])
+def test_every_dropin_entry_point_across_three_ranks(hip, mode):
+    """FASTSPARSE_NGPU=3 FASTSPARSE_DEVICES=0,0,0 routes EVERY product entry point of sparse.h / dsparse.h /
+    csr.h / cbcsr.h / cg.h through the row-sharded path (fs_dropin.hip "several GPUs" -> fs_dist.hip).  `golden`: all golden cases
+    through HipDropinBackend with host vectors, the single-GPU bars (bit-exact for pattern matrices with integer x, 1e-12 row-scaled
+    otherwise, y pre-poisoned), every output proven to come from sharded products (fs_debug_dist_products).  `resident`: x / y in
+    HBM -- read in place and written by the unpack launch, never staged through the host.  tests/_dropin_ngpu.py is the child."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dropin_ngpu.py")
+    p = subprocess.run([sys.executable, child, mode], env=dict(os.environ, **_NGPU3), capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and p.stdout.rstrip().endswith("OK"), (mode, p.stdout[-3000:] + p.stderr[-3000:])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("valued", [True, False])
 def test_products_with_host_vectors_overlap_copies(hip, valued):
@@ -2453,6 +2470,32 @@ def test_the_references_own_test_program_passes_on_the_product_library(hip, tmp_
     p = subprocess.run([exe], cwd=_data_dir(tmp_path), capture_output=True, text=True, timeout=600)
     out = p.stdout + p.stderr
     assert p.returncode == 0 and "ALL TESTS PASSED" in out and "Tests run: 29" in out, out[-2000:]
+
+
+def test_the_references_own_test_program_passes_across_three_ranks(hip, tmp_path):
+    """the same binary with FASTSPARSE_NGPU=3 FASTSPARSE_DEVICES=0,0,0: all 29 of the reference's tests with every product on the
+    row-sharded path (three virtual ranks on this GPU); FS_TRACE_DIST=1 makes the library report how many sharded products it ran"""
+    import subprocess
+    exe = _ref_caller("test_sparse_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_sparse_hip was not built (no /root/reference where build() ran)")
+    cwd = _data_dir(tmp_path)
+    p = subprocess.run([exe], cwd=cwd, env=dict(os.environ, FS_TRACE_DIST="1", **_NGPU3), capture_output=True, text=True,
+                       timeout=900)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "ALL TESTS PASSED" in out and "Tests run: 29" in out, out[-2000:]
+    import re
+    m = re.search(r"\[fastsparse\] (\d+) sharded products on 3 ranks", out)
+    assert m and int(m.group(1)) >= 30, out[-2000:]
+    # and the reference's harness, every section, incl. the two host threads of "[2x cg2]" sharing the context
+    exe = _ref_caller("bench_a_mul_b_hip")
+    if os.path.exists(exe):
+        p = subprocess.run([exe, "-f", "data/sbm-100-50.data", "-r", "-c"], cwd=cwd, env=dict(os.environ, **_NGPU3),
+                           capture_output=True, text=True, timeout=900)
+        out = p.stdout + p.stderr
+        assert p.returncode == 0, out[-2000:]
+        for label in ("[unsorted]", "[block]", "[cg2]", "[csr]", "[cg8**-csr]", "[BlockCG2]\tniter:", "[2x cg2]"):
+            assert label in out, (label, out[-2000:])
 
 
 def test_the_references_own_bench_harness_runs_on_the_product_library(hip, tmp_path):
