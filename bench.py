@@ -488,10 +488,12 @@ def _klabel(ka, kt=None):
 
 
 def _traffic(kernels, workload, rows, per):
-    """PMC traffic per product (profiles/traffic_<workload>_<kernel>.json, measured on this workload): the mean over the
-    step's products"""
+    """PMC traffic per product: NOT measured by this run (counters need rocprofv3 --pmc passes of their own) -- the mean over the
+    step's products of profiles/traffic_<workload>_<kernel>.json, which tools/refresh_traffic.py writes from a round's PMC run of
+    this same command; the file's round and source ride along (roofline.traffic_from_profiles)"""
+    global _TRAFFIC_SOURCE
     try:
-        vals_ = []
+        vals_, src = [], []
         for kn in kernels:
             name = "traffic_spmv_%s.json" % kn.replace("-", "_") if workload == "c2" else \
                    "traffic_%s_%s.json" % (workload, kn.replace("-", "_"))
@@ -499,9 +501,15 @@ def _traffic(kernels, workload, rows, per):
             if tj.get("rows") != rows or tj.get("per_row") != per:
                 raise ValueError("traffic file is for another workload")
             vals_.append(float(tj["hbm_bytes_per_launch"]))
+            src.append({"file": "profiles/" + name, "round": tj.get("round"), "pmc_summary": tj.get("source")})
+        _TRAFFIC_SOURCE = src
         return sum(vals_) / len(vals_)
     except Exception:
+        _TRAFFIC_SOURCE = None
         return None
+
+
+_TRAFFIC_SOURCE = None
 
 
 def _roofline(kernel, achieved, traffic, alg_bytes, avg_ms, launches, traffic_file=None):
@@ -511,11 +519,114 @@ def _roofline(kernel, achieved, traffic, alg_bytes, avg_ms, launches, traffic_fi
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
          "avg_launch_ms": avg_ms, "launches_timed": launches}
     if traffic:
+        r["traffic_from_profiles"] = {"measured_by_this_run": False, "files": _TRAFFIC_SOURCE,
+                                      "how": "rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE per launch), tools/refresh_traffic.py"}
         r["design_ceiling_frac"] = alg_bytes / traffic * HBM_COPY_GBS / HBM_PEAK_GBS
         r["frac_of_design_ceiling"] = r["frac"] / r["design_ceiling_frac"]
         r["design_ceiling_source"] = ("algorithmic bytes / PMC traffic of the kept kernel (%s) x 6.29 TB/s copy rate "
                                       "(MI355X_MICROARCH.md) / 8 TB/s" % (traffic_file or "profiles/traffic_*.json"))
     return r
+
+
+def one_time_costs(handles, what, products_per_step=1):
+    """What an unmodified caller's FIRST call pays and what the result holds: per handle the phases of
+    fs_matrix_build_ms -- arrays into HBM + validation, ordering, schedule, every candidate copy built, the candidates timed, the
+    losers freed -- the HBM the handle holds afterwards, and the break-even: products after which the kept copy has paid for the
+    one-time work against the kernel that needs no copy (the chunk-streaming kernel, timed by the builder on the same matrix).
+    The reference's one-time step is new_csr / new_bcsr (csr.h:375-422, 30-67).  `handles`: [(label, Matrix, transposed)]."""
+    out = {"what": what}
+    total_ms = saved = 0.0
+    held = [0, 0, 0]
+    seen = set()
+    for label, M, tr in handles:
+        try:
+            b = M.build_ms(tr)
+            c = M.candidate_ms(tr)
+            b["total_ms"] = round(sum(b.values()), 3)
+            kept = M.kernel_name(tr)
+            kept_ms = c.get(kept, 0.0)
+            b["kept"] = kept
+            b["builder_timed_ms"] = c
+            if kept != "stream" and c.get("stream", 0) > 0 and kept_ms > 0:
+                b["saves_ms_per_product_vs_no_copy"] = round(c["stream"] - kept_ms, 4)
+                saved += c["stream"] - kept_ms
+            total_ms += b["total_ms"]
+            out[label] = b
+            if id(M) not in seen:
+                seen.add(id(M))
+                for i, v in enumerate(M.device_bytes()):
+                    held[i] += v
+        except Exception as ex:
+            out[label] = {"error": repr(ex)}
+    out["build_s"] = round(total_ms * 1e-3, 4)
+    out["hbm_held_bytes"] = dict(zip(("csr_and_schedule", "kept_single_vector_copy", "k_column_copies_and_scratch"), held))
+    out["hbm_held_bytes"]["total"] = sum(held)
+    # one step = one product per handle listed: the copies together save `saved` ms per step
+    out["break_even_steps"] = round(total_ms / saved, 1) if saved > 0 else None
+    out["break_even_products"] = round(total_ms / saved * len(handles), 1) if saved > 0 else None
+    return out
+
+
+def rccl_info(prov, world, rank, nccl, backend):
+    """Proof in the line that the group really had N ranks on N devices: the rank count by an all-reduce of
+    ones over the group, every rank's device index / PCI bus id / name (all-gathered), the RCCL version torch was built with"""
+    import torch
+    import torch.distributed as dist
+    cdev = prov.dev if nccl else "cpu"
+    ones = torch.ones(1, dtype=torch.float64, device=cdev)
+    dist.all_reduce(ones)
+    me = {"rank": rank, "pid": os.getpid()}
+    try:
+        pr = torch.cuda.get_device_properties(prov.dev)
+        me.update({"device_index": prov.dev.index, "name": pr.name,
+                   "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff, getattr(pr, "pci_device_id", 0)),
+                   "uuid": str(getattr(pr, "uuid", ""))})
+    except Exception as ex:
+        me["device_error"] = repr(ex)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if nccl else None
+    except Exception:
+        pass
+    return {"backend": "nccl (RCCL over xGMI)" if nccl else backend, "ranks_counted_by_all_reduce_of_ones": int(ones.item()),
+            "world_size": world, "ranks": everyone, "rccl_version": ver,
+            "distinct_devices": len({(r or {}).get("pci_bus_id", (r or {}).get("rank")) for r in everyone})}
+
+
+class ExchangeFault(RuntimeError):
+    """the exchange inside the product disagreed with the plain one (verify_overlap) and --strict-exchange asked for a loud stop"""
+
+    def __init__(self, info):
+        RuntimeError.__init__(self, "overlapped exchange disagrees with the whole-shard all-gather: %r" % (info,))
+        self.info = info
+
+
+def error_record(ex, args, world, rank):
+    """the OTHER shape of the line (N > 1 only): what went wrong, where, and how to tell an exchange fault from a kernel fault"""
+    import traceback
+    tb = traceback.format_exception(type(ex), ex, ex.__traceback__)
+    return {"metric": METRIC, "value": None, "unit": "GB/s", "n_gpus": world, "error": repr(ex), "error_rank": rank,
+            "error_kind": "exchange_fault" if isinstance(ex, ExchangeFault) else "exception in the headline workload",
+            "exchange_fault": getattr(ex, "info", None),
+            "exchange": {"parts": args.parts, "mode": "conservative" if args.parts <= 1 else "overlapped", "how": getattr(args, "exchange", "allgather")},
+            "traceback_tail": "".join(tb).splitlines()[-6:],
+            "hint": "--parts 1 runs the conservative exchange (one whole-shard all-gather behind the local product): a line that fails "
+                    "with --parts 4 and passes with --parts 1 points at the overlapped exchange, not at the kernels"}
+
+
+def _exchange_fault(exchange_check, args):
+    """None, or what verify_overlap found: which vector, the part / rank / row range of the first bad segment"""
+    bad = {k: v for k, v in (exchange_check or {}).items() if v.get("checked") and v.get("mode") == "conservative"}
+    if not bad:
+        return None
+    fault = {"vectors": bad, "parts": args.parts,
+             "consequence": "every rank switched to ONE whole-shard all-gather behind the finished local product for these operators; the "
+                            "numbers of this line are the conservative exchange's"}
+    if getattr(args, "strict_exchange", False):
+        raise ExchangeFault(fault)
+    return fault
 
 
 def _same_on_all_ranks(values, dev_or_cpu):
@@ -559,33 +670,66 @@ def fixed_order_cost(prov, capi, products, kernel_name, how):
         return {"error": repr(ex)}
 
 
-def config2_bound(alg_bytes):
-    """Why 0.60 of peak is out of reach on config 2, as numbers in the line.  Uniformly random columns over an
-    80 MB x leave two ways to touch x[col]: (a) ONE cache-line request per non-zero -- the chip answers at most ~250 G of them per
-    second even when every one hits L2 (profiles/r01_probe_gather.jsonl: 160 M gathers from an L2-resident window take 0.61-0.67 ms,
-    2.9 ms from the whole 80 MB table), next to which the 12-byte entry stream has to run (0.31 ms at the copy rate); the two were
-    measured NOT to overlap in a kernel with an LDS-resident y slice (probe_mix, DESIGN.md "gather ceiling"), but even perfectly
-    overlapped the gathers alone bound the product; or (b) no gathers at all -- every random access in LDS, which costs a pass
-    over an intermediate: 28 bytes per entry (the kept two-pass pair), 2.33 x the algorithmic bytes."""
-    gather_floor_ms = 0.606                     # 160 M L2-hit gathers, best of profiles/r04_probe_gather.jsonl ("tiled", 0.26 MB window; r01: 0.606)
+def config2_bound(alg_bytes, prov=None):
+    """Why 0.60 of peak is out of reach on config 2, as numbers in the line (r4 item 2a: MEASURED BY THIS RUN).
+    Uniformly random columns over an 80 MB x leave two ways to touch x[col]: (a) ONE cache-line request per non-zero -- the chip
+    answers at most ~250 G of them per second even when every one hits L2, next to which the 12-byte entry stream has to run
+    (0.31 ms at the copy rate); the two do not overlap in one kernel; or (b) no gathers at all -- every random access in LDS, which
+    costs a pass over an intermediate: 28 bytes per entry (the kept two-pass pair), 2.33 x the algorithmic bytes.
+    The gather and gather + stream times come from the library's own probes (csrc/fs_probes.hip: fs_debug_probe_gather /
+    fs_debug_probe_mix, millisecond kernels run here, after the timed region); where a probe cannot run the numbers of earlier
+    rounds are quoted under names that say so (*_from_profiles)."""
+    import ctypes as C
+    live, err = {}, None
+    try:
+        L = prov.capi.lib()
+        L.fs_debug_probe_gather.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.fs_debug_probe_mix.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        ms = C.c_float(0)
+        n, table = 160_000_000, 80 << 20
+        prov.synchronize()
+        best = None
+        for window in (256 << 10, 1 << 20, 2 << 20):            # L2-hit gathers: per-XCD windows of an 80 MB table
+            prov.capi.check(L.fs_debug_probe_gather(n, table, window, 64, 5, C.byref(ms)), "fs_debug_probe_gather")
+            live["gather_l2_window_%dKiB_ms" % (window >> 10)] = float(ms.value)
+            best = float(ms.value) if best is None else min(best, float(ms.value))
+        live["gather_floor_ms"] = best
+        prov.capi.check(L.fs_debug_probe_gather(n, table, table, 1, 5, C.byref(ms)), "fs_debug_probe_gather")
+        live["gather_uniform_over_80MB_ms"] = float(ms.value)       # what a plain CSR kernel's gathers cost: one fabric request each
+        prov.capi.check(L.fs_debug_probe_mix(n, 2 << 20, 256, 0, 5, C.byref(ms)), "fs_debug_probe_mix")
+        live["gathers_plus_stream_measured_ms"] = float(ms.value)   # small workgroups, no y at all
+        prov.capi.check(L.fs_debug_probe_mix(n, 2 << 20, 1024, 256, 5, C.byref(ms)), "fs_debug_probe_mix")
+        live["gathers_plus_stream_one_workgroup_per_cu_ms"] = float(ms.value)   # the shape an LDS-resident y slice forces
+    except Exception as ex:
+        live, err = {}, repr(ex)
+    measured = "gather_floor_ms" in live
+    gather_floor_ms = live["gather_floor_ms"] if measured else 0.606
     stream_floor_ms = 1.92e9 / (HBM_COPY_GBS * 1e9) * 1e3     # the 12-byte entry stream at the copy rate
     overlapped = max(gather_floor_ms, stream_floor_ms)
     two_pass_floor_ms = (28.0 * 160e6 + 2 * 8e7 + 4e7) / (HBM_COPY_GBS * 1e9) * 1e3
+    mix_ms = live.get("gathers_plus_stream_measured_ms")
     best = min(overlapped, two_pass_floor_ms)
-    return {"gather_floor_ms": gather_floor_ms, "stream_floor_ms": stream_floor_ms,
-            "gather_kernel_ceiling_frac": alg_bytes / (overlapped * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "gather_kernel_ceiling_if_not_overlapped_frac": alg_bytes / ((gather_floor_ms + stream_floor_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "two_pass_floor_ms": two_pass_floor_ms,
-            "any_kernel_ceiling_frac": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "gathers_plus_stream_measured_ms": 0.772,      # probe_mix: the gathers AND the 12-byte stream in one kernel, no y at all
-            "bound_sources": ["profiles/r04_probe_gather.jsonl, r01_probe_gather.jsonl (L2-hit gather rate: 0.606-0.69 ms for 160 M)",
-                              "profiles/r04_probe_mix.jsonl, r01_probe_mix.jsonl (gathers + stream in one kernel: 0.77-0.84 ms with small "
-                              "workgroups, 0.91-1.06 ms with the one-workgroup-per-CU shape an LDS-resident y slice forces: not overlapped)", "profiles/r02_probe_hybrid_cu_mask.jsonl, r04_probe_overlap.jsonl (gather role and "
-                              "stream role side by side, on disjoint CUs or in one launch: the SUM of their times, no overlap)", "profiles/r01_probe_mall.jsonl (intermediate through the Infinity Cache: x 1.3 only)",
-                              "MI355X_MICROARCH.md (6.29 TB/s copy rate)"],
-            "bound_statement": "uniform-random columns over an 80 MB x: measured, this algorithm's ceiling (design_ceiling_frac) and the "
-                               "ceiling of any exact-fp64 kernel on this chip (any_kernel_ceiling_frac); the 0.60 target needs 364 G "
-                               "gathers/s or 14 bytes per entry"}
+    rec = {"bounds_measured_by_this_run": measured,
+           "gather_kernel_ceiling_frac": alg_bytes / (overlapped * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "gather_kernel_ceiling_if_not_overlapped_frac": alg_bytes / ((gather_floor_ms + stream_floor_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "stream_floor_ms_at_copy_rate": stream_floor_ms, "two_pass_floor_ms_at_copy_rate": two_pass_floor_ms,
+           "any_kernel_ceiling_frac": alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "copy_rate_GBs_from_guide": HBM_COPY_GBS,
+           "bound_statement": "uniform-random columns over an 80 MB x: this algorithm's ceiling (design_ceiling_frac) and the ceiling of any "
+                              "exact-fp64 kernel on this chip (any_kernel_ceiling_frac: the better of perfectly overlapped L2-hit gathers "
+                              "and 28 bytes per entry at the copy rate); the 0.60 target needs 364 G gathers/s or 14 bytes per entry"}
+    if measured:
+        rec.update(live)
+        rec["gather_kernel_as_measured_frac"] = alg_bytes / (mix_ms * 1e-3) / 1e9 / HBM_PEAK_GBS   # gathers + stream in ONE kernel, no y
+        rec["bound_sources"] = ["libfastsparse_amd/csrc/fs_probes.hip, run by this process after the timed region (160 M gathers per launch, "
+                                "median of 5)", "MI355X_MICROARCH.md (6.29 TB/s copy rate)",
+                                "not re-run here: profiles/r04_probe_overlap.jsonl, r02_probe_hybrid_cu_mask.jsonl (gather role and stream role "
+                                "side by side take the SUM of their times), r01_probe_mall.jsonl"]
+    else:
+        rec.update({"gather_floor_ms_from_profiles": 0.606, "gathers_plus_stream_ms_from_profiles": 0.772,
+                    "from_profiles": {"files": ["profiles/r04_probe_gather.jsonl", "profiles/r04_probe_mix.jsonl"], "round": 4,
+                                      "why_not_measured": err}})
+    return rec
 
 
 def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
@@ -654,11 +798,12 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     z = prov.empty(ncol)
     # first contact: is the exchange inside the product sound on this fabric?  (it never ran on more than one RCCL rank before
     # the driver's run; an operator whose overlapped and plain exchanges disagree falls back to the plain one, on every rank)
-    exchange_check = None
+    exchange_check = fault = None
     if _multi(world):
         exchange_check = {"y": op_a.verify_overlap(y, x, nparts)}
         if z_scheme == "gather":
             exchange_check["z"] = op_t.verify_overlap(z, u, nparts)
+        fault = _exchange_fault(exchange_check, args)        # --strict-exchange: raises on every rank (the verdict is collective)
 
     def step(ev=None, exchange=True):
         """N = 1: A x, A' u.  N > 1, the iterating consumer's order (cg.h:15-16): [A x in parts, the all-gather of the finished
@@ -802,6 +947,12 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
                                  "the same handle with option reproducible = 1: pass 2 of the two-pass pair then runs one wave per panel "
                                  "and adds in stream order (bit-identical run to run); ten products each")
 
+    rccl = per_rank = None
+    if _multi(world):       # collective: every rank takes part, rank 0 keeps the answer
+        rccl = rccl_info(prov, world, rank, nccl, os.environ.get("FS_BENCH_BACKEND", "nccl"))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "local_products_GBs": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+                                          "avg_local_product_ms": avg_ms})
     if rank != 0:
         return None
     stream_gbs = stream_probe(prov) if hasattr(prov, "torch") else None
@@ -813,7 +964,10 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     else:
         what = ("%s: CSR %d x %d, %d rows/GPU, %d nnz/row, step = (A_mul_B in %d parts with the all-gather of y inside the product) "
                 "then (At_mul_B, %s)" % ("BASELINE config 2 cut over %d GPUs (strong scaling)" % world if strong else
-                                         "config-2 shards, weak scaling by rows", n_global, ncol, n_local, per, nparts,
+                                         "config-2 shards, WEAK scaling by rows with x fixed at %d columns: every rank receives %.0f MB of y "
+                                         "per product (y all-gather = 8 B x %d rows x (N - 1) ranks) next to a ~0.9 ms local product, so the "
+                                         "curve is exchange-bound by construction, not a kernel regression" % (ncol, 8e-6 * (n_global - n_local), n_local),
+                                         n_global, ncol, n_local, per, nparts,
                                          "row shards of A' + all-gather of z inside the product" if z_scheme == "gather" else
                                          "local A_r' u_r + all-reduce of z"))
     traffic = _traffic((kname, kname_t), "c2", n_local, per) if not _multi(world) else None
@@ -838,8 +992,14 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    if hasattr(A, "build_ms"):
+        rec["config"]["one_time"] = one_time_costs(
+            [("A", A, False), ("At", At, False) if z_scheme == "gather" else ("At", A, True)],
+            "device arrays in (borrowed in place: phase 0 is validation only; a drop-in caller adds the PCIe upload of 12 B per entry); "
+            "A' = fs_matrix_build_transpose (device sort by column) or, at N > 1, this rank's row shard of A' from exchanged entries; "
+            "one step = A x + A' u")
     if not _multi(world) and not strong and n_global == 10_000_000 and per == 16:
-        rec["roofline"].update(config2_bound(bytes_per_launch))
+        rec["roofline"].update(config2_bound(bytes_per_launch, prov))
     if _multi(world):
         rec["config"].update({
             "exchange_check": exchange_check,
@@ -852,6 +1012,14 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
                              "z_all_reduce_ring": 2.0 * F8 * (world - 1) / world}},
             "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
             "rccl_status": "first contact: no multi-GPU machine was available to the builder; numbers above are the driver's"})
+        rec["config"]["exchange"].update({"parts": nparts, "mode": "conservative (one whole-shard all-gather behind the local product)"
+                                          if nparts <= 1 or (exchange_check or {}).get("y", {}).get("mode") == "conservative"
+                                          else "overlapped (the all-gather of part p under part p + 1)"})
+        rec["rccl"] = rccl
+        rec["per_rank"] = per_rank
+        rec["aggregate_frac_of_hbm_peak"] = value / (HBM_PEAK_GBS * world)
+        if fault:
+            rec["exchange_fault"] = fault
     if not _multi(world) and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
             rec["cpu_baseline"] = cpu_baseline_c2(n_local, ncol, per)
@@ -968,6 +1136,11 @@ def run_c3(args, prov, world, rank, nccl):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    rec["config"]["one_time"] = one_time_costs(
+        [("A", A, False), ("At", At, False)],
+        "COO arrays already in HBM -> fs_coo_create twice (A from (rows, cols), A' from (cols, rows)): validation, stable device sort by "
+        "row, every candidate copy built, timed, the losers freed; wall seconds per handle in device_coo_to_csr_and_format_s; a "
+        "drop-in caller adds the PCIe upload of 8 B per entry per handle; one step = A_mul_B + At_mul_B")
     if not args.no_cpu_baseline:
         try:
             rec["cpu_baseline"] = cpu_baseline_c3(nrow, ncol, per, sample_rows=args.cpu_sample_rows or 2_500_000)
@@ -1062,6 +1235,12 @@ def run_c4(args, prov, world, rank, nccl):
     }
     rec["config"]["hbm_held_by_the_handle_bytes"] = dict(zip(("csr_and_schedule", "kept_single_vector_copy", "k_column_copies_and_scratch"),
                                                              A.device_bytes()))
+    rec["config"]["one_time"] = one_time_costs(
+        [("A", A, False)], "device arrays in (borrowed); k = 32 runs on the row kernel and needs no copy of its own (the single-vector copy "
+                           "the builder keeps serves k <= 4 and the solvers); the k-column copies of k = 2 / 4: small_k[*].prepare_s")
+    released = A.release_prepared(0)
+    rec["config"]["hbm_held_after_release_prepared_bytes"] = dict(zip(("csr_and_schedule", "kept_single_vector_copy", "k_column_copies_and_scratch"),
+                                                                      A.device_bytes()), released=released)
     if not args.no_cpu_baseline:
         try:
             rec["cpu_baseline"] = cpu_baseline_c4(n, per, k, sample_rows=args.cpu_sample_rows or 400_000)
@@ -1170,11 +1349,12 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         if float(ok_t.item()) == 0.0 and opt is not None:
             opt, t_err = None, "another rank could not build its shard of A'"
 
-    exchange_check = None
+    exchange_check = fault = None
     if _multi(world):
         exchange_check = {"y": op.verify_overlap(y, x, nparts)}
         if opt is not None:
             exchange_check["z"] = opt.verify_overlap(z, u, nparts)
+        fault = _exchange_fault(exchange_check, args)
 
     def step(ev=None, exchange=True, transpose=False):
         if not _multi(world):
@@ -1258,6 +1438,37 @@ def run_c5(args, prov, world, rank, nccl, out=None):
                 del y1
             finally:
                 prov.capi.set_option("reproducible", 0)
+    # what the handle holds, and what is left once the plain CSR is given back: the products of this matrix run on
+    # the kept copy alone; strict_order -- the self-check above -- was the last user of the plain arrays
+    release = None
+    if hasattr(A, "release_csr") and not _multi(world):
+        try:
+            import torch
+            before = A.device_bytes()
+            free0 = torch.cuda.mem_get_info()[0]
+            kn0 = prov.kernel_name(A)
+            n_rel = A.release_csr()
+            del rp, cc, vv                        # the borrowed arrays are the caller's: now they can go
+            prov.trim()
+            free1 = torch.cuda.mem_get_info()[0]
+            after = A.device_bytes()
+            y_chk = prov.empty(n_local)
+            prov.spmv(A, y_chk, x)                 # still the same product
+            same = bool(((y_chk - (y[lo:hi] if _multi(world) else y)).abs() <= 1e-12 * lens).all())
+            release = {"sides_released": n_rel, "kernel": kn0, "hbm_held_bytes_before": {"caller_csr_arrays_borrowed": 16 * nnz - 4 * nnz + 4 * (n_local + 1),
+                                                                                      "handle": sum(before)},
+                       "hbm_held_bytes_after": {"caller_csr_arrays_borrowed": 0, "handle": sum(after)},
+                       "device_memory_freed_bytes": int(free1 - free0), "handle_over_its_copy": sum(after) / max(after[1], 1),
+                       "product_after_release_matches": same}
+            del y_chk
+        except Exception as ex:
+            release = {"error": repr(ex)}
+    per_rank = rccl = None
+    if _multi(world):
+        rccl = rccl_info(prov, world, rank, nccl, os.environ.get("FS_BENCH_BACKEND", "nccl"))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "rows": n_local, "nnz": nnz, "local_A_mul_B_ms": local_ms,
+                                          "frac_of_hbm_peak": bytes_local / (local_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     if rank != 0:
         return None
     kname = prov.kernel_name(A)
@@ -1285,9 +1496,18 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    if hasattr(A, "build_ms"):
+        rec["config"]["one_time"] = one_time_costs([("A", A, False)], "this rank's shard: device arrays in (borrowed), candidates built and timed")
+    if release is not None:
+        rec["config"]["release_csr"] = release
     if _multi(world):
         rec["config"]["rccl_status"] = "first contact: no multi-GPU machine was available to the builder"
         rec["config"]["exchange_check"] = exchange_check
+        rec["config"]["exchange"] = {"parts": nparts, "mode": "conservative" if nparts <= 1 or exchange_check["y"].get("mode") == "conservative" else "overlapped"}
+        rec["rccl"], rec["per_rank"] = rccl, per_rank
+        rec["aggregate_frac_of_hbm_peak"] = value / (HBM_PEAK_GBS * world)
+        if fault:
+            rec["exchange_fault"] = fault
     if not _multi(world) and not args.no_cpu_baseline and hasattr(prov, "capi"):
         try:
             rec["cpu_baseline"] = cpu_baseline_c5(lo, ncol, sample_rows=args.cpu_sample_rows or 1_000_000)
@@ -1527,6 +1747,10 @@ def main():
                          "every peer (no padding, no unpack) -- to be A/B'ed on a machine with more than one GPU")
     ap.add_argument("--z-scheme", default="gather", choices=["gather", "reduce"],
                     help="c2, N > 1: z = A'u by row shards of A' + all-gather (default) or local A_r'u_r + all-reduce")
+    ap.add_argument("--strict-exchange", action="store_true",
+                    help="N > 1: when the exchange inside the product disagrees with the plain whole-shard all-gather (verify_overlap, before "
+                         "the timed loops) print ONE JSON line with \"error\" and the failing part / rank / row range and exit 3; default: "
+                         "say so in the line (exchange_fault), switch every rank to the conservative exchange and measure that")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproducible-cost", action="store_true", help="c2: skip timing the products with fixed-order sums")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baselines' samples (0: the workload's default)")
@@ -1585,7 +1809,17 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ.get("FS_BENCH_BUDGET_S", "480")), repeat=False, exit=True)
     if args.workload in ("all", "c2"):
-        rec = run_c2(args, prov, world, rank, nccl, strong=args.strong)
+        try:
+            rec = run_c2(args, prov, world, rank, nccl, strong=args.strong)
+        except Exception as ex:
+            if not _multi(world):
+                raise
+            # first contact with RCCL on more than one GPU must be cheap to diagnose: ONE line, from whichever
+            # rank met the error (rank 0 may be waiting in a collective: the launcher ends it), a normal exit path, no retry
+            emit(error_record(ex, args, world, rank))
+            sys.stdout.flush()
+            sys.stderr.write("bench.py: rank %d: %r\n" % (rank, ex))
+            os._exit(3)
         if _multi(world) and not os.environ.get("FS_BENCH_WATCHDOG"):
             import faulthandler
             faulthandler.cancel_dump_traceback_later()      # the headline exists: from here on the budget watchdog prints it

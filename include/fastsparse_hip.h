@@ -46,7 +46,8 @@ enum fs_status {
   FS_ERR_HIP = -1,        /* a HIP runtime call failed (message has the HIP error string) */
   FS_ERR_ARG = -2,        /* bad argument (NULL handle, negative size, k < 1, ...)          */
   FS_ERR_NO_DEVICE = -3,  /* no gfx950 device visible                                        */
-  FS_ERR_NO_TRANSPOSE = -4 /* transposed product asked for before fs_matrix_build_transpose  */
+  FS_ERR_NO_TRANSPOSE = -4, /* transposed product asked for before fs_matrix_build_transpose */
+  FS_ERR_RELEASED = -5     /* the operation reads the plain CSR arrays, which fs_matrix_release_csr gave back */
 };
 
 enum fs_memspace { FS_HOST = 0, FS_DEVICE = 1 };
@@ -115,6 +116,11 @@ int  fs_matrix_spmv_kernel(fs_matrix_t A, int transposed);
  * [0] the chunk-streaming kernel, [1] the L2-tiled kernel, [2] the LDS-staged tiled kernel, [3] the two-pass pair;
  * 0 for a candidate that was not built (ruled out by the estimates, or the matrix is small) */
 int  fs_matrix_candidate_ms(fs_matrix_t A, int transposed, float *ms4);
+/* where the one-time work of the matrix (transposed != 0: of its A') went, ms of host wall time: [0] arrays into HBM + validation,
+ * [1] ordering (COO -> CSR; the transpose), [2] chunk schedule, [3] two-pass copy built, [4] L2-tiled copy built, [5] LDS-staged copy
+ * built, [6] candidates timed, [7] losers freed + scratch trimmed.  The reference's one-time step is new_csr / new_bcsr (csr.h:375-422,
+ * 30-67); fs_matrix_device_bytes says what the result holds. */
+int  fs_matrix_build_ms(fs_matrix_t A, int transposed, float *ms8);
 int  fs_matrix_nrow(fs_matrix_t A);
 int  fs_matrix_ncol(fs_matrix_t A);
 int64_t fs_matrix_nnz(fs_matrix_t A);
@@ -170,6 +176,21 @@ int fs_matrix_spmm_plan(fs_matrix_t A, int k, int transposed);
 /* HBM the handle holds (A and, once built, A'), in bytes: [0] the CSR arrays it owns + chunk schedule, [1] the kept
  * single-vector copy (two-pass incl. its product stream / L2-tiled / LDS-staged), [2] k-column copies and multi-column scratch */
 int fs_matrix_device_bytes(fs_matrix_t A, int64_t *bytes3);
+/* Give back what the handle no longer needs.  fs_matrix_release_csr: once the format builder has KEPT a re-ordered copy (two-pass,
+ * LDS-staged or L2-tiled) the products run on it alone; the plain row_ptr / cols / vals -- owned arrays are freed, borrowed arrays
+ * are forgotten so that the caller may free them -- and the chunk schedule are dead weight (config 2: 1.96 of 5.3 GB; a config-5
+ * shard: 4.8 of 12.9 GB).  Applies to A and, when built, A'; returns the number of sides released (0: no kept copy, nothing done).
+ * What still needs the plain arrays afterwards fails with FS_ERR_RELEASED: strict_order and spmv_kernel 1 / 2 / 3 products, the row
+ * kernel of multi-column products (k >= 5 on two-pass matrices, k > 16), fs_matrix_prepare for a new k, fs_matrix_build_transpose,
+ * fs_matrix_download, the fused A'A kernel, and option "reproducible" on an LDS-staged copy that is not orderable.
+ * fs_matrix_restore_csr hands the same arrays back (same meaning of space / borrow as fs_csr_create; they are NOT validated or
+ * compared again) -- "rebuild on demand" is the caller's: the re-ordered copies do not keep the storage order of a row.
+ * Option "release_csr" (FS_RELEASE_CSR, default 0) = 1 releases at the end of fs_csr_create / fs_coo_create /
+ * fs_matrix_build_transpose; the drop-in layer never releases (its callers keep the host arrays, and call any entry point next).
+ * fs_matrix_release_prepared: the k-column copy and scratch fs_matrix_prepare made for k (0: for every k), on A and A'. */
+int fs_matrix_release_csr(fs_matrix_t A);
+int fs_matrix_restore_csr(fs_matrix_t A, int transposed, const int *row_ptr, const int *cols, const double *vals, int space, int borrow);
+int fs_matrix_release_prepared(fs_matrix_t A, int k);
 /* y[ncol] = A'A x[ncol]; tmp is caller scratch of nrow doubles in HBM   (bcsr_AA_mul_B, parallel_bcsr_AA_mul_B) */
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream);
 

@@ -10,7 +10,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libfastsparse_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["fs_kernels.hip", "fs_kernels_tiled.hip", "fs_kernels_twopass.hip", "fs_format.hip", "fs_abi.hip", "fs_dropin.hip", "fs_cg.hip", "fs_dist.hip"]
+HIP_SOURCES = ["fs_probes.hip", "fs_kernels.hip", "fs_kernels_tiled.hip", "fs_kernels_twopass.hip", "fs_format.hip", "fs_abi.hip", "fs_dropin.hip", "fs_cg.hip", "fs_dist.hip"]
 C_SOURCES = ["fs_host.c", "fs_sort.c"]
 HEADERS = [os.path.join(CSRC, "fs_common.h"), os.path.join(CSRC, "fs_kernel_util.h")] + [os.path.join(ROOT, "include", h) for h in
                                                  ("fastsparse_hip.h", "sparse.h", "dsparse.h", "csr.h", "cbcsr.h", "cg.h", "linalg.h", "hilbert.h", "quickSort.h", "quickSortD.h")]

@@ -22,7 +22,8 @@ _lib = None
 DEVICE_API = [
     "fs_version", "fs_last_error", "fs_device_count", "fs_set_device", "fs_set_option", "fs_get_option",
     "fs_device_alloc", "fs_device_free", "fs_copy_to_device", "fs_copy_to_host", "fs_device_synchronize",
-    "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel", "fs_matrix_candidate_ms",
+    "fs_csr_create", "fs_coo_create", "fs_matrix_destroy", "fs_matrix_build_transpose", "fs_matrix_has_transpose", "fs_matrix_spmv_kernel", "fs_matrix_candidate_ms", "fs_matrix_build_ms",
+    "fs_matrix_release_csr", "fs_matrix_restore_csr", "fs_matrix_release_prepared",
     "fs_matrix_prepare", "fs_matrix_spmm_plan", "fs_matrix_device_bytes", "fs_spmv_part", "fs_spmv_part_rows", "fs_spmm_part", "fs_spmm_part_rows", "fs_copy_segments",
     "fs_matrix_nrow", "fs_matrix_ncol", "fs_matrix_nnz", "fs_matrix_algorithmic_bytes", "fs_matrix_download",
     "fs_spmv", "fs_spmv_t", "fs_spmv_host", "fs_spmv_t_host", "fs_spmm", "fs_spmm_t", "fs_ata_mul", "fs_cg", "fs_cg2", "fs_axpy",
@@ -100,6 +101,10 @@ def lib():
     L.fs_matrix_has_transpose.argtypes = [vp]
     L.fs_matrix_spmv_kernel.argtypes = [vp, C.c_int]
     L.fs_matrix_candidate_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.fs_matrix_build_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.fs_matrix_release_csr.argtypes = [vp]
+    L.fs_matrix_restore_csr.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int]
+    L.fs_matrix_release_prepared.argtypes = [vp, C.c_int]
     L.fs_matrix_prepare.argtypes = [vp, C.c_int, C.c_int, vp]
     L.fs_matrix_spmm_plan.argtypes = [vp, C.c_int, C.c_int]
     L.fs_matrix_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -242,6 +247,36 @@ class Matrix:
         out = (C.c_float * 4)()
         check(lib().fs_matrix_candidate_ms(self.h, int(transposed), out), "fs_matrix_candidate_ms")
         return dict(zip(("stream", "tiled", "lds-staged", "two-pass"), (round(float(v), 4) for v in out)))
+
+    BUILD_PHASES = ("upload_and_validate", "ordering", "chunk_schedule", "two_pass_copy", "l2_tiled_copy", "lds_staged_copy",
+                    "candidates_timed", "losers_freed")
+
+    def build_ms(self, transposed=False):
+        """where the one-time work of this matrix went, ms by phase (fs_matrix_build_ms)"""
+        out = (C.c_float * 8)()
+        check(lib().fs_matrix_build_ms(self.h, int(transposed), out), "fs_matrix_build_ms")
+        return dict(zip(self.BUILD_PHASES, (round(float(v), 3) for v in out)))
+
+    def release_csr(self):
+        """give back the plain CSR arrays once a re-ordered copy is kept (fs_matrix_release_csr); returns the sides released"""
+        n = lib().fs_matrix_release_csr(self.h)
+        if n < 0:
+            check(n, "fs_matrix_release_csr")
+        if n:
+            self._keep = ()
+        return n
+
+    def restore_csr(self, row_ptr, cols, vals=None, transposed=False, borrow=False):
+        check(lib().fs_matrix_restore_csr(self.h, int(transposed), _ptr(row_ptr), _ptr(cols), _ptr(vals), _space(cols), int(borrow)),
+              "fs_matrix_restore_csr")
+        if borrow:
+            self._keep = tuple(self._keep) + (row_ptr, cols, vals)
+
+    def release_prepared(self, k=0):
+        n = lib().fs_matrix_release_prepared(self.h, int(k))
+        if n < 0:
+            check(n, "fs_matrix_release_prepared")
+        return n
 
     SPMM_PLANS = {0: "spmv", 1: "row", 2: "k-column two-pass", 3: "two-pass per column", 4: "mfma", 5: "lds-staged per column",
                   6: "lds-staged strided", 7: "tiled strided"}

@@ -2,12 +2,18 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+
 #include "fs_common.h"
 
 namespace fs {
 
 static thread_local std::string g_err;
 thread_local int tl_fixed_order = 0;
+thread_local int tl_keep_csr = 0;
+static std::atomic<unsigned> g_option_epoch{0};
+unsigned option_epoch() { return g_option_epoch.load(std::memory_order_relaxed); }
 
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -35,6 +41,7 @@ Options &options()
     if (const char *v = getenv("FS_SPMM_WIDE")) q.spmm_wide = atoi(v);
     if (const char *v = getenv("FS_CG_FIXED_ORDER")) q.cg_fixed_order = atoi(v);
     if (const char *v = getenv("FS_DIST_CG_SCHEME")) q.dist_cg_scheme = atoi(v);
+    if (const char *v = getenv("FS_RELEASE_CSR")) q.release_csr = atoi(v);
     return q;
   }();
   return o;
@@ -136,6 +143,8 @@ int fs_device_synchronize(void)
 int fs_set_option(const char *name, int value)
 {
   if (!name) { set_error("fs_set_option: NULL name"); return FS_ERR_ARG; }
+  fs::g_option_epoch.fetch_add(1, std::memory_order_relaxed);
+  if (!strcmp(name, "release_csr")) { fs::options().release_csr = value; return FS_OK; }
   if (!strcmp(name, "strict_order")) { fs::options().strict_order = value; return FS_OK; }
   if (!strcmp(name, "spmv_kernel")) { fs::options().spmv_kernel = value; return FS_OK; }
   if (!strcmp(name, "tiling")) { fs::options().tiling = value; return FS_OK; }
@@ -180,6 +189,7 @@ int fs_get_option(const char *name)
   if (name && !strcmp(name, "device_build")) return fs::options().device_build;
   if (name && !strcmp(name, "cg_fixed_order")) return fs::options().cg_fixed_order;
   if (name && !strcmp(name, "dist_cg_scheme")) return fs::options().dist_cg_scheme;
+  if (name && !strcmp(name, "release_csr")) return fs::options().release_csr;
   return FS_ERR_ARG;
 }
 
@@ -196,6 +206,7 @@ fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, c
   fs::DeviceCsr &A = M->a;
   A.nrow = nrow; A.ncol = ncol; A.nnz = nnz;
   int rc = FS_OK;
+  const auto t0 = std::chrono::steady_clock::now();
   if (space == FS_DEVICE && borrow && fs::aligned16(cols) && (!vals || fs::aligned16(vals))) {
     A.owns = false;
     A.row_ptr = const_cast<int *>(row_ptr);
@@ -208,9 +219,12 @@ fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, c
     if (!rc && vals) rc = fs::to_device(&A.vals, vals, (size_t)nnz, space);
   }
   if (!rc) rc = fs::validate_indices(nrow, ncol, nnz, A.row_ptr, nullptr, A.cols, nullptr);
+  const float up_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();   // (validation ends in a synchronisation)
   if (!rc) rc = fs::build_schedule(A, nullptr);
+  A.build_ms[0] = up_ms;
   fs::pool_trim();
   if (rc) { fs::free_csr(A); delete M; return nullptr; }
+  if (fs::options().release_csr && fs::tl_keep_csr == 0) (void)fs::release_plain_csr(A);
   return M;
 }
 
@@ -227,6 +241,7 @@ fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, cons
   int *r = nullptr, *c = nullptr;
   double *v = nullptr;
   int rc = FS_OK;
+  const auto t0 = std::chrono::steady_clock::now();
   if (space == FS_DEVICE) {
     r = const_cast<int *>(rows); c = const_cast<int *>(cols); v = const_cast<double *>(vals);
   } else {
@@ -235,7 +250,9 @@ fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, cons
     if (!rc && vals) rc = fs::to_device(&v, vals, (size_t)nnz, FS_HOST);
   }
   if (!rc) rc = fs::validate_indices(nrow, ncol, nnz, nullptr, r, c, nullptr);
+  const float up_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!rc) rc = fs::coo_to_csr_device(M->a, nrow, ncol, nnz, r, c, v, nullptr);
+  M->a.build_ms[0] = up_ms;
   if (space != FS_DEVICE) {
     if (r) (void)hipFree(r);
     if (c) (void)hipFree(c);
@@ -243,6 +260,7 @@ fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, cons
   }
   fs::pool_trim();
   if (rc) { fs::free_csr(M->a); delete M; return nullptr; }
+  if (fs::options().release_csr && fs::tl_keep_csr == 0) (void)fs::release_plain_csr(M->a);
   return M;
 }
 
@@ -265,6 +283,7 @@ int fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream)
   fs::pool_trim();
   if (rc) { fs::free_csr(A->at); return rc; }
   A->has_t = true;
+  if (fs::options().release_csr && fs::tl_keep_csr == 0) (void)fs::release_plain_csr(A->at);
   return FS_OK;
 }
 
@@ -284,6 +303,14 @@ int fs_matrix_candidate_ms(fs_matrix_t A, int transposed, float *ms4)
   return FS_OK;
 }
 
+int fs_matrix_build_ms(fs_matrix_t A, int transposed, float *ms8)
+{
+  if (!A || !ms8 || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  for (int i = 0; i < 8; ++i) ms8[i] = a.build_ms[i];
+  return FS_OK;
+}
+
 int fs_matrix_nrow(fs_matrix_t A) { return A ? A->a.nrow : FS_ERR_ARG; }
 int fs_matrix_ncol(fs_matrix_t A) { return A ? A->a.ncol : FS_ERR_ARG; }
 int64_t fs_matrix_nnz(fs_matrix_t A) { return A ? A->a.nnz : FS_ERR_ARG; }
@@ -292,7 +319,7 @@ int64_t fs_matrix_algorithmic_bytes(fs_matrix_t A, int k)
 {
   if (!A || k < 1) return FS_ERR_ARG;
   const fs::DeviceCsr &a = A->a;
-  return (a.vals ? 12 : 4) * a.nnz + 4 * ((int64_t)a.nrow + 1) + 8ll * k * a.nrow + 8ll * k * a.ncol;
+  return (a.has_vals() ? 12 : 4) * a.nnz + 4 * ((int64_t)a.nrow + 1) + 8ll * k * a.nrow + 8ll * k * a.ncol;
 }
 
 int fs_matrix_download(fs_matrix_t A, int transposed, int *row_ptr, int *cols, double *vals)
@@ -300,6 +327,7 @@ int fs_matrix_download(fs_matrix_t A, int transposed, int *row_ptr, int *cols, d
   if (!A) { set_error("fs_matrix_download: NULL handle"); return FS_ERR_ARG; }
   if (transposed && !A->has_t) { set_error("fs_matrix_download: transpose not built"); return FS_ERR_NO_TRANSPOSE; }
   const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (int rc = fs::need_plain_csr(a, "fs_matrix_download")) return rc;
   if (row_ptr) FS_HIP(hipMemcpy(row_ptr, a.row_ptr, sizeof(int) * ((size_t)a.nrow + 1), hipMemcpyDeviceToHost));
   if (cols && a.nnz) FS_HIP(hipMemcpy(cols, a.cols, sizeof(int) * (size_t)a.nnz, hipMemcpyDeviceToHost));
   if (vals && a.vals && a.nnz) FS_HIP(hipMemcpy(vals, a.vals, sizeof(double) * (size_t)a.nnz, hipMemcpyDeviceToHost));
@@ -400,6 +428,18 @@ int fs_debug_ldsx_orderable(fs_matrix_t A, int transposed)
   if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
   const fs::DeviceCsr &a = transposed ? A->at : A->a;
   if (!a.tiledx || !a.tiledx->built) return FS_ERR_ARG;
+  return a.tiledx->orderable ? 1 : 0;
+}
+
+// 1 when a product on A (transposed != 0: on A') inside a solver's fixed-order scope (cg_fixed_order) really adds in a fixed order,
+// 0 when the kept LDS-staged copy is not orderable and keeps adding in arrival order (the solve is then correct to rounding but
+// not bit-identical from run to run; option "reproducible" = 1 forces a fixed-order kernel at the price of speed)
+int fs_debug_fixed_order_honoured(fs_matrix_t A, int transposed)
+{
+  if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  fs::Options o = fs::options();
+  if (fs::spmv_choice(a, o) != 8) return 1;
   return a.tiledx->orderable ? 1 : 0;
 }
 
@@ -616,6 +656,50 @@ int fs_matrix_device_bytes(fs_matrix_t A, int64_t *bytes3)
   if (A->has_t) fs::device_bytes(A->at, t);
   for (int i = 0; i < 3; ++i) bytes3[i] = a[i] + t[i];
   return FS_OK;
+}
+
+int fs_matrix_release_csr(fs_matrix_t A)
+{
+  if (!A) { set_error("fs_matrix_release_csr: NULL handle"); return FS_ERR_ARG; }
+  std::lock_guard<std::mutex> g(A->lock);
+  FS_HIP(hipDeviceSynchronize());        // products in flight may still read the arrays
+  int n = fs::release_plain_csr(A->a);
+  if (A->has_t) n += fs::release_plain_csr(A->at);
+  return n;
+}
+
+int fs_matrix_restore_csr(fs_matrix_t A, int transposed, const int *row_ptr, const int *cols, const double *vals, int space, int borrow)
+{
+  if (!A || !row_ptr || (transposed && !A->has_t)) { set_error("fs_matrix_restore_csr: bad argument"); return FS_ERR_ARG; }
+  std::lock_guard<std::mutex> g(A->lock);
+  fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.released) return FS_OK;
+  if ((a.nnz > 0 && !cols) || (a.released_valued != (vals != nullptr))) { set_error("fs_matrix_restore_csr: these are not the arrays that were released"); return FS_ERR_ARG; }
+  int rc = FS_OK;
+  if (space == FS_DEVICE && borrow && fs::aligned16(cols) && (!vals || fs::aligned16(vals))) {
+    a.owns = false;
+    a.row_ptr = const_cast<int *>(row_ptr); a.cols = const_cast<int *>(cols); a.vals = const_cast<double *>(vals);
+  } else {
+    a.owns = true;
+    rc = fs::to_device(&a.row_ptr, row_ptr, (size_t)a.nrow + 1, space);
+    if (!rc) rc = fs::to_device(&a.cols, cols, (size_t)a.nnz, space);
+    if (!rc && vals) rc = fs::to_device(&a.vals, vals, (size_t)a.nnz, space);
+  }
+  a.released = false;
+  if (!rc) rc = fs::build_schedule(a, nullptr, /*allow_tiled=*/false);     // the chunk schedule of the streaming kernel only: the kept copy stays
+  if (rc) { (void)fs::release_plain_csr(a); return rc; }
+  return FS_OK;
+}
+
+int fs_matrix_release_prepared(fs_matrix_t A, int k)
+{
+  if (!A || k < 0) { set_error("fs_matrix_release_prepared: bad argument"); return FS_ERR_ARG; }
+  std::lock_guard<std::mutex> g(A->lock);
+  FS_HIP(hipDeviceSynchronize());
+  int n = fs::release_prepared(A->a, k);
+  if (A->has_t) n += fs::release_prepared(A->at, k);
+  fs::pool_trim();
+  return n;
 }
 
 int fs_ata_mul(fs_matrix_t A, double *y, const double *x, double *tmp, fs_stream_t stream)

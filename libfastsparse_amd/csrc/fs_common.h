@@ -29,6 +29,10 @@ struct DeviceCsr {
   int *cols = nullptr;         // nnz
   double *vals = nullptr;      // nnz, or nullptr for a pattern-only matrix
   bool owns = true;            // false: arrays borrowed from the caller
+  // fs_matrix_release_csr: row_ptr / cols / vals and the chunk schedule were given back (only the kept re-ordered copy is left);
+  // everything that reads the plain arrays then fails with FS_ERR_RELEASED until fs_matrix_restore_csr
+  bool released = false, released_valued = false;
+  bool has_vals() const { return vals != nullptr || (released && released_valued); }
   // schedule: chunk c streams non-zeros [c*kChunk, (c+1)*kChunk) and finishes the rows
   // whose first non-zero lies in that range: rows [first_row[c], first_row[c+1]).
   int nchunks = 0;
@@ -50,6 +54,10 @@ struct DeviceCsr {
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
+  // where the one-time work of this matrix went, in ms of host wall time (fs_matrix_build_ms): [0] the arrays into HBM (upload or
+  // device copy) + validation, [1] ordering (COO -> CSR, or the transpose), [2] chunk schedule, [3] two-pass copy built, [4] L2-tiled
+  // copy built, [5] LDS-staged copy built, [6] the candidates timed, [7] the losers freed + scratch trimmed
+  float build_ms[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // products in parts (spmv_part_bounds): the cuts per (number of parts, kernel), computed on first use (a synchronous download
   // of the panel tables: call fs_spmv_part_rows before timing) and kept
   struct PartCuts { int n = 0, kind = 0; bool cut = false; std::vector<int> rows, units; };
@@ -291,6 +299,8 @@ struct Options {
                          // single-vector sweep per column, 4 the MFMA row kernel (experiment, see spmm_mfma_kernel)
   int cg_fixed_order = 1;  // fs_cg / fs_cg2 / fs_dist_cg run their products with fixed-order sums (as under "reproducible"), so
                            // that a solve is bit-identical from run to run like the reference's (cg.h:25-187); 0: the default kernels
+  int release_csr = 0;     // 1: fs_csr_create / fs_coo_create / fs_matrix_build_transpose give the plain CSR arrays back once a re-ordered
+                           // copy was kept (fs_matrix_release_csr); FS_RELEASE_CSR presets it; the drop-in layer never releases
   int dist_cg_scheme = 0;  // fs_dist_cg: 0 every device keeps whole vectors (no exchange for the dots), 1 every device keeps its
                            // slice of the unknowns (vector work divided by the devices; see fs_dist.hip)
 };
@@ -299,6 +309,15 @@ Options &options();
 // Fixed-order sums are wanted NOW, on this thread: the process-wide option, or the calling thread is inside a solver that asks
 // for them (FixedOrderScope).  Read by the launchers at every product.
 extern thread_local int tl_fixed_order;
+extern thread_local int tl_keep_csr;      // > 0: creations on this thread ignore option release_csr (the drop-in layer's scope)
+struct KeepCsrScope {
+  KeepCsrScope() { ++tl_keep_csr; }
+  ~KeepCsrScope() { --tl_keep_csr; }
+  KeepCsrScope(const KeepCsrScope &) = delete;
+  KeepCsrScope &operator=(const KeepCsrScope &) = delete;
+};
+// every fs_set_option moves this on: plans that depend on which kernel a product runs are checked again only when it moved
+unsigned option_epoch();
 inline bool reproducible_now() { return options().reproducible != 0 || tl_fixed_order > 0; }
 struct FixedOrderScope {
   bool on;
@@ -392,6 +411,9 @@ int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, co
                      hipStream_t s);   // FS_ERR_ARG (with a message) when an index is out of range
 void pool_trim(bool everything = false);   // frees the format builders' idle scratch beyond FS_SCRATCH_POOL_MB (or all of it)
 void free_csr(DeviceCsr &A);
+int release_plain_csr(DeviceCsr &A);          // 1 released, 0 nothing to release (no kept copy / already released)
+int release_prepared(DeviceCsr &A, int k);    // the k-column copy / scratch of k (k = 0: all of them)
+int need_plain_csr(const DeviceCsr &A, const char *who);   // FS_OK, or FS_ERR_RELEASED with a message
 void device_bytes(const DeviceCsr &A, int64_t out[3]);   // HBM held: CSR + schedule, kept single-vector copy, k-column copies + scratch
 
 }  // namespace fs

@@ -148,6 +148,7 @@ struct DistSide {
   int nseg = 0, nseg1 = 0;
   int64_t max_seg = 0;
   bool built = false;
+  unsigned epoch = 0;                 // fs::option_epoch() when the cuts were last checked against the kernels (replan_if_moved)
 };
 
 struct CgWork {                       // vectors of fs_dist_cg, kept on the handle between solves
@@ -326,6 +327,7 @@ int plan_side(fs_dist_t D, DistSide &S, int nparts)
     FS_HIP(hipEventCreateWithFlags(&S.done[(size_t)r], hipEventDisableTiming));
   }
   S.built = true;
+  S.epoch = fs::option_epoch();
   return FS_OK;
 }
 
@@ -378,6 +380,8 @@ int exchange_equal(fs_dist_t D, const std::vector<const double *> &send, const s
 int replan_if_moved(fs_dist_t D, DistSide &S)
 {
   const int n = D->n;
+  const unsigned epoch = fs::option_epoch();
+  if (S.epoch == epoch) return FS_OK;     // no option was set since the last check: the products run on the same kernels
   bool same = true;
   std::vector<int> now((size_t)S.nparts + 1);
   for (int r = 0; same && r < n; ++r) {
@@ -391,6 +395,7 @@ int replan_if_moved(fs_dist_t D, DistSide &S)
     free_plan(D, S);
     if (int rc = plan_side(D, S, S.nparts)) return rc;
   }
+  S.epoch = epoch;
   return FS_OK;
 }
 
@@ -1031,7 +1036,10 @@ int fs_dist_matrix_build_transpose_device(fs_dist_matrix_t M)
   fs_dist_t D = M->D;
   const int n = D->n, nrow = M->nrow, ncol = M->ncol;
   if (int rc = dist_sync(D)) return rc;
-  const bool valued = [&] { for (int r = 0; r < n; ++r) if (M->a.shard_nnz[(size_t)r] > 0) return M->a.shard[(size_t)r]->a.vals != nullptr; return false; }();
+  const bool valued = [&] { for (int r = 0; r < n; ++r) if (M->a.shard_nnz[(size_t)r] > 0) return M->a.shard[(size_t)r]->a.has_vals(); return false; }();
+  for (int r = 0; r < n; ++r)
+    if (M->a.shard[(size_t)r])
+      if (int rc = fs::need_plain_csr(M->a.shard[(size_t)r]->a, "fs_dist_matrix_build_transpose_device")) return rc;
   DistSide &T = M->t;
   T.nrow = ncol; T.ncol = nrow;
   T.bounds.assign((size_t)n + 1, 0);

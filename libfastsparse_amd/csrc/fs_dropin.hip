@@ -177,6 +177,7 @@ EntryP lookup(const void *host, int variant, uint64_t print, Build build, const 
     g_table.erase(it);        // a stale copy: gone from the table now, destroyed when its last user returns
   }
   EntryP e = std::make_shared<Entry>();
+  fs::KeepCsrScope keep;       // option release_csr is not for this layer: its callers may use any entry point next
   build(*e);
   if (!e->m && !e->cb && !e->dm) {
     evict_lru(0);

@@ -182,6 +182,50 @@ void free_csr(DeviceCsr &A)
   A = DeviceCsr();
 }
 
+int need_plain_csr(const DeviceCsr &A, const char *who)
+{
+  if (!A.released) return FS_OK;
+  set_error(std::string(who) + " reads the plain CSR arrays, which fs_matrix_release_csr gave back (fs_matrix_restore_csr hands them in again)");
+  return FS_ERR_RELEASED;
+}
+
+// the plain arrays and the chunk schedule of a matrix whose products run on a kept re-ordered copy: owned arrays freed, borrowed ones
+// forgotten.  Products in parts keep their cached cuts (they come from the copy's panel tables).
+int release_plain_csr(DeviceCsr &A)
+{
+  const bool kept = (A.binned && A.binned->built) || (A.tiledx && A.tiledx->built) || (A.tiled && A.tiled->built);
+  if (A.released || !kept) return 0;
+  A.released_valued = A.vals != nullptr;
+  if (A.owns) {
+    if (A.row_ptr) (void)traced_free(A.row_ptr);
+    if (A.cols) (void)traced_free(A.cols);
+    if (A.vals) (void)traced_free(A.vals);
+  }
+  A.row_ptr = nullptr; A.cols = nullptr; A.vals = nullptr;
+  for (void **p : {(void **)&A.first_row, (void **)&A.head, (void **)&A.tail})
+    if (*p) { (void)traced_free(*p); *p = nullptr; }
+  A.released = true;
+  return 1;
+}
+
+int release_prepared(DeviceCsr &A, int k)
+{
+  int n = 0;
+  if ((k == 0 || k == 2 || k == 3) && A.binned2) { free_binned_slot(A.binned2); A.tried2 = false; ++n; }
+  if ((k == 0 || k == 4) && A.binned4) { free_binned_slot(A.binned4); A.tried4 = false; ++n; }
+  if (A.spmm_scratch && (k == 0 || (k >= 2 && k <= 16))) {
+    // the column-major scratch serves every k up to the largest prepared: it goes when the last k that used it goes (k = 0: now)
+    bool others = false;
+    if (k != 0) { A.spmm_choice[k] = 0; for (int j = 2; j <= 16; ++j) others = others || (j != k && A.spmm_choice[j] != 0); }
+    if (!others) {
+      (void)traced_free(A.spmm_scratch); A.spmm_scratch = nullptr; A.spmm_scratch_doubles = 0; ++n;
+      for (int j = 0; j <= 16; ++j) A.spmm_choice[j] = 0;
+    }
+  }
+  A.partk[0] = DeviceCsr::PartCuts(); A.partk[1] = DeviceCsr::PartCuts();
+  return n;
+}
+
 // HBM held by a handle's CSR and every copy / scratch made for it so far, in bytes: [0] the CSR itself (0 when the arrays
 // are borrowed) + chunk schedule, [1] the kept single-vector copy (two-pass incl. its product stream, L2-tiled or LDS-staged),
 // [2] the k-column two-pass copies (k = 2, 4) and the column-major scratch of multi-column products
@@ -204,7 +248,7 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
                     8ll * N->lr->nwg * N->lr->nlong;
     return b;
   };
-  out[0] = (A.owns ? 4ll * (A.nrow + 1) + 4 * A.nnz + (A.vals ? 8 * A.nnz : 0) : 0) + 4ll * (A.nchunks + 1) + 16ll * A.nchunks;
+  out[0] = A.released ? 0 : (A.owns ? 4ll * (A.nrow + 1) + 4 * A.nnz + (A.vals ? 8 * A.nnz : 0) : 0) + 4ll * (A.nchunks + 1) + 16ll * A.nchunks;
   out[1] = tiled_bytes(A.tiled) + tiled_bytes(A.tiledx) + binned_bytes(A.binned);
   out[2] = binned_bytes(A.binned2) + binned_bytes(A.binned4) + 8ll * (int64_t)A.spmm_scratch_doubles;
 }
@@ -240,8 +284,25 @@ __global__ void count_spanning_kernel(int nchunks, int64_t nnz, const int *__res
   if ((int64_t)row_ptr[r1] > e) atomicAdd(count, 1);
 }
 
+namespace {
+struct BuildClock {
+  hipStream_t s;
+  std::chrono::steady_clock::time_point t;
+  explicit BuildClock(hipStream_t st) : s(st) { (void)hipStreamSynchronize(s); t = std::chrono::steady_clock::now(); }
+  float lap()      // ms since the last lap, the stream drained (a handful of synchronisations per matrix built)
+  {
+    (void)hipStreamSynchronize(s);
+    const auto n = std::chrono::steady_clock::now();
+    const float ms = std::chrono::duration<float, std::milli>(n - t).count();
+    t = n;
+    return ms;
+  }
+};
+}  // namespace
+
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
 {
+  BuildClock clock(s);
   A.nchunks = (int)((A.nnz + kChunk - 1) / kChunk);
   if (A.nchunks < 1) A.nchunks = 1;
   FS_HIP(traced_malloc(&A.first_row, sizeof(int) * ((size_t)A.nchunks + 1)));
@@ -261,27 +322,23 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
   FS_HIP(hipGetLastError());
   FS_HIP(hipMemcpyAsync(&A.spanning, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
+  A.build_ms[2] = clock.lap();
   if (!allow_tiled) return FS_OK;
-  // FS_TRACE_BUILD=1 prints where the one-time format work goes
+  // where the one-time format work goes: kept per matrix (fs_matrix_build_ms); FS_TRACE_BUILD=1 also prints it
   static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
-  auto now = [&] { (void)hipStreamSynchronize(s); return std::chrono::steady_clock::now(); };
-  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-    return std::chrono::duration<double, std::milli>(b - a).count();
-  };
-  const auto t0 = trace ? now() : std::chrono::steady_clock::time_point();
   if (int rc = build_binned(A, s)) return rc;
-  const auto t1 = trace ? now() : t0;
+  A.build_ms[3] = clock.lap();
   if (int rc = build_tiled(A, s)) return rc;
-  const auto t2 = trace ? now() : t0;
+  A.build_ms[4] = clock.lap();
   if (int rc = build_tiledx(A, s)) return rc;
-  const auto t3 = trace ? now() : t0;
-  const int rc = choose_copy(A, s);
+  A.build_ms[5] = clock.lap();
+  const int rc = choose_copy(A, s);        // fills build_ms[6] (timing) and starts [7] (freeing the losers)
   pool_trim();
-  if (trace) {
-    const auto t4 = now();
-    fprintf(stderr, "[fastsparse] %d x %d, %lld nnz: two-pass copy %.1f ms, tiled copy %.1f ms, LDS-staged copy %.1f ms, "
-            "timed choice %.1f ms\n", A.nrow, A.ncol, (long long)A.nnz, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
-  }
+  A.build_ms[7] += clock.lap() - A.build_ms[6];
+  if (trace)
+    fprintf(stderr, "[fastsparse] %d x %d, %lld nnz: schedule %.1f ms, two-pass copy %.1f ms, tiled copy %.1f ms, LDS-staged copy %.1f ms, "
+            "candidates timed %.1f ms, losers freed %.1f ms\n", A.nrow, A.ncol, (long long)A.nnz, A.build_ms[2], A.build_ms[3], A.build_ms[4],
+            A.build_ms[5], A.build_ms[6], A.build_ms[7]);
   return rc;
 }
 
@@ -363,6 +420,7 @@ int validate_indices(int nrow, int ncol, int64_t nnz, const int *row_ptr_dev, co
 int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int *rows_dev, const int *cols_dev,
                       const double *vals_dev, hipStream_t s)
 {
+  BuildClock clock(s);
   out = DeviceCsr();
   out.nrow = nrow; out.ncol = ncol; out.nnz = nnz; out.owns = true;
   const size_t n = (size_t)(nnz > 0 ? nnz : 1);
@@ -392,8 +450,11 @@ int coo_to_csr_device(DeviceCsr &out, int nrow, int ncol, int64_t nnz, const int
                      out.row_ptr);
   FS_HIP(hipGetLastError());
   FS_HIP(hipStreamSynchronize(s));
-  return build_schedule(out, s);   // the temporaries above go back to the pool when this function returns; the next
-                                   // creation's pool_trim (or fs_release_all) frees them
+  const float order_ms = clock.lap();
+  const int rc = build_schedule(out, s);   // the temporaries above go back to the pool when this function returns; the next
+                                           // creation's pool_trim (or fs_release_all) frees them
+  out.build_ms[1] += order_ms;
+  return rc;
 }
 
 // ---- the reference's format constructors on the device ----------------------------------------------------
@@ -523,6 +584,8 @@ int cbcsr_rows_device(DeviceCsr &out, int nrow, int ncol, int nblocks, int64_t n
 
 int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
 {
+  if (int rc = need_plain_csr(A, "fs_matrix_build_transpose")) return rc;
+  BuildClock clock(s);
   Scratch<int> rows;
   const size_t n = (size_t)(A.nnz > 0 ? A.nnz : 1);
   FS_HIP(rows.alloc(n));
@@ -533,7 +596,10 @@ int transpose_device(const DeviceCsr &A, DeviceCsr &At, hipStream_t s)
   // A' in COO is (cols, rows, vals); stable sort by column keeps the row order inside each column,
   // i.e. the order in which the serial loops of At_mul_B (sparse.h:72-74) visit a column's entries
   // when the COO itself is row ordered.
-  return coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows.p, A.vals, s);
+  const float expand_ms = clock.lap();
+  const int rc = coo_to_csr_device(At, A.ncol, A.nrow, A.nnz, A.cols, rows.p, A.vals, s);
+  At.build_ms[1] += expand_ms;
+  return rc;
 }
 
 // ---- row shards of A' from the row shards of A, without any whole-matrix host array -----------------------------------
@@ -2050,6 +2116,7 @@ static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, f
 
 int choose_copy(DeviceCsr &A, hipStream_t s)
 {
+  BuildClock clock(s);
   const Options &o = options();
   const bool hb = A.binned && A.binned->built, ht = A.tiled && A.tiled->built, hx = A.tiledx && A.tiledx->built;
   if (!hb && !ht && !hx) return FS_OK;
@@ -2076,6 +2143,7 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc != FS_OK) return rc;
+  A.build_ms[6] = clock.lap();
   A.candidate_ms[0] = t_stream;
   A.candidate_ms[1] = ht ? t_tiled : 0.f;
   A.candidate_ms[2] = hx ? t_ldsx : 0.f;
@@ -2092,6 +2160,7 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   if (keep != 3) free_binned(A);
   if (keep != 2) free_tiledx(A);
   if (keep != 1) free_tiled(A);
+  A.build_ms[7] = clock.lap();
   return FS_OK;
 }
 

@@ -181,16 +181,28 @@ __global__ void spmv_fixup_kernel(int nchunks, int64_t nnz, const int *__restric
   y[r] = acc;
 }
 
-// strict_order variant: a row that crosses chunks must still be ONE left-to-right sum, so the
-// thread continues the running sum tail[c] with the remaining terms themselves (recomputed from
-// global memory) instead of adding the later chunks' partial sums.
-template <bool VALUED>
-__global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__restrict__ row_ptr,
-                                         const int *__restrict__ first_row, const int *__restrict__ cols,
-                                         const double *__restrict__ vals, const double *__restrict__ x,
-                                         const double *__restrict__ tail, double *__restrict__ y)
+// strict_order variant: a row that crosses chunks must still be ONE left-to-right sum (csr.h:430-437), so the running sum tail[c]
+// is continued with the remaining terms themselves instead of with the later chunks' partial sums.  Storage order forbids
+// re-associating the ADDS, not prefetching the TERMS: a crossing row belongs to one WAVE; its 64 lanes load 64 consecutive
+// cols / vals and gather x[col] -- independent loads, kFixU steps of 64 in flight, the entries two super-steps and the gathers
+// one super-step ahead of the sum -- and the products are then added in lane order through v_readlane (every lane carries the
+// same running sum).  One thread walking the row with dependent loads took 593 ms on a config-5 shard (a 10^6-entry row).
+// Lanes past the end of the row contribute +0.0: a sum that started from +0.0 is never -0.0, so x + (+0.0) == x bit for bit.
+constexpr int kFixU = 4;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+template <bool VALUED>
+__global__ __launch_bounds__(kBlock) void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__restrict__ row_ptr,
+                                                                   const int *__restrict__ first_row, const int *__restrict__ cols,
+                                                                   const double *__restrict__ vals, const double *__restrict__ x,
+                                                                   const double *__restrict__ tail, double *__restrict__ y)
+{
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // one wave per chunk: everything below is wave-uniform
   if (c >= nchunks) return;
   const int r0 = first_row[c], r1 = first_row[c + 1];
   if (r1 <= r0) return;
@@ -200,11 +212,38 @@ __global__ void spmv_fixup_strict_kernel(int nchunks, int64_t nnz, const int *__
   if (e > nnz) e = nnz;
   if (b <= e) return;
   double acc = tail[c];
-  for (int64_t i = e; i < b; ++i) {
-    const double xv = x[cols[i]];
-    acc += VALUED ? xv * vals[i] : xv;
+  int ci[kFixU];
+  double vv[kFixU], p[kFixU], pn[kFixU];
+  auto load_entries = [&](int64_t at) {
+#pragma unroll
+    for (int u = 0; u < kFixU; ++u) {
+      const int64_t i = at + u * 64 + lane;
+      const bool in = i < b;
+      ci[u] = in ? cols[i] : -1;
+      if (VALUED) vv[u] = in ? vals[i] : 0.0;
+    }
+  };
+  auto gather = [&](double (&out)[kFixU]) {
+#pragma unroll
+    for (int u = 0; u < kFixU; ++u) {
+      const double xv = ci[u] >= 0 ? x[ci[u]] : 0.0;
+      out[u] = ci[u] >= 0 ? (VALUED ? xv * vv[u] : xv) : 0.0;
+    }
+  };
+  load_entries(e);
+  gather(p);
+  load_entries(e + 64 * kFixU);
+  for (int64_t base = e; base < b; base += 64 * kFixU) {
+    gather(pn);                                   // the next super-step's x: in flight under the sum below
+    load_entries(base + 2 * 64 * kFixU);          // and the entries of the one after
+#pragma unroll
+    for (int u = 0; u < kFixU; ++u)
+#pragma unroll
+      for (int j = 0; j < 64; ++j) acc += readlane_f64(p[u], j);
+#pragma unroll
+    for (int u = 0; u < kFixU; ++u) p[u] = pn[u];
   }
-  y[r] = acc;
+  if (lane == 0) y[r] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -596,9 +635,13 @@ int spmv_choice(const DeviceCsr &A, const Options &o)
   // (fixed-order sums -- "reproducible", the solvers -- keep the builder's choice: pass 2 of the two-pass pair then runs one wave per
   // panel in stream order, the long-row path gives every row to one wave, the LDS-staged kernel waits for a phase's adds before
   // its barrier; only an LDS-staged copy whose items could not be arranged row-per-wave, TiledCsr::orderable, drops out)
-  const bool repro = o.reproducible != 0 || tl_fixed_order > 0;
+  // Option "reproducible" is a REQUIREMENT: such a copy then drops out and the product falls to a kernel that can give fixed-order
+  // sums.  A solver's scope (cg_fixed_order, FixedOrderScope) is a WISH: the kept copy keeps running -- in arrival order where it is
+  // not orderable -- instead of silently moving every product of a solve to the chunk-streaming kernel;
+  // fs_debug_fixed_order_honoured tells which it is.
+  const bool must = o.reproducible != 0;
   if (A.binned && A.binned->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 7)) return 7;
-  if (A.tiledx && A.tiledx->built && !o.strict_order && (!repro || A.tiledx->orderable) && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
+  if (A.tiledx && A.tiledx->built && !o.strict_order && (!must || A.tiledx->orderable) && (o.spmv_kernel == 0 || o.spmv_kernel == 8)) return 8;
   if (A.tiled && A.tiled->built && !o.strict_order && (o.spmv_kernel == 0 || o.spmv_kernel == 6)) return 6;
   return o.spmv_kernel == 2 ? 2 : 1;
 }
@@ -615,16 +658,18 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
     case 6: return launch_spmv_tiled(A, *A.tiled, y, x, s);
     default: break;
   }
-  // "reproducible" / "strict_order" set AFTER the matrix was created leave its kept copy unusable: the product then runs on
-  // the chunk-streaming kernel (correct, but slow on large matrices).  Said once under FS_TRACE_BUILD.
-  if ((reproducible_now() || o.strict_order) && o.spmv_kernel == 0 && ((A.binned && A.binned->built) || (A.tiledx && A.tiledx->built))) {
+  if (int rc = need_plain_csr(A, "this product (strict_order, spmv_kernel 1-3, or \"reproducible\" on a copy that cannot give fixed-order sums)")) return rc;
+  // strict_order (storage-order sums: only the chunk-streaming kernel gives them), or "reproducible" on a matrix whose kept
+  // LDS-staged copy could not be arranged row-per-wave: the product runs on the chunk-streaming kernel (correct, fixed order, but
+  // slow on large matrices).  Said once under FS_TRACE_BUILD.
+  if ((o.reproducible || o.strict_order) && o.spmv_kernel == 0 && ((A.binned && A.binned->built) || (A.tiledx && A.tiledx->built))) {
     static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
     static bool said = false;
     if (trace && !said) {
       said = true;
-      fprintf(stderr, "[fastsparse] %d x %d: option %s was set after this matrix was created with a %s copy; its products run on "
-              "the chunk-streaming kernel (set the option before creating the matrix to get a fixed-order copy)\n", A.nrow, A.ncol,
-              o.strict_order ? "strict_order" : "reproducible", A.binned && A.binned->built ? "two-pass" : "LDS-staged");
+      fprintf(stderr, "[fastsparse] %d x %d: option %s: the kept %s copy cannot give such sums%s; products run on the chunk-streaming "
+              "kernel\n", A.nrow, A.ncol, o.strict_order ? "strict_order" : "reproducible", A.binned && A.binned->built ? "two-pass" : "LDS-staged",
+              o.strict_order ? "" : " (some work item holds more of one row than one wave can take: TiledCsr::orderable)");
     }
   }
   if (o.spmv_kernel == 2) {
@@ -652,7 +697,7 @@ int launch_spmv(const DeviceCsr &A, double *y, const double *x, hipStream_t s, b
 #undef FS_LAUNCH_STREAM
   FS_HIP(hipGetLastError());
   if (A.spanning > 0 && o.strict_order) {
-    const dim3 fg((A.nchunks + kBlock - 1) / kBlock), fb(kBlock);
+    const dim3 fg((A.nchunks + kBlock / 64 - 1) / (kBlock / 64)), fb(kBlock);    // one wave per chunk
     if (valued)
       hipLaunchKernelGGL(spmv_fixup_strict_kernel<true>, fg, fb, 0, s, A.nchunks, A.nnz, A.row_ptr, A.first_row,
                          A.cols, A.vals, x, A.tail, y);
@@ -966,8 +1011,7 @@ int spmm_plan(const DeviceCsr &A, int k, int *needs_prepare)
 {
   const Options &o = options();
   if (needs_prepare) *needs_prepare = 0;
-  const bool repro = reproducible_now();
-  const bool free_order = !o.strict_order && (!repro || (A.tiledx && A.tiledx->orderable));   // fixed-order sums on the LDS-staged copy: see spmv_choice
+  const bool free_order = !o.strict_order && (!o.reproducible || (A.tiledx && A.tiledx->orderable));   // fixed-order sums on the LDS-staged copy: see spmv_choice
   // the two-pass kernels: under "reproducible" their pass 2 runs one wave per panel in stream order -- not the long-row side path
   const bool bin_order = !o.strict_order;
   const int want = o.spmm_kernel;
@@ -1017,6 +1061,7 @@ static int spmm_scratch_alloc(DeviceCsr &A, int k)      // prepare_spmm only
 
 static int launch_spmm_row(const DeviceCsr &A, double *Y, const double *X, int k, hipStream_t s)
 {
+  if (int rc = need_plain_csr(A, "the row kernel of multi-column products")) return rc;
   // two columns per lane and 16-byte loads where the layout allows it and it measured faster (config 4's matrix, k = 4 / 6 / 8 /
   // 12: 3.39 / 3.88 / 3.32 / 5.00 ms -> 3.30 / 3.76 / 3.19 / 4.83; k = 16 / 32 / 64: 3.65 / 7.94 / 16.15 -> 3.71 / 7.93 / 16.20:
   // there both sit at the HBM rate for the lines they pull, profiles/r03_spmm_wide_ab.jsonl); option spmm_wide: 1 wherever
@@ -1100,6 +1145,7 @@ static int launch_spmm_plan(DeviceCsr &A, int plan, double *Y, const double *X, 
       return FS_OK;
     }
     case kPlanMfma: {   // the matrix-core experiment (see spmm_mfma_kernel)
+      if (int rc = need_plain_csr(A, "the matrix-core SpMM experiment")) return rc;
       const unsigned g4 = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
       if (A.vals) hipLaunchKernelGGL(spmm_mfma_kernel<true>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
       else        hipLaunchKernelGGL(spmm_mfma_kernel<false>, dim3(g4), dim3(kBlock), 0, s, A.nrow, k, A.row_ptr, A.cols, A.vals, X, Y);
@@ -1183,6 +1229,7 @@ int prepare_spmm(DeviceCsr &A, int k, hipStream_t s)
   int needs = 0;
   int plan = spmm_plan(A, k, &needs);
   if (needs & 1) {
+    if (int rc = need_plain_csr(A, "fs_matrix_prepare (the k-column copy is built from the plain arrays)")) return rc;
     if (int rc = build_binned_k(A, k == 4 ? 4 : 2, s)) return rc;     // declines (and says so in tried2 / tried4) where it would not pay
     plan = spmm_plan(A, k, &needs);
   }

@@ -773,15 +773,15 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
                      T.lcol_bits, A.ncol, T.items, T.chunk_panel + c0, T.chunk_item + 2 * c0, T.pk, T.vals, x, out, ost,    \
                      T.chunk_ord + c0, T.ticket)
 #define FS_LDSXD2(V, N) do { if (ordered) FS_LDSXD(V, N, true); else FS_LDSXD(V, N, false); } while (0)
-        if (A.vals) { if (nt) FS_LDSXD2(true, true); else FS_LDSXD2(true, false); }
+        if (A.has_vals()) { if (nt) FS_LDSXD2(true, true); else FS_LDSXD2(true, false); }
         else        { if (nt) FS_LDSXD2(false, true); else FS_LDSXD2(false, false); }
 #undef FS_LDSXD2
 #undef FS_LDSXD
       } else if (xs == 1 && A.ncol >= 2) {
-        if (A.vals) { if (nt) FS_LDSXP(true, true, true); else FS_LDSXP(true, false, true); }
+        if (A.has_vals()) { if (nt) FS_LDSXP(true, true, true); else FS_LDSXP(true, false, true); }
         else        { if (nt) FS_LDSXP(false, true, true); else FS_LDSXP(false, false, true); }
       } else {                                     // one column of a row-major X: strided slice loads
-        if (A.vals) FS_LDSXP(true, true, false); else FS_LDSXP(false, true, false);
+        if (A.has_vals()) FS_LDSXP(true, true, false); else FS_LDSXP(false, true, false);
       }
 #undef FS_LDSXP
       FS_HIP(hipGetLastError());
@@ -796,7 +796,7 @@ int launch_spmv_tiled(const DeviceCsr &A, const TiledCsr &T, double *y, const do
 #define FS_TILED(V, N)                                                                                         \
   hipLaunchKernelGGL((spmv_tiled_kernel<V, N>), dim3(c1 - c0), dim3(kTiledBlock), 0, s, T.panel_row + c0, T.W, T.lcol_bits, \
                      T.items, T.item_ptr + c0, T.pk, T.vals, x, out, xs, os)
-    if (A.vals) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
+    if (A.has_vals()) { if (nt) FS_TILED(true, true); else FS_TILED(true, false); }
     else        { if (nt) FS_TILED(false, true); else FS_TILED(false, false); }
 #undef FS_TILED
   }
@@ -821,9 +821,10 @@ int launch_ata_fused(const DeviceCsr &A, double *y, const double *x, hipStream_t
 #define FS_ATA(V)                                                                                                        \
   hipLaunchKernelGGL((ata_ldsx_kernel<V, true, kLdsxSets>), dim3(T->nchunks), dim3(kTiledBlock), 0, s, T->panel_row, \
                      T->W, T->lcol_bits, A.ncol, T->items, T->chunk_panel, T->chunk_item, T->pk, T->vals, x, y, 1, 1)
-    if (A.vals) FS_ATA(true); else FS_ATA(false);
+    if (A.has_vals()) FS_ATA(true); else FS_ATA(false);
 #undef FS_ATA
   } else {
+    if (int rc = need_plain_csr(A, "the fused A'A kernel on the plain CSR")) return rc;
     const unsigned grid = (unsigned)(((int64_t)A.nrow + kBlock / 64 - 1) / (kBlock / 64));
     if (A.vals) hipLaunchKernelGGL(ata_csr_kernel<true>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.row_ptr, A.cols, A.vals, x, y);
     else        hipLaunchKernelGGL(ata_csr_kernel<false>, dim3(grid), dim3(kBlock), 0, s, A.nrow, A.row_ptr, A.cols, A.vals, x, y);

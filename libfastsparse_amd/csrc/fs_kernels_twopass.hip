@@ -385,8 +385,8 @@ static int launch_longrows(const DeviceCsr &A, const LongRows &L, const double *
   hipLaunchKernelGGL((spmv_longrows_kernel<V, BC, NA, ORD>), dim3(L.nwg), dim3(kBinBlock), 0, s, A.ncol, L.B, L.nlong, L.band_ptr, \
                      L.seg_ptr, L.lcol, L.lrow, L.vals, x, xs, L.ylong, L.ypart)
 #define FS_LONG2(V, BC, NA) do { if (ordered) FS_LONG(V, BC, NA, true); else FS_LONG(V, BC, NA, false); } while (0)
-  if (L.bcols == kLongBandB) { if (A.vals) FS_LONG2(true, kLongBandB, kLongRowsB); else FS_LONG2(false, kLongBandB, kLongRowsB); }
-  else                       { if (A.vals) FS_LONG2(true, kLongBandA, kLongRowsA); else FS_LONG2(false, kLongBandA, kLongRowsA); }
+  if (L.bcols == kLongBandB) { if (A.has_vals()) FS_LONG2(true, kLongBandB, kLongRowsB); else FS_LONG2(false, kLongBandB, kLongRowsB); }
+  else                       { if (A.has_vals()) FS_LONG2(true, kLongBandA, kLongRowsA); else FS_LONG2(false, kLongBandA, kLongRowsA); }
 #undef FS_LONG2
 #undef FS_LONG
   FS_HIP(hipGetLastError());
@@ -651,14 +651,14 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   hipLaunchKernelGGL((spmv_expand_kernel<V, U, NL, NS>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
                      N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog))
     if (N.bcols == kBinColsBig) {                // the large-band copy: default switches only
-      if (A.vals)
+      if (A.has_vals())
         hipLaunchKernelGGL((spmv_expand_kernel<true, 4, false, true, kBinColsBig>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B,
                            N.band_ptr, N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog));
       else
         hipLaunchKernelGGL((spmv_expand_kernel<false, 4, false, true, kBinColsBig>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B,
                            N.band_ptr, N.lcol, N.vals, N.gdst, x, xs, N.prod, 0u, (unsigned)(N.n >> kBinGroupLog));
     } else
-    if (A.vals) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
+    if (A.has_vals()) { if ((flags & 3) == 1) FS_EXPAND4(true, 8); else if ((flags & 3) == 2) FS_EXPAND4(true, 2); else FS_EXPAND4(true, 4); }
     else        { if ((flags & 3) == 1) FS_EXPAND4(false, 8); else if ((flags & 3) == 2) FS_EXPAND4(false, 2); else FS_EXPAND4(false, 4); }
 #undef FS_EXPAND4
 #undef FS_EXPAND
@@ -706,8 +706,8 @@ int launch_expand_groups(const DeviceCsr &A, const double *x, unsigned g0, unsig
 #define FS_XH(V, BC)                                                                                                    \
   hipLaunchKernelGGL((spmv_expand_kernel<V, 4, false, true, BC>), dim3(wgs), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, \
                      N.lcol, N.vals, N.gdst, x, 1, N.prod, g0, g1)
-  if (N.bcols == kBinColsBig) { if (A.vals) FS_XH(true, kBinColsBig); else FS_XH(false, kBinColsBig); }
-  else                        { if (A.vals) FS_XH(true, kBinCols); else FS_XH(false, kBinCols); }
+  if (N.bcols == kBinColsBig) { if (A.has_vals()) FS_XH(true, kBinColsBig); else FS_XH(false, kBinColsBig); }
+  else                        { if (A.has_vals()) FS_XH(true, kBinCols); else FS_XH(false, kBinCols); }
 #undef FS_XH
   FS_HIP(hipGetLastError());
   return FS_OK;
@@ -740,8 +740,8 @@ int launch_spmm_binned(const DeviceCsr &A, const BinnedCsr &N, double *Y, const 
   hipLaunchKernelGGL((spmm_expand_kernel<V, KK, 4>), dim3(nwg1), dim3(kBinBlock), 0, s, A.ncol, N.B, N.band_ptr, N.lcol, \
                      N.vals, N.gdst, X, xs, N.prod)
   if (nwg1 > 0) {
-    if (K == 2) { if (A.vals) FS_XP(true, 2); else FS_XP(false, 2); }
-    else        { if (A.vals) FS_XP(true, 4); else FS_XP(false, 4); }
+    if (K == 2) { if (A.has_vals()) FS_XP(true, 2); else FS_XP(false, 2); }
+    else        { if (A.has_vals()) FS_XP(true, 4); else FS_XP(false, 4); }
     FS_HIP(hipGetLastError());
   }
 #undef FS_XP

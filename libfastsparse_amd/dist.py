@@ -210,14 +210,37 @@ class ShardedOperator:
         was written): the same product with the exchange INSIDE it and with the plain whole-shard all-gather behind it must give
         the same vector on every rank (to rounding: the parts do not change a row's terms, only -- without fixed-order sums --
         their order).  If any rank sees a difference, every rank switches this operator to the conservative exchange.  Collective.
-        Returns {"mode": "overlapped" | "conservative", "max_rel_diff": ...} (what bench.py puts into its record)."""
+        Returns {"mode": "overlapped" | "conservative", "max_rel_diff": ..., and after a disagreement "first_bad_segment_per_rank":
+        per rank the first (owner rank, part, row range) whose rows arrived wrong} (what bench.py puts into its record)."""
         if _single(self.world) or self.parts is None or nparts <= 1 or self.conservative:
             return {"mode": "conservative" if self.conservative else "overlapped", "checked": False}
         yo = torch.empty_like(y_full)
         self.apply_overlapped_async(yo, x_full, nparts).wait()
         self.gather(y_full, self.local(y_full, x_full))
+        inject = os.environ.get("FS_DIST_INJECT_MISMATCH", "")      # "rank:part" (tests): that segment of the overlapped result is spoiled
+        plan = self._part_plan(nparts, y_full) if self.exchange == "allgather" or inject else None
+        if inject and plan is not None:
+            r_, p_ = (int(v) for v in inject.split(":"))
+            a = (self.bounds[r_] + plan["cuts"][r_][p_]) * self.k
+            if plan["cuts"][r_][p_ + 1] > plan["cuts"][r_][p_]:
+                yo[a] += 1.0
         scale = float(y_full.abs().max().item())
-        diff = float((yo - y_full).abs().max().item()) / (scale if scale > 0 else 1.0)
+        scale = scale if scale > 0 else 1.0
+        diff = float((yo - y_full).abs().max().item()) / scale
+        first_bad = None
+        if diff > 1e-9 and plan is not None:
+            # whose rows, of which part, arrived wrong on THIS rank: the first segment of the padded layout that differs
+            for p in range(nparts):
+                for r in range(self.world):
+                    a, b = self.bounds[r] + plan["cuts"][r][p], self.bounds[r] + plan["cuts"][r][p + 1]
+                    if b > a:
+                        d = float((yo[a * self.k:b * self.k] - y_full[a * self.k:b * self.k]).abs().max().item()) / scale
+                        if d > 1e-9:
+                            first_bad = {"seen_by_rank": self.rank, "rows_owned_by_rank": r, "part": p, "of_parts": nparts,
+                                         "row_range": [a, b], "max_rel_diff": d}
+                            break
+                if first_bad:
+                    break
         bad = torch.tensor([0.0 if diff <= 1e-9 else 1.0, diff], dtype=torch.float64, device=y_full.device)
         if _host_collective(bad, self.group):
             h = bad.cpu()
@@ -226,7 +249,13 @@ class ShardedOperator:
         else:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
         self.conservative = bool(float(bad[0].item()) > 0.0)
-        return {"mode": "conservative" if self.conservative else "overlapped", "checked": True, "max_rel_diff": float(bad[1].item())}
+        out = {"mode": "conservative" if self.conservative else "overlapped", "checked": True, "max_rel_diff": float(bad[1].item()),
+               "parts": nparts, "exchange": self.exchange}
+        if self.conservative:
+            seen = [None] * self.world
+            dist.all_gather_object(seen, first_bad, group=self.group)       # every rank's first bad segment (None: that rank saw none)
+            out["first_bad_segment_per_rank"] = seen
+        return out
 
     @property
     def nrow(self):

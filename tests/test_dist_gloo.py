@@ -405,9 +405,83 @@ def _c2_worker(rank, world, port, z_scheme, ret):
                 and all("error" not in r and r["config"]["self_check"]["ok"] and r["roofline"]["achieved"] > 0 for r in also) \
                 and also[0]["scaling"] == "strong" and also[1]["config"]["with_transpose"]["value"] > 0
             ret["names"] = names
+            # the line proves its world and names its exchange
+            rc = rec["rccl"]
+            ok = ok and rc["ranks_counted_by_all_reduce_of_ones"] == world and len(rc["ranks"]) == world \
+                and sorted(r["rank"] for r in rc["ranks"]) == list(range(world)) and len(rec["per_rank"]) == world \
+                and ex["parts"] == 3 and ex["mode"].startswith("overlapped") and "exchange_fault" not in rec \
+                and "WEAK scaling" in rec["config"]["workload"] and rec["aggregate_frac_of_hbm_peak"] > 0
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
+
+
+def _fault_worker(rank, world, port, strict, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FS_DIST_INJECT_MISMATCH="1:2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import argparse
+        import bench
+        prov = OracleProvider()
+        args = argparse.Namespace(rows=2500, per_row=16, c5_rows=9000, steps=2, warmup=1, transpose=False, strong=False, parts=3,
+                                  z_scheme="gather", no_cpu_baseline=True, no_reproducible_cost=True, cpu_sample_rows=0,
+                                  spmm_kernel=0, exchange="allgather", strict_exchange=strict)
+        try:
+            rec = bench.run_c2(args, prov, world, rank, False)
+            info = None
+        except bench.ExchangeFault as ex:
+            rec, info = None, ex.info
+        if strict:          # every rank raises (the verdict of verify_overlap is collective); main() turns it into the error line
+            seg = info["vectors"]["y"]["first_bad_segment_per_rank"][rank]
+            ret[rank] = bool(rec is None and seg["rows_owned_by_rank"] == 1 and seg["part"] == 2 and seg["row_range"][1] > seg["row_range"][0])
+        elif rank == 0:     # default: the fault is in the line, the numbers are the conservative exchange's
+            f = rec["exchange_fault"]
+            seg = f["vectors"]["y"]["first_bad_segment_per_rank"][0]
+            ret[rank] = bool(rec["value"] > 0 and rec["config"]["self_check"]["ok"] and seg["rows_owned_by_rank"] == 1 and seg["part"] == 2
+                             and rec["config"]["exchange"]["mode"].startswith("conservative") and f["parts"] == 3)
+        else:
+            ret[rank] = rec is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_error_line_shape():
+    """the line main() prints when the headline workload of an N > 1 run raises: "error", the rank, the fault's segment, the exchange
+    that was selected -- json-serialisable, no value"""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(parts=4, exchange="allgather")
+    fault = {"vectors": {"y": {"first_bad_segment_per_rank": [{"rows_owned_by_rank": 1, "part": 2, "row_range": [10, 20]}]}}, "parts": 4}
+    try:
+        raise bench.ExchangeFault(fault)
+    except bench.ExchangeFault as ex:
+        rec = json.loads(json.dumps(bench.error_record(ex, args, 8, 5)))
+    assert rec["value"] is None and rec["n_gpus"] == 8 and rec["error_rank"] == 5 and rec["error_kind"] == "exchange_fault"
+    assert rec["exchange_fault"]["vectors"]["y"]["first_bad_segment_per_rank"][0]["part"] == 2
+    assert rec["exchange"] == {"parts": 4, "mode": "overlapped", "how": "allgather"} and "--parts 1" in rec["hint"]
+    try:
+        raise RuntimeError("NCCL error: unhandled system error")
+    except RuntimeError as ex:
+        rec = bench.error_record(ex, argparse.Namespace(parts=1, exchange="direct"), 2, 0)
+    assert rec["error_kind"].startswith("exception") and rec["exchange"]["mode"] == "conservative" and "NCCL error" in rec["error"]
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_bench_reports_a_faulty_overlapped_exchange(strict):
+    """the first contact with RCCL must be cheap to diagnose.  An overlapped exchange whose part 2 of rank 1
+    arrives wrong (injected: FS_DIST_INJECT_MISMATCH) is found by verify_overlap BEFORE the timed loops; by default the line says
+    which part / rank / row range (exchange_fault) and carries the conservative exchange's numbers; under --strict-exchange every
+    rank raises ExchangeFault, which main() prints as ONE JSON line with "error" and exits 3 (the other shape of the line:
+    test_bench_error_line_shape)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_fault_worker, args=(world, _free_port(), strict, ret), nprocs=world, join=True)
+    assert ret.get(0) is True and ret.get(1) is True, dict(ret)
 
 
 @pytest.mark.parametrize("z_scheme", ["gather", "reduce"])

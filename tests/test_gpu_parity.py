@@ -115,10 +115,12 @@ def test_kernel_variants_agree(hip, kernel):
             gold = np.load(os.path.join(S.GOLDEN, name + ".npz"))
             y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, None, c.xs["int"])
             assert np.array_equal(y, gold["bcsr_A_mul_B|int"])
+            rp, cc, vv = O.coo_to_csr(c.nrow, c.rows, c.cols, c.vals)
             for tag in ("int", "bench"):
                 y = be.csr_mul(c.nrow, c.ncol, c.rows, c.cols, c.vals, c.xs[tag])
                 g = gold["csr_A_mul_B|" + tag]
-                assert np.max(np.abs(y - g)) <= TOL * max(1.0, np.max(np.abs(g)))
+                scale = O.csr_abs_scale(c.nrow, rp, cc, vv, c.xs[tag])       # |y - y_ref| <= 1e-12 sum_j |a_ij||x_j|
+                assert np.all(np.abs(y - g) <= TOL * scale), (name, tag, float(np.max(np.abs(y - g) - TOL * scale)))
     finally:
         capi.set_option("spmv_kernel", 0)
 
@@ -139,8 +141,9 @@ def test_csr_transposed_product(hip, backend):
                 y = be.transposed_csr_mul(c.nrow, c.ncol, c.rows, c.cols, vals, xt)
                 if tag == "int" and vals is None:
                     assert np.array_equal(y, ref), (name, tag)
-                else:
-                    assert np.max(np.abs(y - ref)) <= TOL * max(1.0, np.max(np.abs(ref))), (name, tag)
+                else:       # row-scaled: the same column sums on |A|, |x|
+                    scale = O.coo_tmul(c.ncol, rows_sorted, cc, None if vv is None else np.abs(vv), np.abs(xt))
+                    assert np.all(np.abs(y - ref) <= TOL * scale), (name, tag, float(np.max(np.abs(y - ref) - TOL * scale)))
 
 
 @pytest.mark.parametrize("geometry", [(64, 128), (7, 33), (2048, 4096), (0, 0)])
@@ -1972,6 +1975,130 @@ print("OK")
     for mode, extra in (("dropin", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}), ("rccl", {"FS_DIST_FORCE_RCCL": "1"})):
         p = subprocess.run([sys.executable, "-c", code, mode], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, (mode, p.stdout[-1500:] + p.stderr[-1500:])
+
+
+def test_release_and_restore_of_the_plain_csr(hip):
+    """once the builder has kept a re-ordered copy the plain arrays are dead weight.  fs_matrix_release_csr gives
+    them back (A and A'): the default products are unchanged, the handle holds its copy alone, everything that reads the plain arrays
+    (strict_order, the row kernel of k = 8, a new prepare, download) fails with FS_ERR_RELEASED and a message -- never garbage -- and
+    fs_matrix_restore_csr brings them back.  fs_matrix_release_prepared drops the k-column copies."""
+    import torch
+    from libfastsparse_amd import capi
+    n, per = 300_000, 16
+    capi.set_option("binning", 2)
+    try:
+        rp, cc, vv = capi.synth_uniform(n, n, per, 0x5EED77)
+        A = capi.Matrix.from_csr(n, n, rp, cc, vv)           # an owned copy of the arrays
+        st = capi.current_stream()
+        A.build_transpose(st)
+        assert A.kernel_name() == "two-pass" and A.kernel_name(True) == "two-pass"
+        hrp, hcc, hvv = rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy()
+        x = S.x_sin(n)
+        xd = torch.from_numpy(x).cuda()
+        ref, scale = O.csr_mul(n, hrp, hcc, hvv, x), O.csr_abs_scale(n, hrp, hcc, hvv, x)
+        rows = np.repeat(np.arange(n, dtype=np.int32), per)
+        zref, zscale = O.coo_tmul(n, rows, hcc, hvv, x), O.coo_tmul(n, rows, hcc, np.abs(hvv), np.abs(x))
+        y = torch.full((n,), -1.0, dtype=torch.float64, device="cuda")
+        A.prepare(2, st)
+        X2 = np.ascontiguousarray(np.stack([x, 3.0 * x], 1))
+        Y2 = torch.full((n, 2), -1.0, dtype=torch.float64, device="cuda")
+        held0 = A.device_bytes()
+        assert held0[0] >= 2 * 12 * n * per and held0[2] > 0
+        assert A.release_csr() == 2 and A.release_csr() == 0
+        held1 = A.device_bytes()
+        assert held1[0] == 0 and held1[1] == held0[1] and held1[2] == held0[2]
+        for tr, r, sc in ((False, ref, scale), (True, zref, zscale)):
+            y.fill_(-1.0)
+            A.spmv(y, xd, st, transposed=tr)
+            assert np.all(np.abs(y.cpu().numpy() - r) <= TOL * sc)
+        A.spmm(Y2, torch.from_numpy(X2).cuda(), 2, st)                  # the prepared k = 2 sweep needs no plain array
+        assert np.all(np.abs(Y2.cpu().numpy()[:, 1] - 3.0 * ref) <= 3.0 * TOL * scale)
+        for what in (lambda: A.spmm(torch.empty(n, 8, dtype=torch.float64, device="cuda"), torch.zeros(n, 8, dtype=torch.float64, device="cuda"), 8, st),
+                     lambda: A.prepare(4, st), lambda: A.download()):
+            with pytest.raises(capi.FastsparseError, match="fs_matrix_release_csr"):
+                what()
+        capi.set_option("strict_order", 1)
+        try:
+            with pytest.raises(capi.FastsparseError, match="fs_matrix_release_csr"):
+                A.spmv(y, xd, st)
+            A.restore_csr(rp, cc, vv)                                    # the same arrays back (copied)
+            A.spmv(y, xd, st)
+            assert np.array_equal(y.cpu().numpy(), ref)                  # storage order: the oracle's bits
+        finally:
+            capi.set_option("strict_order", 0)
+        assert A.device_bytes()[0] >= 12 * n * per
+        assert A.release_prepared(2) >= 1 and A.device_bytes()[2] == 0
+        assert A.spmm_plan(2) != "k-column two-pass"
+        A.close()
+        # option release_csr: creation itself gives the arrays back
+        capi.set_option("release_csr", 1)
+        try:
+            B = capi.Matrix.from_csr(n, n, rp, cc, vv)
+            assert B.device_bytes()[0] == 0
+            B.spmv(y, xd, st)
+            assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * scale)
+            B.close()
+        finally:
+            capi.set_option("release_csr", 0)
+    finally:
+        capi.set_option("binning", 1)
+
+
+def test_solvers_keep_a_lds_staged_copy_that_cannot_be_ordered(hip):
+    """fs_cg / fs_cg2 ask for fixed-order sums by default (cg_fixed_order).  On a matrix whose kept LDS-staged copy could
+    NOT be arranged one-row-per-wave (dense rows: 300 entries of a row inside one 2048-entry work item) that wish must not move every
+    product of the solve to the chunk-streaming kernel: the copy keeps running, in arrival order, and fs_debug_fixed_order_honoured
+    says so.  Option "reproducible" = 1 is a requirement: the product then leaves the copy and two runs agree bit for bit."""
+    import ctypes as C
+    import torch
+    from libfastsparse_amd import capi
+    L = capi.lib()
+    L.fs_debug_ldsx_orderable.argtypes = [C.c_void_p, C.c_int]
+    L.fs_debug_fixed_order_honoured.argtypes = [C.c_void_p, C.c_int]
+    nrow, ncol, per = 6000, 2048, 300
+    capi.set_option("ldsx", 2)
+    try:
+        hrp, hcc, _ = pysynth_uniform(nrow, ncol, per)
+        d = lambda a: torch.from_numpy(a).cuda()
+        A = capi.Matrix.from_csr(nrow, ncol, d(hrp), d(hcc), None)
+        rows = np.repeat(np.arange(nrow, dtype=np.int32), per)
+        At = capi.Matrix.from_coo(ncol, nrow, d(hcc), d(rows), None)
+        if A.kernel_name() != "lds-staged" or L.fs_debug_ldsx_orderable(A.h, 0) != 0:
+            pytest.skip("the builder arranged this matrix row-per-wave: nothing to check")
+        assert L.fs_debug_fixed_order_honoured(A.h, 0) == 0
+        st = capi.current_stream()
+        x = S.x_sin(ncol)
+        y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        ref, scale = O.csr_mul(nrow, hrp, hcc, None, x), O.csr_abs_scale(nrow, hrp, hcc, None, x)
+        A.spmv(y, d(x), st)
+        assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * scale)
+        # the solver: same answer with the wish on and off, and as the oracle's within the bar of the golden CG cases
+        b1, _ = _cases.cg_rhs(ncol)
+        xref, itref = O.cg_normal(nrow, ncol, rows, hcc, b1, 5.0, 1e-6, False)
+        for wish in (1, 0):
+            capi.set_option("cg_fixed_order", wish)
+            xs = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+            it = C.c_int(-1)
+            capi.check(L.fs_cg(A.h, At.h, xs.data_ptr(), d(b1).data_ptr(), 5.0, 1e-6, C.byref(it), st), "fs_cg")
+            assert abs(it.value - itref) <= 1 and np.max(np.abs(xs.cpu().numpy() - xref)) <= 1e-5 * np.max(np.abs(xref)), (wish, it.value, itref)
+        capi.set_option("cg_fixed_order", 1)
+        # the requirement: off the copy, onto a fixed-order kernel
+        capi.set_option("reproducible", 1)
+        try:
+            assert A.kernel_name() == "stream"
+            A.spmv(y, d(x), st); y1 = y.clone()
+            A.spmv(y, d(x), st)
+            assert torch.equal(y, y1) and np.all(np.abs(y.cpu().numpy() - ref) <= TOL * scale)
+        finally:
+            capi.set_option("reproducible", 0)
+    finally:
+        capi.set_option("ldsx", 1)
+        capi.set_option("cg_fixed_order", 1)
+
+
+def pysynth_uniform(nrow, ncol, per):
+    from oracle import pysynth
+    return pysynth.uniform(nrow, ncol, per, 0x5EED55, valued=False)
 
 
 _NGPU3 = {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}
