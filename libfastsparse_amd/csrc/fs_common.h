@@ -86,6 +86,7 @@ struct TiledCsr {
   bool built = false;
   bool ldsx = false;           // geometry of the LDS-staged kernel (W <= kLdsxCols, R <= kLdsxRows)
   int R = 0, W = 0, P = 0, J = 0, lcol_bits = kTiledColBits;
+  float entries_per_tile = 0.f;  // nnz / (P * J): how full the (panel, band) tiles are on average
   unsigned *pk = nullptr;      // nnz packed (local row, local col)
   double *vals = nullptr;      // nnz permuted values (nullptr: pattern-only)
   int4 *items = nullptr;       // nitems: {first entry, count, band, 0}

@@ -122,7 +122,6 @@ struct fs_dist_s {
   bool use_rccl = false;
   bool conservative = false;          // one whole-shard all-gather behind the product (FS_DIST_PARTS=1, or after an error)
   bool broken = false;                // an RCCL call failed: the communicators were aborted, every later product is an error return
-  bool fail_injected = false;
   std::vector<ncclComm_t> comm;
   std::mutex lock;                    // the streams and communicators serve one product at a time (a communicator must not be
                                       // used from two host threads at once): taken behind the matrix's own lock
@@ -459,8 +458,8 @@ int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, cons
       recv[(size_t)r] = S.pad[(size_t)r] + S.off[(size_t)p];
       ready[(size_t)r] = S.ev[(size_t)r][(size_t)p];
     }
-    const bool inject = !D->fail_injected && env_fail_part() == p;
-    if (inject) D->fail_injected = true;
+    static std::atomic<bool> injected{false};        // once per process
+    const bool inject = env_fail_part() == p && !injected.exchange(true);
     if (int rc = exchange_equal(D, send, recv, (size_t)S.maxc[(size_t)p], D->comm_stream, ready, inject)) {
       static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
       D->conservative = true;

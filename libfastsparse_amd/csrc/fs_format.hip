@@ -284,6 +284,8 @@ __global__ void count_spanning_kernel(int nchunks, int64_t nnz, const int *__res
   if ((int64_t)row_ptr[r1] > e) atomicAdd(count, 1);
 }
 
+constexpr float kLdsxClearWin = 1000.f;    // entries per tile from which the LDS-staged copy is not raced against the others
+
 namespace {
 struct BuildClock {
   hipStream_t s;
@@ -326,12 +328,21 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
   if (!allow_tiled) return FS_OK;
   // where the one-time format work goes: kept per matrix (fs_matrix_build_ms); FS_TRACE_BUILD=1 also prints it
   static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
-  if (int rc = build_binned(A, s)) return rc;
-  A.build_ms[3] = clock.lap();
-  if (int rc = build_tiled(A, s)) return rc;
-  A.build_ms[4] = clock.lap();
+  // The LDS-staged copy first: where its tiles are dense (config 3: 1 700 entries per tile) it beats the two-pass pair and the
+  // L2-tiled kernel two- to threefold (0.68 against 2.2 and 1.9 ms, measured by this builder for four rounds), and building and
+  // timing those two only to free them again cost 135 of config 3's 475 ms per matrix and 13 GB of transient HBM.  From
+  // kLdsxClearWin entries per tile on they are not built (auto mode; near the crossover -- 500 per tile -- all candidates still race).
   if (int rc = build_tiledx(A, s)) return rc;
   A.build_ms[5] = clock.lap();
+  const bool ldsx_clear_win = A.tiledx && A.tiledx->built && A.tiledx->entries_per_tile >= kLdsxClearWin && options().binning != 2 &&
+                              options().tiling != 2 && (A.tiledx->orderable || !options().reproducible);   // (a copy that cannot give the
+                                                                              // fixed-order sums asked for needs its rivals)
+  if (!ldsx_clear_win)
+    if (int rc = build_binned(A, s)) return rc;
+  A.build_ms[3] = clock.lap();
+  if (!ldsx_clear_win)
+    if (int rc = build_tiled(A, s)) return rc;
+  A.build_ms[4] = clock.lap();
   const int rc = choose_copy(A, s);        // fills build_ms[6] (timing) and starts [7] (freeing the losers)
   pool_trim();
   A.build_ms[7] += clock.lap() - A.build_ms[6];
@@ -937,14 +948,22 @@ constexpr int kReorderPer = kTiledItem / kReorderThreads;        // entries per 
 // too large to search): fixed-order products then leave this copy alone.
 constexpr int kRepairMaxClass = 256;   // entries of one class the repair searches (2048 / 32 = 64 on average)
 constexpr int kRepairMaxGroup = 8;     // entries of one row inside an item the per-class pass handles
+constexpr int kRepairMaxDup = 16;      // rows of one class with several entries that the per-class pass lists (more: it scans for the rest)
 constexpr int kRepairMaxLeft = 128;    // rows of an item left to the any-class pass
 constexpr int kRepairMaxBig = 96;      // entries of one row inside an item at most (a wave holds 128 entries of an item)
 
 template <bool ARRANGE>
 __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int4 *__restrict__ items, int lcol_bits,
                                                                       unsigned *__restrict__ pk, double *__restrict__ vals,
-                                                                      int *__restrict__ bad)
+                                                                      int *__restrict__ bad, unsigned long long *__restrict__ clk)
 {
+  // clk (FS_LDSX_REORDER_PROFILE=1, else nullptr): core clocks of thread 0 per phase, summed over the workgroups -- [0] load + count,
+  // [1] prefixes + lists, [2] the rounds (wave 0), [3] repair: rows and leaders, [4] repair per class, [5] repair of what is left,
+  // [6] copy out
+  long long tick = clk ? clock64() : 0;
+  auto lap = [&](int phase) {
+    if (clk && threadIdx.x == 0) { const long long now = clock64(); atomicAdd(&clk[phase], (unsigned long long)(now - tick)); tick = now; }
+  };
   __shared__ unsigned w[kTiledItem];
   __shared__ unsigned short lst[kTiledItem];   // entries grouped by (row class, column bank), stored order inside a group
   __shared__ unsigned short seq[kTiledItem];   // first: rank of an entry inside its (segment, class, bank); then the sequence
@@ -966,6 +985,8 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
   __shared__ unsigned short pmem[kRepairMaxBig];  // the entries of one such row
   __shared__ int nunres, ndup, wcount[32];
   __shared__ unsigned short wfree[32][16];
+  __shared__ unsigned short rmem[32][kRepairMaxGroup];   // per class: the entries of the row being brought together
+  __shared__ unsigned short dlist[32][kRepairMaxDup];   // per class: the leaders of the rows with several entries
   const int4 d = items[blockIdx.x];
   const int n = d.y, t = threadIdx.x;
   for (int i = t; i < n; i += kReorderThreads) w[i] = pk[(int64_t)d.x + i];
@@ -983,6 +1004,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
       }
   }
   __syncthreads();
+  lap(0);
   // per (class, bank): prefix over the segments, total
   for (int k = t; k < 32 * 32; k += kReorderThreads) {
     int a = 0;
@@ -1021,6 +1043,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
     }
   }
   __syncthreads();
+  lap(1);
   if (t < 64) {                                 // the rounds: wave 0, lanes 32-63 only take part in the ballots
     int remaining = t < 32 ? mine : 0, placed = 0;
     for (int r = 0;; ++r) {
@@ -1060,6 +1083,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
     }
   }
   __syncthreads();
+  lap(2);
   const int half = (n + 1) >> 1;
   // ---- the repair: the entries of a row with one wave ----------------------------------------------------------------------
   {
@@ -1089,6 +1113,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
     __syncthreads();
     // an item in which every fourth entry repeats a row (dense rows: long rows of a short panel) is not worth the search: the
     // copy then simply has no fixed-order form
+    lap(3);
     const bool hopeless = 4 * ndup > n && n > 128;   // (up to 128 entries all sit with wave 0 anyway)
     // (b) lane c of wave 0 brings the rows of class c together, one after the other, trading places with single-entry rows of
     // the SAME class only (the lanes work on disjoint lists); what does not fit that way goes on the list of (c)
@@ -1105,18 +1130,38 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
       const int base = off[t * 32], m = mine < kRepairMaxClass ? mine : kRepairMaxClass;
       unsigned short *free1 = &wfree[t][0];                       // free single-entry rows of this class per wave
       for (int v = 0; v < 16; ++v) free1[v] = 0;
+      // one pass over the class: the free single-entry rows per wave, and the LIST of the rows that need bringing together (their
+      // leaders).  The lanes then walk their lists side by side -- a handful of steps, most lanes busy in each -- instead of all
+      // scanning their 64 entries with the wave paying for the body whenever any one lane has work (that scan was 0.8 M of the
+      // kernel's 1.1 M clocks per item after the scratch array had gone; FS_LDSX_REORDER_PROFILE)
+      int nd = 0;
       for (int j = base; j < base + m; ++j)
-        if (lead[j] == j && !(flag[j] & 3)) ++free1[wave_of(j)];
-      for (int g = base; g < base + m; ++g) {
+        if (lead[j] == j) {
+          if (!(flag[j] & 3)) ++free1[wave_of(j)];
+          else if ((flag[j] & 1) && !(flag[j] & 2)) { if (nd < kRepairMaxDup) dlist[t][nd] = (unsigned short)j; ++nd; }
+        }
+      const int listed = nd < kRepairMaxDup ? nd : kRepairMaxDup;
+      // (a class with more such rows than the list holds scans for the rest behind the last listed one, as before)
+      const int steps = nd > kRepairMaxDup ? listed + (base + m - 1 - (int)dlist[t][kRepairMaxDup - 1]) : listed;
+      for (int u = 0; u < steps; ++u) {
+        const int g = u < listed ? (int)dlist[t][u] : (int)dlist[t][kRepairMaxDup - 1] + 1 + (u - listed);
         if (lead[g] != g || !(flag[g] & 1) || (flag[g] & 2)) continue;
-        int mem[kRepairMaxGroup], gs = 0;
+        // the members of the row in LDS and their waves packed into a register, four bits each: a per-lane array indexed at run time
+        // lives in scratch memory, and with the lanes of the wave taking turns (the rows differ from class to class) those
+        // accesses were 78 % of this kernel's time (1.14 M of 1.46 M clocks per item, FS_LDSX_REORDER_PROFILE)
+        unsigned short *const mem = &rmem[t][0];
+        int gs = 0;
+        unsigned mwave = 0;
         bool fits = true;
         for (int j = g; j < base + m; ++j)
-          if (lead[j] == g) { if (gs < kRepairMaxGroup) mem[gs++] = j; else fits = false; }
+          if (lead[j] == g) {
+            if (gs < kRepairMaxGroup) { mem[gs] = (unsigned short)j; mwave |= (unsigned)wave_of(j) << (4 * gs); ++gs; }
+            else fits = false;
+          }
         int best = -1, best_have = -1;                             // the wave that holds most of the row already, among those with room
         for (int v = 0; fits && v < 16; ++v) {
           int have = 0;
-          for (int q = 0; q < gs; ++q) have += wave_of(mem[q]) == v;
+          for (int q = 0; q < gs; ++q) have += (int)((mwave >> (4 * q)) & 15u) == v;
           if (have + free1[v] >= gs && have > best_have) { best = v; best_have = have; }
         }
         if (best < 0) {
@@ -1127,16 +1172,18 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
         int next = base;
         for (int q = 0; q < gs; ++q) {
           const int j = mem[q];
-          if (wave_of(j) == best) { flag[j] |= 2; continue; }
+          if ((int)((mwave >> (4 * q)) & 15u) == best) { flag[j] |= 2; continue; }
           while (next < base + m && !(wave_of(next) == best && lead[next] == next && !(flag[next] & 3))) ++next;   // a single-entry row with that wave
           if (next >= base + m) { failed = true; break; }          // (cannot happen: free1 counted it)
+          const int from = (int)((mwave >> (4 * q)) & 15u);
           trade(j, next, g);
           --free1[best];
-          ++free1[wave_of(j)];                                     // j now holds the single-entry row
+          ++free1[from];                                           // j now holds the single-entry row
         }
       }
     }
     __syncthreads();
+    lap(4);
     // (c) what is left -- rows with more entries than a wave has places for their class, or an unlucky packing -- trades places
     // with single-entry rows of ANY class of the chosen wave (a few lanes of that wave then share a bank: rare).  One row after
     // the other; the whole workgroup counts the members and the free single-entry rows per wave, thread 0 chooses and trades.
@@ -1181,6 +1228,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
     if (failed) atomicAdd(bad, 1);
   }
   __syncthreads();
+  lap(5);
   // copy out: sources into registers first (the item is permuted in place)
   double v[kReorderPer];
 #pragma unroll
@@ -1198,6 +1246,7 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
       if (vals) vals[(int64_t)d.x + pos] = v[j];
     }
   }
+  lap(6);
 }
 
 // how many column bands of W columns do the entries of panel (blockIdx.x * stride) touch?  out[2b] = bands, out[2b + 1] = entries
@@ -1384,6 +1433,7 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   }
   if (ntiles >= (1ll << 31)) return FS_OK;
   T->R = R; T->W = W; T->P = P; T->J = J;
+  T->entries_per_tile = (float)((double)A.nnz / (double)ntiles);
   FS_HIP(traced_malloc(&T->panel_row, sizeof(int) * panel_row.size()));
   FS_HIP(hipMemcpyAsync(T->panel_row, panel_row.data(), sizeof(int) * panel_row.size(), hipMemcpyHostToDevice, s));
 
@@ -1446,14 +1496,25 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
   FS_HIP(hipMemcpy(T->item_ptr, item_ptr.data(), sizeof(int) * item_ptr.size(), hipMemcpyHostToDevice));
   if (ldsx && T->nitems > 0) {
     static const bool arrange = [] { const char *v = getenv("FS_LDSX_ARRANGE"); return !(v && *v == '0'); }();
+    static const bool profile = [] { const char *v = getenv("FS_LDSX_REORDER_PROFILE"); return v && *v == '1'; }();
     Scratch<int> bad;
+    Scratch<unsigned long long> clk;
     FS_HIP(bad.alloc(1));
     FS_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+    if (profile) { FS_HIP(clk.alloc(8)); FS_HIP(hipMemsetAsync(clk, 0, 8 * sizeof(unsigned long long), s)); }
     if (arrange)
-      hipLaunchKernelGGL(ldsx_reorder_kernel<true>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals, bad.p);
+      hipLaunchKernelGGL(ldsx_reorder_kernel<true>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals, bad.p, profile ? clk.p : nullptr);
     else
-      hipLaunchKernelGGL(ldsx_reorder_kernel<false>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals, bad.p);
+      hipLaunchKernelGGL(ldsx_reorder_kernel<false>, dim3(T->nitems), dim3(kReorderThreads), 0, s, T->items, T->lcol_bits, T->pk, T->vals, bad.p, profile ? clk.p : nullptr);
     FS_HIP(hipGetLastError());
+    if (profile) {
+      unsigned long long h[8] = {};
+      FS_HIP(hipMemcpyAsync(h, clk, sizeof h, hipMemcpyDeviceToHost, s));
+      FS_HIP(hipStreamSynchronize(s));
+      fprintf(stderr, "[fastsparse] ldsx_reorder_kernel, %d items, mean clocks per item: load+count %.0f, lists %.0f, rounds %.0f, repair rows+leaders %.0f, "
+              "per class %.0f, leftovers %.0f, copy out %.0f\n", T->nitems, (double)h[0] / T->nitems, (double)h[1] / T->nitems, (double)h[2] / T->nitems,
+              (double)h[3] / T->nitems, (double)h[4] / T->nitems, (double)h[5] / T->nitems, (double)h[6] / T->nitems);
+    }
     int hbad = 0;
     FS_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
     FS_HIP(hipStreamSynchronize(s));

@@ -2415,9 +2415,10 @@ def test_native_multi_gpu_cg_with_the_vector_work_divided_by_rows(hip):
 def test_native_multi_gpu_conservative_exchange_and_fallback(hip):
     """the overlapped exchange (one all-gather per part, padded windows) has never run with more than one RCCL rank,
     so there is a conservative mode -- ONE whole-shard all-gather behind the finished local product: FS_DIST_PARTS=1 selects it, and
-    a group call that returns an error in the overlapped mode (injected here with FS_DIST_FAIL_PART) finishes that product
-    conservatively and keeps the context there.  Virtual ranks and the forced one-rank RCCL group, separate processes (the
-    environment is read once)."""
+    an exchange that fails half-issued in the overlapped mode (injected with FS_DIST_FAIL_PART: the first destination's copies /
+    rank 0's call are already enqueued) finishes that product conservatively on VIRTUAL ranks and keeps the context there; with
+    RCCL the communicators are aborted and the context returns errors (no second collective on a failed group).  Separate
+    processes (the environment is read once)."""
     import subprocess
     import sys
     code = r'''
@@ -2440,6 +2441,18 @@ assert start == (1 if os.environ.get("FS_DIST_PARTS") == "1" else 0)
 M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None)
 assert M, L.fs_last_error()
 ref = O.csr_mul(nrow, rp, cc, None, xi)
+if os.environ.get("FS_DIST_FORCE_RCCL") == "1" and os.environ.get("FS_DIST_FAIL_PART"):
+    # RCCL: a group call that failed may have launched the collective on some ranks only -- no second collective on those
+    # communicators (ADVICE r4): they are aborted, this product and every later one on the context return the error
+    y = np.full(nrow, -1.0)
+    assert L.fs_dist_spmv(M, y.ctypes.data, xi.ctypes.data) != 0 and b"aborted" in L.fs_last_error(), L.fs_last_error()
+    assert L.fs_dist_spmv(M, y.ctypes.data, xi.ctypes.data) != 0 and b"unusable" in L.fs_last_error(), L.fs_last_error()
+    L.fs_dist_matrix_destroy(M); L.fs_dist_destroy(D)
+    D2 = L.fs_dist_create(1, None)                      # a new context works
+    M2 = L.fs_dist_csr_create(D2, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None)
+    assert L.fs_dist_spmv(M2, y.ctypes.data, xi.ctypes.data) == 0 and np.array_equal(y, ref), L.fs_last_error()
+    L.fs_dist_matrix_destroy(M2); L.fs_dist_destroy(D2)
+    print("OK"); sys.exit(0)
 for rep in range(3):
     y = np.full(nrow, -1.0)
     assert L.fs_dist_spmv(M, y.ctypes.data, xi.ctypes.data) == 0, L.fs_last_error()

@@ -13,3 +13,6 @@ torch.cuda.synchronize(); t1 = time.time()
 At = capi.Matrix.from_coo(ncol, nrow, cols, rows, None)
 torch.cuda.synchronize(); t2 = time.time()
 print("build s", t1 - t0, t2 - t1, "kernels", A.kernel_name(), At.kernel_name(), "orderable", L.fs_debug_ldsx_orderable(A.h, 0), L.fs_debug_ldsx_orderable(At.h, 0))
+print("build_ms A ", A.build_ms())
+print("build_ms At", At.build_ms())
+print("held", A.device_bytes(), At.device_bytes())
