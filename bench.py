@@ -868,7 +868,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         split = {"A_mul_B_ms": prov.elapsed_ms(e[0], e[1]) / 5, "At_mul_B_ms": prov.elapsed_ms(e[1], e[2]) / 5}
         # SURVEY 8(d)'s timing protocol: every launch with its own event pair, min / median / mean of 20
         per_launch = {}
-        for name, tr, yy, xx in (("A_mul_B", False, y, x), ("At_mul_B", True, z, u)):
+        for name, tr, yy, xx in (("A_mul_B", False, y, x), ("At_mul_B", True, z, u)) if not getattr(args, "lean", False) else ():
             pairs = [(prov.event(), prov.event()) for _ in range(20)]
             for a, b in pairs:
                 a.record()
@@ -880,7 +880,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
         split["per_launch_ms"] = per_launch
         # the drop-in call as a reference caller makes it (csr_A_mul_B with malloc'ed vectors, csr.h:425): x goes up and y comes
         # down over PCIe inside the call, overlapped with the kernels part by part.  Never `value`: the PCIe-inclusive rate.
-        if hasattr(A, "spmv_host"):
+        if hasattr(A, "spmv_host") and not getattr(args, "lean", False):
             try:
                 import numpy as np
                 xh = x.cpu().numpy()
@@ -998,7 +998,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
             "device arrays in (borrowed in place: phase 0 is validation only; a drop-in caller adds the PCIe upload of 12 B per entry); "
             "A' = fs_matrix_build_transpose (device sort by column) or, at N > 1, this rank's row shard of A' from exchanged entries; "
             "one step = A x + A' u")
-    if not _multi(world) and not strong and n_global == 10_000_000 and per == 16:
+    if not _multi(world) and not strong and n_global == 10_000_000 and per == 16 and not getattr(args, "lean", False):
         rec["roofline"].update(config2_bound(bytes_per_launch, prov))
     if _multi(world):
         rec["config"].update({
@@ -1751,6 +1751,9 @@ def main():
                     help="N > 1: when the exchange inside the product disagrees with the plain whole-shard all-gather (verify_overlap, before "
                          "the timed loops) print ONE JSON line with \"error\" and the failing part / rank / row range and exit 3; default: "
                          "say so in the line (exchange_fault), switch every rank to the conservative exchange and measure that")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs (tools/profile.sh): the timed products and the self-check only -- no per-launch events, no "
+                         "host-pointer call, no probes, so that the per-kernel means of a PMC pass are the full products'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproducible-cost", action="store_true", help="c2: skip timing the products with fixed-order sums")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baselines' samples (0: the workload's default)")

@@ -139,7 +139,10 @@ constexpr int kBinBigRunEntries = 192;                     // chosen below this 
 static_assert(kBinColsBig % 1024 == 0 && kBinColsBig < 65536, "band loads are 1024 threads wide; 16-bit local ids");
 static_assert(kBinCols % 1024 == 0 && kBinCols % 4 == 0 && kBinRowsMax % 4 == 0 && kBinCols < 65536 && kBinRowsMax <= 65536,
               "band loads are 1024 threads wide; 16-bit local ids; k-column copies divide both by 2 and 4");
-constexpr int kBinGroupLog = 4;
+#ifndef FS_BIN_GROUP_LOG          // (experiment builds only, FS_HIPCC_EXTRA=-DFS_BIN_GROUP_LOG=5: 256-byte groups, profiles/r05_c2_group32_ab.txt)
+#define FS_BIN_GROUP_LOG 4
+#endif
+constexpr int kBinGroupLog = FS_BIN_GROUP_LOG;
 constexpr int kBinGroup = 1 << kBinGroupLog;  // entries per group = one 128-byte L2 line of products (runs that start on half
                                                // lines were measured 19 % slower in pass 1: 0.459 vs 0.386 ms)
 constexpr int kBinShareMin = 8192;     // a pass-1 workgroup streams at least this many entries

@@ -26,6 +26,7 @@ def pick(d, prefix, wg=None):
 
 
 def dump(name, obj):
+    obj["round"] = int(tag.lstrip("r"))
     json.dump(obj, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     print(name, "%.3f GB" % (obj["hbm_bytes_per_launch"] / 1e9))
 
@@ -57,3 +58,13 @@ dump("traffic_c5_two_pass.json", {
     "hbm_bytes_per_launch": e + lr + r + cb, "parts": {"expand": e, "longrows": lr, "reduce": r, "combine": cb},
     "algorithmic_bytes": old["algorithmic_bytes"],
     "source": "profiles/%s_c5_pmc_summary.csv (the 12 032 longest rows outside the two-pass copy); 2 x FETCH_SIZE + WRITE_SIZE" % tag})
+
+try:
+    c4 = rows_of("%s_c4_pmc_summary.csv" % tag)
+    k, kn = pick(c4, "fs::spmm_kernel<true, 5>") if any(x[0].startswith("fs::spmm_kernel<true, 5>") for x in c4) else pick(c4, "fs::spmm_kernel<true,5>")
+    dump("traffic_c4_spmm_k32.json", {
+        "rows": 10000000, "per_row": 16, "kernel": kn, "hbm_bytes_per_launch": k, "algorithmic_bytes": 7080000004,
+        "gather_model_bytes": 40960000000,
+        "source": "profiles/%s_c4_pmc_summary.csv: 2 x FETCH_SIZE + WRITE_SIZE per dispatch of the k = 32 row kernel" % tag})
+except Exception as ex:      # the c4 pass is optional
+    print("c4 not refreshed:", repr(ex))
