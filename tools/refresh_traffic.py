@@ -15,6 +15,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 def rows_of(name):
     out = {}
     for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
+        if not r["mean_FETCH_SIZE"] or not r["mean_WRITE_SIZE"]:
+            continue          # a kernel that did not run in one of the passes (a timed builder choice may differ from pass to pass)
         out[(r["kernel"], int(r["workgroups"]))] = (2.0 * float(r["mean_FETCH_SIZE"]) + float(r["mean_WRITE_SIZE"])) * 1024.0
     return out
 
