@@ -443,6 +443,19 @@ int fs_debug_fixed_order_honoured(fs_matrix_t A, int transposed)
   return a.tiledx->orderable ? 1 : 0;
 }
 
+// chunks of the LDS-staged copy that ever gave up waiting for their turn under fixed-order sums and added out of turn (a wrong order
+// of additions, not a wrong sum): 0 on a healthy run; < 0 without such a copy
+int fs_debug_ldsx_ticket_giveups(fs_matrix_t A, int transposed)
+{
+  if (!A || (transposed && !A->has_t)) return FS_ERR_ARG;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.tiledx || !a.tiledx->built || !a.tiledx->ticket) return FS_ERR_ARG;
+  int n = 0;
+  FS_HIP(hipDeviceSynchronize());
+  FS_HIP(hipMemcpy(&n, a.tiledx->ticket - 1, sizeof(int), hipMemcpyDeviceToHost));
+  return n;
+}
+
 // the two-pass copy of A (transposed != 0: of A'): device addresses of lcol, vals, gdst, lrow, prod, then n (padded entries), B, P
 // (tools/placement_probe.py: identical copies run at different speeds depending on where their arrays land)
 int fs_debug_two_pass_layout(fs_matrix_t A, int transposed, unsigned long long *out8)

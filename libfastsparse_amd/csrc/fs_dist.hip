@@ -936,10 +936,26 @@ fs_dist_matrix_t fs_dist_csr_create_from_shards(fs_dist_t D, int nrow, int ncol,
     nnz += shard_nnz[r];
   }
   if (rows != nrow) { fs::set_error("fs_dist_csr_create_from_shards: the shards' rows do not add up to nrow"); return nullptr; }
-  const bool valued = vals && n > 0 && vals[0] != nullptr;
+  // valued or pattern-only: what the first NON-EMPTY shard says (the caller chooses the cuts: an empty first shard is legal, and an
+  // empty shard's vals pointer means nothing)
+  bool valued = false;
+  for (int r = 0; r < n; ++r)
+    if (shard_nnz[r] > 0) { valued = vals && vals[r] != nullptr; break; }
   for (int r = 0; r < n; ++r)
     if (shard_nnz[r] > 0 && (valued != (vals && vals[r] != nullptr))) { fs::set_error("fs_dist_csr_create_from_shards: values for some shards only"); return nullptr; }
   DeviceGuard guard;
+  // a shard's row_ptr must end at its shard_nnz (the device kernels trust both): one int per shard, read where it lives
+  for (int r = 0; r < n; ++r) {
+    int last = 0;
+    if (space == FS_DEVICE) {
+      if (hipSetDevice(D->dev[r]) != hipSuccess || hipMemcpy(&last, row_ptr[r] + shard_rows[r], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        fs::set_error("fs_dist_csr_create_from_shards: cannot read a shard's row_ptr on its device");
+        return nullptr;
+      }
+    } else last = row_ptr[r][shard_rows[r]];
+    if ((int64_t)last != shard_nnz[r]) { fs::set_error("fs_dist_csr_create_from_shards: row_ptr[shard_rows] of a shard is not its shard_nnz"); return nullptr; }
+  }
   fs_dist_matrix_t M = new_dist_matrix(D, nrow, ncol);
   M->nnz = nnz;
   DistSide &S = M->a;

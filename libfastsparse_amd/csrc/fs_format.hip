@@ -124,7 +124,7 @@ static void free_tiled_slot(TiledCsr *&T)
 {
   if (!T) return;
   void *owned[] = {T->pk, T->vals, T->items, T->item_ptr, T->panel_row, T->vfirst, T->yv, T->chunk_panel, T->chunk_item,
-                   T->chunk_ord, T->ticket};
+                   T->chunk_ord, T->ticket ? T->ticket - 1 : nullptr};   // (ticket[-1] = the give-up counter: one block)
   for (void *q : owned)
     if (q) (void)traced_free(q);
   free(T->h_panel_row);
@@ -1597,7 +1597,12 @@ static int build_tiled_impl(DeviceCsr &A, hipStream_t s, TiledCsr *&slot, bool l
     FS_HIP(traced_malloc(&T->chunk_panel, sizeof(int) * (chunk_panel.size() ? chunk_panel.size() : 1)));
     FS_HIP(traced_malloc(&T->chunk_item, sizeof(int) * (chunk_item.size() ? chunk_item.size() : 2)));
     FS_HIP(traced_malloc(&T->chunk_ord, sizeof(int) * (chunk_ord.size() ? chunk_ord.size() : 1)));
-    FS_HIP(traced_malloc(&T->ticket, sizeof(int) * (size_t)(P > 0 ? P : 1)));
+    {   // ticket[-1]: chunks that gave up waiting for their turn (ldsx_store_slice), ever; ticket[0 .. P): whose turn it is
+      int *base = nullptr;
+      FS_HIP(traced_malloc(&base, sizeof(int) * ((size_t)(P > 0 ? P : 1) + 1)));
+      FS_HIP(hipMemset(base, 0, sizeof(int)));
+      T->ticket = base + 1;
+    }
     if (!chunk_panel.empty()) {
       FS_HIP(hipMemcpy(T->chunk_panel, chunk_panel.data(), sizeof(int) * chunk_panel.size(), hipMemcpyHostToDevice));
       FS_HIP(hipMemcpy(T->chunk_item, chunk_item.data(), sizeof(int) * chunk_item.size(), hipMemcpyHostToDevice));

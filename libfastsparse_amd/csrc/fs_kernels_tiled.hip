@@ -204,10 +204,11 @@ __global__ __launch_bounds__(kTiledBlock, 4) void spmv_tiled_kernel(
 // The panel's slice of y leaves LDS.  A workgroup that owns its rows stores them.  Chunks that share a panel add theirs into the
 // (zeroed) output with HBM atomics -- in arrival order, or, for fixed-order sums (`ordered`), one chunk after the other in the
 // order of their ordinals inside the panel: *ticket says whose turn it is.  Chunks of one panel are launched in ascending
-// ordinal order and workgroups are dispatched in index order, so the chunk waited for is running or done; the wait is bounded
-// all the same (a chunk that gives up adds out of turn: a wrong ORDER, never a hang).
+// ordinal order and workgroups are dispatched in index order (an ASSUMPTION about the hardware's dispatcher), so
+// the chunk waited for is running or done; the wait is bounded all the same: a chunk that gives up adds out of turn -- a wrong
+// ORDER, never a hang -- and says so in *giveups, which fs_debug_ldsx_ticket_giveups reads and the fixed-order tests assert is 0.
 __device__ __forceinline__ void ldsx_store_slice(const double *__restrict__ ytile, int nr, int row0, double *__restrict__ y, int ys, bool shared,
-                                                 bool ordered, int *__restrict__ ticket, int ord)
+                                                 bool ordered, int *__restrict__ ticket, int ord, int *__restrict__ giveups)
 {
   const int t = threadIdx.x;
   if (!shared) {
@@ -221,6 +222,7 @@ __device__ __forceinline__ void ldsx_store_slice(const double *__restrict__ ytil
     if (t == 0) {
       int spins = 0;
       while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ord && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
+      if (spins >= (1 << 24)) atomicAdd(giveups, 1);
     }
     __syncthreads();
   }
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_pipe_kernel(
   __syncthreads();
   // (every phase ends in __syncthreads, which waits for the phase's adds: with the builder's row-per-wave items the sums of this
   // kernel are in a fixed order as they are; `ordered` only matters for chunks that share a panel)
-  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ordered != 0, ticket + p, shared ? chunk_ord[blockIdx.x] : 0);
+  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ordered != 0, ticket + p, shared ? chunk_ord[blockIdx.x] : 0, ticket - 1);
 }
 
 // y[r * ys] = v[r] (output of a product that went through a contiguous scratch vector)
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(kTiledBlock) void spmv_ldsx_dma_kernel(
   }
   __builtin_amdgcn_s_waitcnt(FS_WAIT_IMM(0, 0));
   __syncthreads();
-  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ORDERED, ticket + p, shared ? chunk_ord[blockIdx.x] : 0);
+  ldsx_store_slice(ytile, nr, row0, y, ys, shared, ORDERED, ticket + p, shared ? chunk_ord[blockIdx.x] : 0, ticket - 1);
 }
 #endif   // FS_LAB
 

@@ -2260,6 +2260,48 @@ def _ptr_array(C, arrays):
     return (C.c_void_p * len(arrays))(*[None if a is None else a.ctypes.data for a in arrays])
 
 
+def test_native_multi_gpu_shards_with_an_empty_first_shard(hip):
+    """the caller chooses the cuts, so shard 0 may be EMPTY (vals[0] == NULL, shard_nnz[0] == 0) on a valued matrix -- it
+    used to be taken for a pattern-only matrix and rejected -- and a shard whose row_ptr does not end at its shard_nnz is refused
+    before any device kernel trusts it."""
+    import ctypes as C
+    from libfastsparse_amd import capi
+    L = capi.lib()
+    ranks = 3
+    nrow, ncol = 9000, 7000
+    c = BY_NAME["syn_u16_2048"]
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 9, nrow).astype(np.int32)
+    lens[:3000] = 0                                            # rows 0 .. 2999 empty: the first shard holds nothing
+    rp = np.zeros(nrow + 1, np.int32); np.cumsum(lens, out=rp[1:])
+    cc = rng.integers(0, ncol, int(rp[-1])).astype(np.int32)
+    vv = rng.uniform(-1, 1, int(rp[-1]))
+    cuts = [0, 3000, 6000, nrow]
+    shards = _shard_arrays(rp, cc, vv, cuts)
+    assert len(shards[0][1]) == 0
+    D = L.fs_dist_create(ranks, (C.c_int * ranks)(0, 0, 0))
+    assert D
+    try:
+        p_rp = _ptr_array(C, [s[0] for s in shards])
+        p_cc = (C.c_void_p * ranks)(None, shards[1][1].ctypes.data, shards[2][1].ctypes.data)
+        p_vv = (C.c_void_p * ranks)(None, shards[1][2].ctypes.data, shards[2][2].ctypes.data)
+        srows = (C.c_int * ranks)(3000, 3000, nrow - 6000)
+        snnz = (C.c_int64 * ranks)(*[len(s[1]) for s in shards])
+        M = L.fs_dist_csr_create_from_shards(D, nrow, ncol, srows, snnz, p_rp, p_cc, p_vv, capi.FS_HOST)
+        assert M, L.fs_last_error()
+        x = S.x_sin(ncol)
+        y = np.full(nrow, -1.0)
+        assert L.fs_dist_spmv(M, y.ctypes.data, x.ctypes.data) == 0, L.fs_last_error()
+        ref, sc = O.csr_mul(nrow, rp, cc, vv, x), O.csr_abs_scale(nrow, rp, cc, vv, x)
+        assert np.all(np.abs(y - ref) <= TOL * sc) and np.all(y[:3000] == 0.0)
+        L.fs_dist_matrix_destroy(M)
+        bad = (C.c_int64 * ranks)(0, len(shards[1][1]) + 1, len(shards[2][1]))
+        assert not L.fs_dist_csr_create_from_shards(D, nrow, ncol, srows, bad, p_rp, p_cc, p_vv, capi.FS_HOST)
+        assert b"shard_nnz" in L.fs_last_error()
+    finally:
+        L.fs_dist_destroy(D)
+
+
 @pytest.mark.parametrize("space", ["host", "device"])
 def test_native_multi_gpu_matrix_from_per_rank_shards_and_device_transpose(hip, space):
     """the native C path must hold a matrix that only exists as per-rank shards (BASELINE config 5: 3.2 G
@@ -2527,6 +2569,9 @@ def test_lds_staged_kernel_fixed_order_sums(hip, valued):
         assert all(np.array_equal(ys[0], v_) for v_ in ys[1:]), "A x differs between runs under fixed-order sums"
         assert all(np.array_equal(zs[0], v_) for v_ in zs[1:]), "A' u differs between runs under fixed-order sums"
         assert np.all(np.abs(ys[0] - ref) <= TOL * sc) and np.all(np.abs(zs[0] - reft) <= TOL * sct)
+        # no chunk gave up waiting for its turn and added out of turn (a silent break of the fixed order must show)
+        L.fs_debug_ldsx_ticket_giveups.argtypes = [C.c_void_p, C.c_int]
+        assert L.fs_debug_ldsx_ticket_giveups(A.h, 0) == 0 and L.fs_debug_ldsx_ticket_giveups(A.h, 1) == 0
         # ... and across BUILDS: a second handle made from the same arrays arranges its work items the same way (the format
         # builder is deterministic), so its fixed-order sums are the first handle's, bit for bit -- what "the same result in every
         # run of the program" needs
