@@ -3,8 +3,8 @@
 // (xGMI) WHILE the product still runs.
 //
 // This is the north_star's "host C dispatching through a thin C-ABI ... rows range-partitioned across the 8 GPUs of one
-// node with y gathered via RCCL" for a plain C caller: csr_A_mul_B / bcsr_A_mul_B / csr_At_mul_B / bcsr_At_mul_B take this
-// path when FASTSPARSE_NGPU > 1 (fs_dropin.hip).  The Python bench uses one process per GPU and torch.distributed over the
+// node with y gathered via RCCL" for a plain C caller: EVERY product entry point of sparse.h / dsparse.h / csr.h / cbcsr.h / cg.h
+// takes this path when FASTSPARSE_NGPU > 1 (fs_dropin.hip, "several GPUs").  The Python bench uses one process per GPU and torch.distributed over the
 // same RCCL (libfastsparse_amd/dist.py); both shard the same way.
 //
 // Both directions are "rows + all-gather" ("prefer holding CSR' row-sharded too"):
@@ -20,8 +20,11 @@
 // part finished -- one ncclAllGather per part on a padded buffer (counts differ between ranks), all ranks' calls of a part
 // in one ncclGroupStart/End -- while the next part computes; one fs_copy_segments launch per rank unpacks the padded buffer
 // into the full vector at the end.  No n^2 broadcasts, no host round trip.
-// The CONSERVATIVE mode (FS_DIST_PARTS=1, or after a group call of the overlapped mode returned an error) is one whole-shard
-// all-gather behind the finished local product: no send window ever reaches into rows that are still being written.
+// The CONSERVATIVE mode (FS_DIST_PARTS=1; on virtual ranks also after an exchange of the overlapped mode failed) is one whole-shard
+// all-gather behind the finished local product: no send window ever reaches into rows that are still being written.  With RCCL a
+// group call that failed aborts the communicators (no second collective on a half-issued group): the context then returns errors.
+// The caller's vectors may live in host memory or in the HBM of any device (vec_in / vec_out): a vector in HBM is read in place by
+// the ranks of its device, travels device to device to the others, and an output in HBM is written by the unpack launch itself.
 //
 // RCCL is loaded with dlopen when the first context with more than one distinct device is created, so that
 // single-GPU users never load it and a process that already holds a copy (PyTorch ships one) shares it.

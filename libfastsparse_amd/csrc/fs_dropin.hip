@@ -11,6 +11,7 @@
 //     ref-counted: a copy in use by another host thread outlives its removal from the table.
 //   * x / y may be host or device pointers (hipPointerGetAttributes decides); host vectors are
 //     staged through per-thread device buffers.  The call returns after y is complete.
+//   * FASTSPARSE_NGPU=N in the environment: every product below runs row-sharded over N GPUs ("several GPUs" further down).
 //   * y is overwritten, never accumulated into (SURVEY.md note N5).
 //   * the functions return void like the reference's; a HIP failure prints the reason and
 //     exits -- there is no CPU fallback.
