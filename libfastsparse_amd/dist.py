@@ -221,6 +221,8 @@ class ShardedOperator:
         plan = self._part_plan(nparts, y_full) if self.exchange == "allgather" or inject else None
         if inject and plan is not None:
             r_, p_ = (int(v) for v in inject.split(":"))
+            while p_ < nparts - 1 and plan["cuts"][r_][p_ + 1] <= plan["cuts"][r_][p_]:
+                p_ += 1                     # (a kernel that finishes no row in that part: the next part that does)
             a = (self.bounds[r_] + plan["cuts"][r_][p_]) * self.k
             if plan["cuts"][r_][p_ + 1] > plan["cuts"][r_][p_]:
                 yo[a] += 1.0
