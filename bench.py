@@ -1819,7 +1819,8 @@ def main():
                 raise
             # first contact with RCCL on more than one GPU must be cheap to diagnose: ONE line, from whichever
             # rank met the error (rank 0 may be waiting in a collective: the launcher ends it), a normal exit path, no retry
-            emit(error_record(ex, args, world, rank))
+            if rank == 0 or not isinstance(ex, ExchangeFault):      # (an ExchangeFault is raised on every rank: rank 0 speaks for all)
+                emit(error_record(ex, args, world, rank))
             sys.stdout.flush()
             sys.stderr.write("bench.py: rank %d: %r\n" % (rank, ex))
             os._exit(3)

@@ -11,6 +11,7 @@ Nothing here computes: `local_spmv(y_local, x_full)` is injected -- the HIP C-AB
 (`hip_local_spmv`), the oracle in the gloo tests.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -221,14 +222,18 @@ class ShardedOperator:
         plan = self._part_plan(nparts, y_full) if self.exchange == "allgather" or inject else None
         if inject and plan is not None:
             r_, p_ = (int(v) for v in inject.split(":"))
-            while p_ < nparts - 1 and plan["cuts"][r_][p_ + 1] <= plan["cuts"][r_][p_]:
-                p_ += 1                     # (a kernel that finishes no row in that part: the next part that does)
+            for _ in range(nparts):         # (a kernel that finishes no row in that part: the next part, cyclically, that does)
+                if plan["cuts"][r_][p_ + 1] > plan["cuts"][r_][p_]:
+                    break
+                p_ = (p_ + 1) % nparts
             a = (self.bounds[r_] + plan["cuts"][r_][p_]) * self.k
             if plan["cuts"][r_][p_ + 1] > plan["cuts"][r_][p_]:
                 yo[a] += 1.0
         scale = float(y_full.abs().max().item())
         scale = scale if scale > 0 else 1.0
         diff = float((yo - y_full).abs().max().item()) / scale
+        if os.environ.get("FS_DIST_DEBUG"):
+            print("verify_overlap rank", self.rank, "inject", repr(inject), "plan", None if plan is None else plan["cuts"], "diff", diff, "scale", scale, file=sys.stderr, flush=True)
         first_bad = None
         if diff > 1e-9 and plan is not None:
             # whose rows, of which part, arrived wrong on THIS rank: the first segment of the padded layout that differs
