@@ -111,5 +111,63 @@ def resident():
     L.fs_release_all()
 
 
-{"golden": golden, "resident": resident}[sys.argv[1]]()
+def edges():
+    """shapes the shard cutter must survive: no entries at all, no rows, fewer rows than ranks, one column, one long row (every
+    entry in one shard, the other ranks idle), and the same struct multiplied again after its arrays were edited (the side table's
+    fingerprint holds for sharded copies too)"""
+    be = H.HipDropinBackend()
+    i32 = np.int32
+
+    def mul(name, nout, A, x, *extra):
+        y = np.full(max(nout, 1), -1.0)
+        f = getattr(L, name)
+        f.restype = None
+        f(H._dp(y), A if isinstance(A, C._Pointer) else C.byref(A), H._dp(np.ascontiguousarray(x, dtype=np.float64)), *extra)
+        return y[:nout]
+
+    # nnz == 0: y all zero (overwritten), every format
+    e = np.zeros(0, i32)
+    assert np.array_equal(mul("A_mul_B", 5, be.sbm(5, 3, e, e), np.ones(3)), np.zeros(5))
+    assert np.array_equal(mul("At_mul_B", 3, be.sbm(5, 3, e, e), np.ones(5)), np.zeros(3))
+    assert np.array_equal(mul("bcsr_A_mul_B", 5, be.bcsr(5, 3, e, e), np.ones(3)), np.zeros(5))
+    assert np.array_equal(mul("csr_A_mul_B", 5, be.csr(5, 3, e, e, np.zeros(0)), np.ones(3)), np.zeros(5))
+    assert np.array_equal(mul("bcsr_A_mul_B2", 10, be.bcsr(5, 3, e, e), np.ones(6)), np.zeros(10))
+    # nrow == 0 (blocked: no blocks), fewer rows than ranks, one column
+    s0 = be.sbm(0, 7, e, e)
+    B0 = L.new_bsbm(C.byref(s0), 8)
+    assert B0.contents.nblocks == 0
+    y = mul("bsbm_A_mul_B", 0, B0, np.ones(7))
+    rows, cols = np.array([1, 0, 1], i32), np.array([0, 0, 0], i32)
+    assert np.array_equal(mul("A_mul_B", 2, be.sbm(2, 1, rows, cols), np.array([3.0])), np.array([3.0, 6.0]))
+    assert np.array_equal(mul("At_mul_B", 1, be.sbm(2, 1, rows, cols), np.array([2.0, 5.0])), np.array([12.0]))
+    vals = np.array([0.5, 2.0, -1.0])
+    assert np.array_equal(mul("sdm_A_mul_B", 2, be.sdm(2, 1, rows, cols, vals), np.array([4.0])), np.array([8.0, 2.0 - 4.0]))
+    # one long row among empty ones: all entries in one shard
+    n = 30_000
+    rows = np.full(n, 4, i32)
+    cols = (np.arange(n) % 977).astype(i32)
+    x = S.x_int(3, 977)
+    ref = np.zeros(9); ref[4] = x[cols].sum()
+    assert np.array_equal(mul("A_mul_B", 9, be.sbm(9, 977, rows, cols), x), ref)
+    zt = np.zeros(977); np.add.at(zt, cols, 2.0)
+    u = np.zeros(9); u[4] = 2.0
+    assert np.array_equal(mul("At_mul_B", 977, be.sbm(9, 977, rows, cols), u), zt)
+    # the same struct again after an in-place edit of its arrays: the fingerprint notices, the sharded copy is rebuilt
+    c = T.BY_NAME["syn_dup_1024"]
+    A = be.bcsr(c.nrow, c.ncol, c.rows, c.cols)
+    xi = c.xs["int"]
+    L.bcsr_A_mul_B.restype = None
+    y1 = np.full(c.nrow, -1.0)
+    L.bcsr_A_mul_B(H._dp(y1), C.byref(A), H._dp(xi))
+    rp, cc, _ = O.coo_to_csr(c.nrow, c.rows, c.cols, None)
+    assert np.array_equal(y1, O.csr_mul(c.nrow, rp, cc, None, xi))
+    cols_view = np.ctypeslib.as_array(A.cols, shape=(len(cc),))
+    cols_view[:] = (cols_view + 1) % c.ncol
+    L.bcsr_A_mul_B(H._dp(y1), C.byref(A), H._dp(xi))
+    assert np.array_equal(y1, O.csr_mul(c.nrow, rp, ((cc + 1) % c.ncol).astype(i32), None, xi))
+    assert L.fs_debug_dist_products() >= 10
+    L.fs_release_all()
+
+
+{"golden": golden, "resident": resident, "edges": edges}[sys.argv[1]]()
 print("OK")

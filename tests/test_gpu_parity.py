@@ -2104,13 +2104,14 @@ def pysynth_uniform(nrow, ncol, per):
 _NGPU3 = {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}
 
 
-@pytest.mark.parametrize("mode", ["golden", "resident"])
+@pytest.mark.parametrize("mode", ["golden", "resident", "edges"])
 def test_every_dropin_entry_point_across_three_ranks(hip, mode):
     """FASTSPARSE_NGPU=3 FASTSPARSE_DEVICES=0,0,0 routes EVERY product entry point of sparse.h / dsparse.h /
     csr.h / cbcsr.h / cg.h through the row-sharded path (fs_dropin.hip "several GPUs" -> fs_dist.hip).  `golden`: all golden cases
     through HipDropinBackend with host vectors, the single-GPU bars (bit-exact for pattern matrices with integer x, 1e-12 row-scaled
     otherwise, y pre-poisoned), every output proven to come from sharded products (fs_debug_dist_products).  `resident`: x / y in
-    HBM -- read in place and written by the unpack launch, never staged through the host.  tests/_dropin_ngpu.py is the child."""
+    HBM -- read in place and written by the unpack launch, never staged through the host.  `edges`: no entries, no rows, fewer rows
+    than ranks, one column, one long row, a struct edited in place.  tests/_dropin_ngpu.py is the child."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dropin_ngpu.py")
