@@ -2163,10 +2163,10 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
 // sums that are bit-identical from run to run set "reproducible": the LDS-staged copy leaves the race and the two-pass copy is
 // timed with its ordered pass 2.)
 template <typename F>
-static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *median)
+static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *median, int reps = 5)
 {
-  float t[5];
-  for (int rep = -1; rep < 5; ++rep) {   // run -1 warms the instruction cache and the TLB
+  float t[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+  for (int rep = -1; rep < reps; ++rep) {   // run -1 warms the instruction cache and the TLB
     FS_HIP(hipEventRecord(e0, s));
     if (int rc = launch()) return rc;
     FS_HIP(hipEventRecord(e1, s));
@@ -2175,8 +2175,8 @@ static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, f
     FS_HIP(hipEventElapsedTime(&ms, e0, e1));
     if (rep >= 0) t[rep] = ms;
   }
-  std::sort(t, t + 5);
-  *median = t[2];                          // the tiled kernel's fastest run is not typical of it; its median is
+  std::sort(t, t + reps);
+  *median = t[reps / 2];                   // the tiled kernel's fastest run is not typical of it; its median is
   return FS_OK;
 }
 
@@ -2202,7 +2202,10 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   FS_HIP(hipEventCreate(&e0));
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return FS_OK; }
   float t_stream = 1e30f, t_tiled = 1e30f, t_bin = 1e30f, t_ldsx = 1e30f;
-  int rc = time_product([&] { return launch_spmv(A, y, x, s, true); }, s, e0, e1, &t_stream);
+  // (a lone LDS-staged copy with dense tiles -- build_schedule did not build its rivals -- is 8 to 15 times faster than the
+  // streaming kernel: one timed run of that one is enough to say so, five cost 25-50 ms of a 230 ms build on config 3)
+  const bool lone_ldsx = hx && !hb && !ht && A.tiledx->entries_per_tile >= kLdsxClearWin;
+  int rc = time_product([&] { return launch_spmv(A, y, x, s, true); }, s, e0, e1, &t_stream, lone_ldsx ? 1 : 5);
   if (rc == FS_OK && ht) rc = time_product([&] { return launch_spmv_tiled(A, *A.tiled, y, x, s); }, s, e0, e1, &t_tiled);
   if (rc == FS_OK && hx) rc = time_product([&] { return launch_spmv_tiled(A, *A.tiledx, y, x, s); }, s, e0, e1, &t_ldsx);
   if (rc == FS_OK && hb) rc = time_product([&] { return launch_spmv_binned(A, y, x, s); }, s, e0, e1, &t_bin);

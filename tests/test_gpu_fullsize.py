@@ -431,3 +431,17 @@ def test_native_multi_gpu_path_holds_more_than_2_31_entries(hip_env):
         if M:
             L.fs_dist_matrix_destroy(M)
         L.fs_dist_destroy(D)
+
+
+def test_config2_through_the_dropin_on_three_virtual_ranks(hip_env):
+    """BASELINE config 2 at full size through the reference's own entry points with FASTSPARSE_NGPU=3 (three virtual ranks on this
+    GPU): host structs in, vectors in HBM, the products row-sharded; exact integer checksums, adjointness of the transposed product,
+    oracle windows (tests/_dropin_ngpu.py, mode fullsize)."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dropin_ngpu.py")
+    env = dict(os.environ, FASTSPARSE_NGPU="3", FASTSPARSE_DEVICES="0,0,0")
+    p = subprocess.run([sys.executable, child, "fullsize"], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and p.stdout.rstrip().endswith("OK"), p.stdout[-3000:] + p.stderr[-3000:]
+    print(p.stdout[-600:])
