@@ -902,9 +902,23 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     else:
         split = {"A_mul_B_ms": sum(prov.elapsed_ms(e[0], e[1]) for e in evs) / len(evs),
                  "At_mul_B_ms": sum(prov.elapsed_ms(e[2], e[3]) for e in evs) / len(evs)}
-    noex = None
+    noex = piped = None
     if _multi(world):   # the same loop without any exchange: what the exchanges cost on top of the local products
         noex, _, _ = timed_steps(prov, lambda ev=None: step(None, exchange=False), lambda: None, args.steps, 1, world, nccl)
+        # and with the two products of a step treated as what BASELINE config 2 defines -- INDEPENDENT (x and u are given vectors):
+        # y's exchange then runs under the local product of A' u, and only the end of the step waits for both vectors.  Reported
+        # beside `value`, which keeps the iterating consumer's order (y complete before A' starts, cg.h:15-16).
+        if z_scheme == "gather":
+            def step_piped(ev=None):
+                hy = op_a.apply_overlapped_async(y, x, nparts)
+                hz = op_t.apply_overlapped_async(z, u, nparts)
+                hy.wait()
+                hz.wait()
+            try:
+                piped, _, _ = timed_steps(prov, step_piped, lambda: None, args.steps, 1, world, nccl)
+            except Exception as ex:
+                piped = None
+                z_err = (z_err or "") + " pipelined loop: %r" % (ex,)
 
     # self-check outside the timed region (no oracle here: that is the tests' job): the products the timed loop left in
     # y and z against the storage-order chunk-streaming kernel on the same operands, and, at N > 1, every rank holding
@@ -1011,6 +1025,10 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
                              "z_row_shards_of_At_plus_all_gather": F8 * (world - 1) / world,
                              "z_all_reduce_ring": 2.0 * F8 * (world - 1) / world}},
             "ms_per_step_without_exchanges": noex / args.steps * 1e3 if noex else None,
+            "ms_per_step_products_independent": piped / args.steps * 1e3 if piped else None,
+            "value_products_independent_GBs": total_bytes / piped / 1e9 if piped else None,
+            "products_independent_what": "the same two products per step with y's all-gather running under the local product of A' u (the "
+                                         "two products of BASELINE config 2 are independent); `value` keeps y complete before A' starts",
             "rccl_status": "first contact: no multi-GPU machine was available to the builder; numbers above are the driver's"})
         rec["config"]["exchange"].update({"parts": nparts, "mode": "conservative (one whole-shard all-gather behind the local product)"
                                           if nparts <= 1 or (exchange_check or {}).get("y", {}).get("mode") == "conservative"

@@ -410,7 +410,8 @@ def _c2_worker(rank, world, port, z_scheme, ret):
             ok = ok and rc["ranks_counted_by_all_reduce_of_ones"] == world and len(rc["ranks"]) == world \
                 and sorted(r["rank"] for r in rc["ranks"]) == list(range(world)) and len(rec["per_rank"]) == world \
                 and ex["parts"] == 3 and ex["mode"].startswith("overlapped") and "exchange_fault" not in rec \
-                and "WEAK scaling" in rec["config"]["workload"] and rec["aggregate_frac_of_hbm_peak"] > 0
+                and "WEAK scaling" in rec["config"]["workload"] and rec["aggregate_frac_of_hbm_peak"] > 0 \
+                and (z_scheme != "gather" or rec["config"]["ms_per_step_products_independent"] > 0)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
