@@ -311,7 +311,8 @@ int  fs_dist_swap_xy(fs_dist_matrix_t M);
 int  fs_dist_cg(fs_dist_matrix_t M, double *x_host, const double *b_host, double lambda, double tol, int *out_iter);
 /* k row-major columns across the GPUs (csr_A_mul_Bn csr.h:441, bcsr_A_mul_Bn csr.h:257, bsbm_A_mul_Bn sparse.h:318): every device
  * multiplies its shard with the k-column kernels of fs_spmm (prepared on the first call with a new k: synchronous) and the Y shards
- * are all-gathered in one whole-shard exchange; host matrices Y[nrow, k], X[ncol, k] / Z[ncol, k], U[nrow, k]; k = 1 is fs_dist_spmv */
+ * are all-gathered -- inside the product, part by part, where the k-column product finishes its rows that way (the one-sweep plan
+ * of k = 2, 4: fs_spmm_part), otherwise in one whole-shard exchange behind it; host matrices Y[nrow, k], X[ncol, k] / Z[ncol, k], U[nrow, k]; k = 1 is fs_dist_spmv */
 int  fs_dist_spmm(fs_dist_matrix_t M, double *Y_host, const double *X_host, int k);
 int  fs_dist_spmm_t(fs_dist_matrix_t M, double *Z_host, const double *U_host, int k);
 /* (A'A + lambda I) X = B with two right-hand sides, row-major ncol x 2: bsbm_cg2 (cg.h:85-187) across the GPUs; the vector steps

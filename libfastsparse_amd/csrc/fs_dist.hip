@@ -95,6 +95,8 @@ struct DeviceGuard {
   ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
+// FS_DIST_FAIL_PART (tests): the exchange of part p fails, once per process -- whichever product gets there first
+bool take_injection(int p);
 std::atomic<long> g_products{0};     // sharded products launched by this process (fs_debug_dist_products: the tests' proof of the path taken)
 
 int env_parts()
@@ -113,6 +115,12 @@ int env_fail_part()
 {
   static const int v = [] { const char *e = getenv("FS_DIST_FAIL_PART"); return e && *e ? atoi(e) : -1; }();
   return v;
+}
+
+bool take_injection(int p)
+{
+  static std::atomic<bool> injected{false};
+  return env_fail_part() == p && !injected.exchange(true);
 }
 
 }  // namespace
@@ -161,13 +169,28 @@ struct CgWork {                       // vectors of fs_dist_cg, kept on the hand
 
 // k row-major columns on the sharded matrix (fs_dist_spmm, fs_dist_cg2): the replicated X / Y / Z, the shards' local outputs, the
 // padded receive buffer, the unpack tables (offsets and counts times k) and the work vectors of the block solver, per rank
+// the k-column local product of one side in parts (fs_spmm_part: the one-sweep plan of k = 2, 4 is cut like the single-vector pair),
+// with the padded layout of the exchange of every part -- the k-column twin of DistSide's plan; counts in ROWS (x k doubles)
+struct KParts {
+  int np = 1;
+  bool real = false;                    // some rank finishes rows in more than one part: the overlapped exchange has something to hide
+  std::vector<std::vector<int>> cut;    // [rank][part]
+  std::vector<int> maxc;                // [part]
+  std::vector<int64_t> off;             // [part]: first ROW of the part's region of the padded buffer
+  int nseg = 0;
+  int64_t max_seg = 0;                  // in doubles
+  size_t tab_at = 0;                    // where this side's (dst, src, cnt) table starts in KWork::tab
+};
+
 struct KWork {
   int k = 0;
   bool with_t = false;
   bool ready = false;                   // every allocation and prepare below succeeded
+  unsigned epoch = 0;                   // fs::option_epoch() when the parts were planned
   std::vector<double *> x, y, z, la, lt, pad;
-  std::vector<int64_t *> tab;           // [A side: dst, src, cnt][A' side: dst, src, cnt]
+  std::vector<int64_t *> tab;           // [A whole-shard: dst, src, cnt][A' whole-shard][A in parts][A' in parts]
   int nseg_a = 0, nseg_t = 0;
+  KParts pa, pt;
   std::vector<double *> sol, r, b, part, red, st;
 };
 
@@ -461,8 +484,7 @@ int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, cons
       recv[(size_t)r] = S.pad[(size_t)r] + S.off[(size_t)p];
       ready[(size_t)r] = S.ev[(size_t)r][(size_t)p];
     }
-    static std::atomic<bool> injected{false};        // once per process
-    const bool inject = env_fail_part() == p && !injected.exchange(true);
+    const bool inject = take_injection(p);
     if (int rc = exchange_equal(D, send, recv, (size_t)S.maxc[(size_t)p], D->comm_stream, ready, inject)) {
       static const bool trace = getenv("FS_TRACE_BUILD") != nullptr;
       D->conservative = true;
@@ -689,12 +711,20 @@ int ensure_k(fs_dist_matrix_t M, int k)
   const int n = D->n;
   KWork &W = M->kw;
   const bool with_t = M->t.built;
-  if (W.ready && W.k == k && W.with_t == with_t) return FS_OK;
+  if (W.ready && W.k == k && W.with_t == with_t && W.epoch == fs::option_epoch()) return FS_OK;
   if (int rc = dist_sync(D)) return rc;
   free_k(D, W);
-  W.k = k; W.with_t = with_t;
+  W.k = k; W.with_t = with_t; W.epoch = fs::option_epoch();
   for (auto *v : {&W.x, &W.y, &W.z, &W.la, &W.lt, &W.pad, &W.sol, &W.r, &W.b, &W.part, &W.red, &W.st}) v->assign((size_t)n, nullptr);
   W.tab.assign((size_t)n, nullptr);
+  // the k-column copies of the shards first (fs_spmm itself never builds): the parts below belong to the plan they leave
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    if (M->a.shard[(size_t)r])
+      if (int rc = fs_matrix_prepare(M->a.shard[(size_t)r], k, 0, D->stream[r])) return rc;
+    if (with_t && M->t.shard[(size_t)r])
+      if (int rc = fs_matrix_prepare(M->t.shard[(size_t)r], k, 0, D->stream[r])) return rc;
+  }
   const int64_t mr = std::max<int64_t>(M->a.max_rows, with_t ? M->t.max_rows : 0);
   std::vector<int64_t> tab;
   auto side_table = [&](const DistSide &S, int *nseg) {
@@ -713,15 +743,57 @@ int ensure_k(fs_dist_matrix_t M, int k)
   };
   side_table(M->a, &W.nseg_a);
   if (with_t) side_table(M->t, &W.nseg_t);
+  // the local products in parts and the padded layout of every part's exchange (rows; the tables are in doubles)
+  auto side_parts = [&](DistSide &S, KParts &P) -> int {
+    P = KParts();
+    P.np = S.nparts > 0 ? S.nparts : 1;
+    P.cut.assign((size_t)n, std::vector<int>((size_t)P.np + 1, 0));
+    for (int r = 0; r < n; ++r) {
+      const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+      if (nl <= 0) continue;
+      FS_HIP(hipSetDevice(D->dev[r]));
+      if (int rc = fs_spmm_part_rows(S.shard[(size_t)r], 0, k, P.np, P.cut[(size_t)r].data())) return rc;
+      int busy = 0;
+      for (int p = 0; p < P.np; ++p) busy += P.cut[(size_t)r][(size_t)p + 1] > P.cut[(size_t)r][(size_t)p];
+      P.real = P.real || busy > 1;
+    }
+    P.maxc.assign((size_t)P.np, 0);
+    P.off.assign((size_t)P.np + 1, 0);
+    for (int p = 0; p < P.np; ++p) {
+      for (int r = 0; r < n; ++r) P.maxc[(size_t)p] = std::max(P.maxc[(size_t)p], P.cut[(size_t)r][(size_t)p + 1] - P.cut[(size_t)r][(size_t)p]);
+      P.off[(size_t)p + 1] = P.off[(size_t)p] + (int64_t)n * P.maxc[(size_t)p];
+    }
+    std::vector<int64_t> dst, src, cnt;
+    for (int p = 0; p < P.np; ++p)
+      for (int r = 0; r < n; ++r) {
+        const int64_t c = P.cut[(size_t)r][(size_t)p + 1] - P.cut[(size_t)r][(size_t)p];
+        if (!c) continue;
+        dst.push_back(((int64_t)S.bounds[(size_t)r] + P.cut[(size_t)r][(size_t)p]) * k);
+        src.push_back((P.off[(size_t)p] + (int64_t)r * P.maxc[(size_t)p]) * k);
+        cnt.push_back(c * k);
+        P.max_seg = std::max<int64_t>(P.max_seg, c * k);
+      }
+    P.nseg = (int)cnt.size();
+    P.tab_at = tab.size();
+    tab.insert(tab.end(), dst.begin(), dst.end());
+    tab.insert(tab.end(), src.begin(), src.end());
+    tab.insert(tab.end(), cnt.begin(), cnt.end());
+    return FS_OK;
+  };
+  if (int rc = side_parts(M->a, W.pa)) return rc;
+  if (with_t)
+    if (int rc = side_parts(M->t, W.pt)) return rc;
+  const int64_t pad_rows = std::max<int64_t>((int64_t)n * mr, std::max<int64_t>(W.pa.off[(size_t)W.pa.np], with_t ? W.pt.off[(size_t)W.pt.np] : 0));
   const size_t F = (size_t)(M->ncol ? M->ncol : 1) * k, N = (size_t)(M->nrow ? M->nrow : 1) * k;
   for (int r = 0; r < n; ++r) {
     FS_HIP(hipSetDevice(D->dev[r]));
     FS_HIP(hipMalloc(&W.x[(size_t)r], sizeof(double) * F));
     FS_HIP(hipMalloc(&W.y[(size_t)r], sizeof(double) * N));
     FS_HIP(hipMalloc(&W.z[(size_t)r], sizeof(double) * F));
-    FS_HIP(hipMalloc(&W.la[(size_t)r], sizeof(double) * (size_t)(M->a.max_rows + 1) * k));
-    FS_HIP(hipMalloc(&W.lt[(size_t)r], sizeof(double) * (size_t)((with_t ? M->t.max_rows : 0) + 1) * k));
-    FS_HIP(hipMalloc(&W.pad[(size_t)r], sizeof(double) * (size_t)(n * mr + 1) * k));
+    // (the send window of a part starts at its first row and is maxc[p] rows long: it may run past the shard's last row)
+    FS_HIP(hipMalloc(&W.la[(size_t)r], sizeof(double) * (size_t)(2 * (int64_t)M->a.max_rows + 1) * k));
+    FS_HIP(hipMalloc(&W.lt[(size_t)r], sizeof(double) * (size_t)(2 * (int64_t)(with_t ? M->t.max_rows : 0) + 1) * k));
+    FS_HIP(hipMalloc(&W.pad[(size_t)r], sizeof(double) * (size_t)(pad_rows + 1) * k));
     FS_HIP(hipMalloc(&W.tab[(size_t)r], sizeof(int64_t) * (tab.size() + 1)));
     if (!tab.empty()) FS_HIP(hipMemcpy(W.tab[(size_t)r], tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice));
     FS_HIP(hipMalloc(&W.sol[(size_t)r], sizeof(double) * F));
@@ -730,19 +802,13 @@ int ensure_k(fs_dist_matrix_t M, int k)
     FS_HIP(hipMalloc(&W.part[(size_t)r], sizeof(double) * fs::kCgPartDoubles));
     FS_HIP(hipMalloc(&W.red[(size_t)r], sizeof(double) * 4));
     FS_HIP(hipMalloc(&W.st[(size_t)r], sizeof(double) * fs::kCgStateDoubles));
-    // the k-column copies of the shards (fs_spmm itself never builds)
-    if (M->a.shard[(size_t)r])
-      if (int rc = fs_matrix_prepare(M->a.shard[(size_t)r], k, 0, D->stream[r])) return rc;
-    if (with_t && M->t.shard[(size_t)r])
-      if (int rc = fs_matrix_prepare(M->t.shard[(size_t)r], k, 0, D->stream[r])) return rc;
   }
   W.ready = true;      // (a failure above leaves ready = false: the next call frees what exists and starts over)
   return FS_OK;
 }
 
-// out = M in for k row-major columns on every rank: the local product, then ONE whole-shard all-gather (the conservative form of
-// the exchange; the k-column product in parts, fs_spmm_part, is what the overlapped form would ride on)
-int dist_product_k(fs_dist_matrix_t M, bool transposed, const std::vector<double *> &in, const std::vector<double *> &out)
+// the whole-shard exchange of a k-column product: ONE all-gather of max_rows * k doubles per rank behind the finished local product
+int dist_gather_k(fs_dist_matrix_t M, bool transposed, const std::vector<double *> &out)
 {
   fs_dist_t D = M->D;
   const int n = D->n;
@@ -750,14 +816,10 @@ int dist_product_k(fs_dist_matrix_t M, bool transposed, const std::vector<double
   DistSide &S = transposed ? M->t : M->a;
   const int k = W.k;
   const std::vector<double *> &loc = transposed ? W.lt : W.la;
-  ++g_products;
   std::vector<const double *> send((size_t)n);
   std::vector<hipEvent_t> ready((size_t)n);
   for (int r = 0; r < n; ++r) {
-    const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
     FS_HIP(hipSetDevice(D->dev[r]));
-    if (nl > 0)
-      if (int rc = fs_spmm(S.shard[(size_t)r], loc[(size_t)r], in[(size_t)r], k, D->stream[r])) return rc;
     FS_HIP(hipEventRecord(S.ev[(size_t)r][0], D->stream[r]));
     FS_HIP(hipStreamWaitEvent(D->comm_stream[r], S.ev[(size_t)r][0], 0));
     send[(size_t)r] = loc[(size_t)r];
@@ -770,6 +832,69 @@ int dist_product_k(fs_dist_matrix_t M, bool transposed, const std::vector<double
     FS_HIP(hipSetDevice(D->dev[r]));
     const int64_t *tab = W.tab[(size_t)r] + (transposed ? 3 * (size_t)W.nseg_a : 0);
     if (int rc = fs_copy_segments(nseg, tab, (int64_t)S.max_rows * k, W.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])) return rc;
+    FS_HIP(hipEventRecord(S.done[(size_t)r], D->comm_stream[r]));
+    FS_HIP(hipStreamWaitEvent(D->stream[r], S.done[(size_t)r], 0));
+  }
+  return FS_OK;
+}
+
+// out = M in for k row-major columns on every rank.  Where the local k-column product finishes its rows part by part (fs_spmm_part:
+// the one-sweep plan of k = 2, 4 -- the block-CG products) the exchange runs INSIDE the product like dist_product's: the all-gather
+// of the rows part p finished under part p + 1, one unpack at the end.  Every other plan (row kernel, column sweeps), FS_DIST_PARTS=1
+// and a context gone conservative: the local product, then ONE whole-shard all-gather.
+int dist_product_k(fs_dist_matrix_t M, bool transposed, const std::vector<double *> &in, const std::vector<double *> &out)
+{
+  fs_dist_t D = M->D;
+  const int n = D->n;
+  KWork &W = M->kw;
+  DistSide &S = transposed ? M->t : M->a;
+  KParts &P = transposed ? W.pt : W.pa;
+  const int k = W.k;
+  const std::vector<double *> &loc = transposed ? W.lt : W.la;
+  if (D->broken) { fs::set_error("fs_dist: this context is unusable after an RCCL error (its communicators were aborted)"); return FS_ERR_HIP; }
+  ++g_products;
+  if (D->conservative || P.np <= 1 || !P.real) {
+    for (int r = 0; r < n; ++r) {
+      const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+      FS_HIP(hipSetDevice(D->dev[r]));
+      if (nl > 0)
+        if (int rc = fs_spmm(S.shard[(size_t)r], loc[(size_t)r], in[(size_t)r], k, D->stream[r])) return rc;
+    }
+    return dist_gather_k(M, transposed, out);
+  }
+  const int np = P.np;
+  for (int p = 0; p < np; ++p) {
+    std::vector<const double *> send((size_t)n);
+    std::vector<double *> recv((size_t)n);
+    std::vector<hipEvent_t> ready((size_t)n);
+    for (int r = 0; r < n; ++r) {
+      const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+      FS_HIP(hipSetDevice(D->dev[r]));
+      if (nl > 0)
+        if (int rc = fs_spmm_part(S.shard[(size_t)r], 0, loc[(size_t)r], in[(size_t)r], k, p, np, D->stream[r])) return rc;
+      FS_HIP(hipEventRecord(S.ev[(size_t)r][(size_t)p], D->stream[r]));
+      FS_HIP(hipStreamWaitEvent(D->comm_stream[r], S.ev[(size_t)r][(size_t)p], 0));
+      send[(size_t)r] = loc[(size_t)r] + (int64_t)P.cut[(size_t)r][(size_t)p] * k;
+      recv[(size_t)r] = W.pad[(size_t)r] + P.off[(size_t)p] * k;
+      ready[(size_t)r] = S.ev[(size_t)r][(size_t)p];
+    }
+    if (int rc = exchange_equal(D, send, recv, (size_t)P.maxc[(size_t)p] * (size_t)k, D->comm_stream, ready, take_injection(p))) {
+      D->conservative = true;
+      if (D->use_rccl) return rc;          // exchange_equal aborted the communicators
+      // virtual ranks: finish the local product, then the whole-shard exchange (see dist_product)
+      for (int q = p + 1; q < np; ++q)
+        for (int r = 0; r < n; ++r) {
+          if (S.bounds[(size_t)r + 1] == S.bounds[(size_t)r]) continue;
+          FS_HIP(hipSetDevice(D->dev[r]));
+          if (int rc2 = fs_spmm_part(S.shard[(size_t)r], 0, loc[(size_t)r], in[(size_t)r], k, q, np, D->stream[r])) return rc2;
+        }
+      if (int rc2 = dist_sync(D)) return rc2;
+      return dist_gather_k(M, transposed, out);
+    }
+  }
+  for (int r = 0; r < n; ++r) {
+    FS_HIP(hipSetDevice(D->dev[r]));
+    if (int rc = fs_copy_segments(P.nseg, W.tab[(size_t)r] + P.tab_at, P.max_seg, W.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])) return rc;
     FS_HIP(hipEventRecord(S.done[(size_t)r], D->comm_stream[r]));
     FS_HIP(hipStreamWaitEvent(D->stream[r], S.done[(size_t)r], 0));
   }
@@ -837,6 +962,21 @@ void fs_dist_destroy(fs_dist_t D)
 }
 
 long fs_debug_dist_products(void) { return g_products.load(); }   // diagnostics, not in include/fastsparse_hip.h
+
+// in how many parts the k-column product of the handle's current k finishes rows (the most any rank has; 1: the exchange simply
+// follows the product; 0: no k-column product was made yet)
+int fs_debug_dist_k_parts(fs_dist_matrix_t M, int transposed)
+{
+  if (!M || !M->kw.ready) return 0;
+  const KParts &P = transposed ? M->kw.pt : M->kw.pa;
+  int most = 0;
+  for (const std::vector<int> &c : P.cut) {
+    int busy = 0;
+    for (size_t p = 0; p + 1 < c.size(); ++p) busy += c[p + 1] > c[p];
+    most = std::max(most, busy);
+  }
+  return most;
+}
 
 int fs_dist_ndev(fs_dist_t D) { return D ? D->n : FS_ERR_ARG; }
 int fs_dist_uses_rccl(fs_dist_t D) { return D ? (int)D->use_rccl : FS_ERR_ARG; }

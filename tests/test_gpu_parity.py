@@ -2484,6 +2484,14 @@ assert start == (1 if os.environ.get("FS_DIST_PARTS") == "1" else 0)
 M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None)
 assert M, L.fs_last_error()
 ref = O.csr_mul(nrow, rp, cc, None, xi)
+if len(sys.argv) > 2 and sys.argv[2] == "k2first":
+    # the k-column exchange inside the product (fs_spmm_part) meets the injected failure: finished conservatively on virtual ranks
+    X2 = np.ascontiguousarray(np.stack([xi, 2.0 * xi], 1))
+    Y2 = np.full((nrow, 2), -1.0)
+    assert L.fs_dist_spmm(M, Y2.ctypes.data, X2.ctypes.data, 2) == 0, L.fs_last_error()
+    assert np.array_equal(Y2[:, 0], ref) and np.array_equal(Y2[:, 1], 2.0 * ref)
+    assert L.fs_dist_is_conservative(D) == 1
+    assert L.fs_dist_spmm(M, Y2.ctypes.data, X2.ctypes.data, 2) == 0 and np.array_equal(Y2[:, 1], 2.0 * ref)
 if os.environ.get("FS_DIST_FORCE_RCCL") == "1" and os.environ.get("FS_DIST_FAIL_PART"):
     # RCCL: a group call that failed may have launched the collective on some ranks only -- no second collective on those
     # communicators (ADVICE r4): they are aborted, this product and every later one on the context return the error
@@ -2519,6 +2527,9 @@ print("OK")
     for ranks, extra in runs:
         p = subprocess.run([sys.executable, "-c", code, ranks], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, (ranks, extra, p.stdout[-1500:] + p.stderr[-1500:])
+    p = subprocess.run([sys.executable, "-c", code, "3", "k2first"], env=dict(os.environ, FS_DIST_FAIL_PART="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout, ("k2first", p.stdout[-1500:] + p.stderr[-1500:])
 
 
 @pytest.mark.parametrize("valued", [False, True])
@@ -2728,6 +2739,8 @@ def test_native_multi_gpu_k_column_products_and_block_cg(hip, ranks):
     D = L.fs_dist_create(ranks, (C.c_int * ranks)(*([0] * ranks)))
     assert D
     capi.set_option("binning", 2)
+    capi.set_option("bin_rows", 64)        # many panels per shard: the k = 2 sweep finishes its rows in several parts
+    L.fs_debug_dist_k_parts.argtypes = [C.c_void_p, C.c_int]
     try:
         for vals in (None, vv):
             M = L.fs_dist_csr_create(D, nrow, ncol, len(cc), rp.ctypes.data, cc.ctypes.data, None if vals is None else vals.ctypes.data)
@@ -2742,6 +2755,9 @@ def test_native_multi_gpu_k_column_products_and_block_cg(hip, ranks):
                     np.ascontiguousarray(np.stack([np.sin(11.0 * np.arange(nrow) - 0.2 + j) for j in range(k)], 1))
                 Z = np.full((ncol, k), -1.0)
                 assert L.fs_dist_spmm_t(M, Z.ctypes.data, U.ctypes.data, k) == 0, L.fs_last_error()
+                if k == 2 and ranks > 1:        # the exchange ran INSIDE the product (round 5): the sweep was really cut
+                    assert L.fs_debug_dist_k_parts(M, 0) >= 2 and L.fs_debug_dist_k_parts(M, 1) >= 2, \
+                        (L.fs_debug_dist_k_parts(M, 0), L.fs_debug_dist_k_parts(M, 1))
                 for j in range(k):
                     zref = O.coo_tmul(ncol, rows_all, cc, vals, np.ascontiguousarray(U[:, j]))
                     if vals is None:
@@ -2771,4 +2787,5 @@ def test_native_multi_gpu_k_column_products_and_block_cg(hip, ranks):
             L.fs_dist_matrix_destroy(M)
     finally:
         capi.set_option("binning", 1)
+        capi.set_option("bin_rows", 0)
         L.fs_dist_destroy(D)
