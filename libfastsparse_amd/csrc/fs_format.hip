@@ -948,7 +948,6 @@ constexpr int kReorderPer = kTiledItem / kReorderThreads;        // entries per 
 // too large to search): fixed-order products then leave this copy alone.
 constexpr int kRepairMaxClass = 256;   // entries of one class the repair searches (2048 / 32 = 64 on average)
 constexpr int kRepairMaxGroup = 8;     // entries of one row inside an item the per-class pass handles
-constexpr int kRepairMaxDup = 16;      // rows of one class with several entries that the per-class pass lists (more: it scans for the rest)
 constexpr int kRepairMaxLeft = 128;    // rows of an item left to the any-class pass
 constexpr int kRepairMaxBig = 96;      // entries of one row inside an item at most (a wave holds 128 entries of an item)
 
@@ -984,9 +983,6 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
   __shared__ unsigned short unres[kRepairMaxLeft]; // leaders of the rows the per-class pass could not bring together
   __shared__ unsigned short pmem[kRepairMaxBig];  // the entries of one such row
   __shared__ int nunres, ndup, wcount[32];
-  __shared__ unsigned short wfree[32][16];
-  __shared__ unsigned short rmem[32][kRepairMaxGroup];   // per class: the entries of the row being brought together
-  __shared__ unsigned short dlist[32][kRepairMaxDup];   // per class: the leaders of the rows with several entries
   const int4 d = items[blockIdx.x];
   const int n = d.y, t = threadIdx.x;
   for (int i = t; i < n; i += kReorderThreads) w[i] = pk[(int64_t)d.x + i];
@@ -1091,15 +1087,50 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
     for (int g = t; g < n; g += kReorderThreads) crow[g] = (unsigned short)(w[seq[cplace[g]]] >> lcol_bits);
     __syncthreads();
     bool too_large = false;
-    for (int g = t; g < n; g += kReorderThreads) {
-      const int c = crow[g] & 31;
-      const int base = off[c * 32];
-      flag[g] = 0;
-      if (g - base >= kRepairMaxClass) { too_large = true; lead[g] = (unsigned short)g; continue; }
-      int first = g;
-      for (int j = base; j < g; ++j)
-        if (crow[j] == crow[g]) { first = j; break; }
-      lead[g] = (unsigned short)first;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    auto rdlane = [](int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); };
+    // wave wv takes the classes 8 wv .. 8 wv + 7, one after the other, 64 entries of the class with its lanes at a time: the rows
+    // travel between the lanes through v_readlane (a thread per entry scanning its class in LDS was 83 K of the kernel's clocks)
+    for (int q8 = 0; q8 < 8; ++q8) {
+      const int c = wv * 8 + q8;
+      // (wave-uniform values read from LDS: said so, or the loops over a class run under exec masks with their counters in VGPRs --
+      // that alone was 70 K clocks per item)
+      const int base = __builtin_amdgcn_readfirstlane((int)off[c * 32]);
+      const int msize = __builtin_amdgcn_readfirstlane((c < 31 ? (int)off[(c + 1) * 32] : n) - base);
+      const int m = msize < kRepairMaxClass ? msize : kRepairMaxClass;
+      int row[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = 64 * e + lane;
+        row[e] = idx < m ? (int)crow[base + idx] : -1 - idx;              // (no row is negative: a lane outside the class matches nothing)
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (64 * e < m) {
+          int first = -1;                                                  // place in the class of the first earlier entry of this row
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            if (e2 <= e) {
+              const int lim = e2 < e ? 64 : lane;
+              const int cnt = m - 64 * e2 < 64 ? m - 64 * e2 : 64;
+              for (int l = 0; l < cnt; ++l) {
+                const int rl = rdlane(row[e2], l);
+                if (first < 0 && rl == row[e] && l < lim) first = 64 * e2 + l;
+              }
+            }
+          }
+          const int idx = 64 * e + lane;
+          if (idx < m) {
+            lead[base + idx] = (unsigned short)(base + (first < 0 ? idx : first));
+            flag[base + idx] = 0;
+          }
+        }
+      }
+      for (int idx = kRepairMaxClass + lane; idx < msize; idx += 64) {     // a class beyond what the repair searches
+        lead[base + idx] = (unsigned short)(base + idx);
+        flag[base + idx] = 0;
+        too_large = true;
+      }
     }
     __syncthreads();
     if (t == 0) { nunres = 0; ndup = 0; }
@@ -1126,61 +1157,122 @@ __global__ __launch_bounds__(kReorderThreads) void ldsx_reorder_kernel(const int
       lead[k] = (unsigned short)g; flag[k] = 2;                  // the member now lives at k, for good
       lead[j] = (unsigned short)j; flag[j] = 0;                  // j holds the single-entry row
     };
-    if (t < 32 && mine > 0 && !hopeless) {
-      const int base = off[t * 32], m = mine < kRepairMaxClass ? mine : kRepairMaxClass;
-      unsigned short *free1 = &wfree[t][0];                       // free single-entry rows of this class per wave
-      for (int v = 0; v < 16; ++v) free1[v] = 0;
-      // one pass over the class: the free single-entry rows per wave, and the LIST of the rows that need bringing together (their
-      // leaders).  The lanes then walk their lists side by side -- a handful of steps, most lanes busy in each -- instead of all
-      // scanning their 64 entries with the wave paying for the body whenever any one lane has work (that scan was 0.8 M of the
-      // kernel's 1.1 M clocks per item after the scratch array had gone; FS_LDSX_REORDER_PROFILE)
-      int nd = 0;
-      for (int j = base; j < base + m; ++j)
-        if (lead[j] == j) {
-          if (!(flag[j] & 3)) ++free1[wave_of(j)];
-          else if ((flag[j] & 1) && !(flag[j] & 2)) { if (nd < kRepairMaxDup) dlist[t][nd] = (unsigned short)j; ++nd; }
-        }
-      const int listed = nd < kRepairMaxDup ? nd : kRepairMaxDup;
-      // (a class with more such rows than the list holds scans for the rest behind the last listed one, as before)
-      const int steps = nd > kRepairMaxDup ? listed + (base + m - 1 - (int)dlist[t][kRepairMaxDup - 1]) : listed;
-      for (int u = 0; u < steps; ++u) {
-        const int g = u < listed ? (int)dlist[t][u] : (int)dlist[t][kRepairMaxDup - 1] + 1 + (u - listed);
-        if (lead[g] != g || !(flag[g] & 1) || (flag[g] & 2)) continue;
-        // the members of the row in LDS and their waves packed into a register, four bits each: a per-lane array indexed at run time
-        // lives in scratch memory, and with the lanes of the wave taking turns (the rows differ from class to class) those
-        // accesses were 78 % of this kernel's time (1.14 M of 1.46 M clocks per item, FS_LDSX_REORDER_PROFILE)
-        unsigned short *const mem = &rmem[t][0];
-        int gs = 0;
-        unsigned mwave = 0;
-        bool fits = true;
-        for (int j = g; j < base + m; ++j)
-          if (lead[j] == g) {
-            if (gs < kRepairMaxGroup) { mem[gs] = (unsigned short)j; mwave |= (unsigned)wave_of(j) << (4 * gs); ++gs; }
-            else fits = false;
+    // Wave wv takes the classes 8 wv .. 8 wv + 7 one after the other with its lanes holding the class's entries (four per lane:
+    // up to kRepairMaxClass): which row is next, who its members are, which wave holds most of them and where that wave has a free
+    // single-entry row are BALLOTS over the lanes, a handful of instructions each, where one lane per class used to walk 64-entry
+    // lists in LDS (0.28 M of the kernel's 0.59 M clocks per item).  Same choices as that serial form, so the same arrangement:
+    // rows in ascending leader order, the wave that holds most members (the lowest on a tie), free rows lowest index first.
+    if (!hopeless) {
+      for (int q8 = 0; q8 < 8; ++q8) {
+        const int c = wv * 8 + q8;
+        const int base = __builtin_amdgcn_readfirstlane((int)off[c * 32]);
+        const int msize = __builtin_amdgcn_readfirstlane((c < 31 ? (int)off[(c + 1) * 32] : n) - base);
+        const int m = msize < kRepairMaxClass ? msize : kRepairMaxClass;
+        if (m <= 0) continue;
+        int wof[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wof[e] = 64 * e + lane < m ? wave_of(base + 64 * e + lane) : 31;
+        int myfree = 0;                                              // lane v < 16: free single-entry rows of this class with wave v
+        {
+          bool fr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int g = base + 64 * e + lane;
+            fr[e] = 64 * e + lane < m && lead[g] == g && !(flag[g] & 3);
           }
-        int best = -1, best_have = -1;                             // the wave that holds most of the row already, among those with room
-        for (int v = 0; fits && v < 16; ++v) {
-          int have = 0;
-          for (int q = 0; q < gs; ++q) have += (int)((mwave >> (4 * q)) & 15u) == v;
-          if (have + free1[v] >= gs && have > best_have) { best = v; best_have = have; }
+          for (int v = 0; v < 16; ++v) {
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cnt += __popcll(__ballot(fr[e] && wof[e] == v));
+            if (lane == v) myfree = cnt;
+          }
         }
-        if (best < 0) {
-          const int slot = atomicAdd(&nunres, 1);
-          if (slot < kRepairMaxLeft) unres[slot] = (unsigned short)g; else failed = true;
-          continue;
-        }
-        int next = base;
-        for (int q = 0; q < gs; ++q) {
-          const int j = mem[q];
-          if ((int)((mwave >> (4 * q)) & 15u) == best) { flag[j] |= 2; continue; }
-          while (next < base + m && !(wave_of(next) == best && lead[next] == next && !(flag[next] & 3))) ++next;   // a single-entry row with that wave
-          if (next >= base + m) { failed = true; break; }          // (cannot happen: free1 counted it)
-          const int from = (int)((mwave >> (4 * q)) & 15u);
-          trade(j, next, g);
-          --free1[best];
-          ++free1[from];                                           // j now holds the single-entry row
+        int cursor = -1;                                             // place in the class of the last row handled
+        for (;;) {
+          int G = -1;                                                // the next leader of a row with several entries
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int idx = 64 * e + lane, g = base + idx;
+            const bool d = idx < m && idx > cursor && lead[g] == g && (flag[g] & 1) && !(flag[g] & 2);
+            const unsigned long long mk = __ballot(d);
+            if (G < 0 && mk) G = 64 * e + __ffsll((long long)mk) - 1;
+          }
+          if (G < 0) break;
+          cursor = G;
+          const int gG = base + G;
+          bool mem[4];
+          int gs = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            mem[e] = 64 * e + lane < m && lead[base + 64 * e + lane] == gG;
+            gs += __popcll(__ballot(mem[e]));
+          }
+          int best = -1;
+          if (gs <= kRepairMaxGroup) {
+            int have = 0;                                            // lane v < 16: members already with wave v
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              unsigned long long bits = __ballot(mem[e]);
+              while (bits) {
+                const int l = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                if (lane == rdlane(wof[e], l)) ++have;
+              }
+            }
+            int key = (lane < 16 && have + myfree >= gs) ? ((have << 8) | (15 - lane)) : -1;   // most members; the lowest wave on a tie
+            for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other > key ? other : key; }
+            if (key >= 0) best = 15 - (key & 255);
+          }
+          if (best < 0) {                                            // too many entries, or no wave with room: left to (c)
+            if (lane == 0) {
+              const int slot = atomicAdd(&nunres, 1);
+              if (slot < kRepairMaxLeft) unres[slot] = (unsigned short)gG; else failed = true;
+            }
+            continue;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned long long bits = __ballot(mem[e]);
+            while (bits) {
+              const int l = __ffsll((long long)bits) - 1;
+              bits &= bits - 1;
+              const int j = base + 64 * e + l;
+              const int wj = rdlane(wof[e], l);
+              if (wj == best) {
+                if (lane == 0) flag[j] |= 2;
+                wave_lds_fence();
+                continue;
+              }
+              int k = -1;                                            // the lowest free single-entry row with that wave
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) {
+                const int g2 = base + 64 * e2 + lane;
+                const bool f = 64 * e2 + lane < m && wof[e2] == best && lead[g2] == g2 && !(flag[g2] & 3);
+                const unsigned long long fm = __ballot(f);
+                if (k < 0 && fm) k = base + 64 * e2 + __ffsll((long long)fm) - 1;
+              }
+              if (k < 0) { failed = true; break; }                   // (cannot happen: myfree counted it)
+              if (lane == 0) trade(j, k, gG);
+              wave_lds_fence();
+              if (lane == best) --myfree;
+              if (lane == wj) ++myfree;                              // j now holds the single-entry row
+            }
+          }
+          wave_lds_fence();
         }
       }
+    }
+    __syncthreads();
+    // the rows left to (c) in ascending order whichever wave listed them first: the arrangement must not depend on timing
+    {
+      const int cnt = nunres < kRepairMaxLeft ? nunres : kRepairMaxLeft;
+      int mine_u = 0, rank = 0;
+      if (t < cnt) {
+        mine_u = unres[t];
+        for (int j = 0; j < cnt; ++j) rank += unres[j] < mine_u;
+      }
+      __syncthreads();
+      if (t < cnt) unres[rank] = (unsigned short)mine_u;
     }
     __syncthreads();
     lap(4);
