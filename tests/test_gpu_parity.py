@@ -1977,6 +1977,62 @@ print("OK")
         assert p.returncode == 0 and "OK" in p.stdout, (mode, p.stdout[-1500:] + p.stderr[-1500:])
 
 
+@pytest.mark.parametrize("kind", ["two-pass", "lds-staged", "tiled", "stream", "long rows"])
+def test_non_finite_x_reaches_exactly_the_rows_that_reference_it(hip, kind):
+    """csr.h:430-437 multiplies what it is given: a NaN or an infinity in x[c] must reach exactly the rows with an entry in column c
+    -- padding entries, zero slots behind a band of x, clamped addresses and masked lanes of the re-ordered copies must not leak
+    it into any other row -- and a -0.0 must stay harmless.  Every kept kernel, valued and pattern-only, single vector and k = 2,
+    against the oracle (NaN == NaN, infinities with their sign; finite rows within the row-scaled bound)."""
+    import torch
+    from libfastsparse_amd import capi
+    opt, nrow, ncol, per = {"two-pass": ("binning", 200_000, 150_001, 9), "lds-staged": ("ldsx", 120_000, 6_001, 40),
+                            "tiled": ("tiling", 200_000, 300_000, 8), "stream": (None, 30_000, 20_000, 10),
+                            "long rows": ("binning", 150_000, 120_000, 6)}[kind]
+    rng = np.random.default_rng(len(kind))
+    lens = rng.integers(0, 2 * per, nrow)
+    if kind == "long rows":
+        lens[[7, 70_000]] = [90_000, 40_000]
+        capi.set_option("long_rows", 2)
+    rp = np.zeros(nrow + 1, np.int64); np.cumsum(lens, out=rp[1:]); rp = rp.astype(np.int32)
+    cc = rng.integers(0, ncol, int(rp[-1])).astype(np.int32)
+    vv = rng.uniform(-1, 1, int(rp[-1]))
+    x = S.x_sin(ncol)
+    bad = {"nan": 17, "+inf": ncol // 2, "-0": ncol - 1}
+    x[bad["nan"]], x[bad["+inf"]], x[bad["-0"]] = np.nan, np.inf, -0.0
+    if opt:
+        capi.set_option(opt, 2)
+    try:
+        st = capi.current_stream()
+        for vals in (vv, None):
+            A = capi.Matrix.from_csr(nrow, ncol, torch.from_numpy(rp).cuda(), torch.from_numpy(cc).cuda(),
+                                     None if vals is None else torch.from_numpy(vals).cuda())
+            assert A.kernel_name() == {"long rows": "two-pass"}.get(kind, kind), A.kernel_name()
+            ref = O.csr_mul(nrow, rp, cc, vals, x)
+            xf = np.where(np.isfinite(x), x, 0.0)
+            scale = O.csr_abs_scale(nrow, rp, cc, vals, xf)
+            y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+            A.spmv(y, torch.from_numpy(x).cuda(), st)
+            got = y.cpu().numpy()
+            fin = np.isfinite(ref)
+            assert 0 < (~fin).sum() < nrow // 2                                         # some rows are hit, most are not
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isposinf(got), np.isposinf(ref)) \
+                and np.array_equal(np.isneginf(got), np.isneginf(ref)), kind
+            assert np.all(np.abs(got[fin] - ref[fin]) <= TOL * scale[fin]), kind
+            X2 = np.ascontiguousarray(np.stack([x, S.x_sin(ncol, 3.0, 0.5)], 1))        # the second column is clean: it must stay clean
+            Y2 = torch.full((nrow, 2), -1.0, dtype=torch.float64, device="cuda")
+            A.prepare(2, st)
+            A.spmm(Y2, torch.from_numpy(X2).cuda(), 2, st)
+            g2 = Y2.cpu().numpy()
+            r1 = O.csr_mul(nrow, rp, cc, vals, np.ascontiguousarray(X2[:, 1]))
+            assert np.all(np.isfinite(g2[:, 1])) and np.all(np.abs(g2[:, 1] - r1) <= TOL * O.csr_abs_scale(nrow, rp, cc, vals, np.ascontiguousarray(X2[:, 1])))
+            assert np.array_equal(np.isnan(g2[:, 0]), np.isnan(ref)) and np.array_equal(np.isinf(g2[:, 0]), np.isinf(ref))
+            A.close()
+    finally:
+        if opt:
+            capi.set_option(opt, 1)
+        capi.set_option("long_rows", 1)
+
+
 def test_release_and_restore_of_the_plain_csr(hip):
     """once the builder has kept a re-ordered copy the plain arrays are dead weight.  fs_matrix_release_csr gives
     them back (A and A'): the default products are unchanged, the handle holds its copy alone, everything that reads the plain arrays
