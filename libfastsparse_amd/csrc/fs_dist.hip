@@ -643,6 +643,8 @@ int make_shards(fs_dist_t D, DistSide &S, int nrow, int ncol, const RP *row_ptr,
     for (int i = lo; i <= hi; ++i) lrp[(size_t)(i - lo)] = (int)((int64_t)row_ptr[i] - a);
     S.shard_nnz[(size_t)r] = b - a;
     FS_HIP(hipSetDevice(D->dev[r]));
+    fs::KeepCsrScope keep_plain_arrays;     // (option release_csr is not for shards: the exchange layer's own later work -- A' on the
+                                            //  devices, a k-column prepare -- reads them)
     S.shard[(size_t)r] = fs_csr_create(hi - lo, ncol, b - a, lrp.data(), cols ? cols + a : nullptr, vals ? vals + a : nullptr, FS_HOST, 0);
     if (!S.shard[(size_t)r]) return FS_ERR_HIP;
   }
@@ -1111,6 +1113,8 @@ fs_dist_matrix_t fs_dist_csr_create_from_shards(fs_dist_t D, int nrow, int ncol,
     S.bounds[(size_t)r + 1] = S.bounds[(size_t)r] + shard_rows[r];
     S.shard_nnz[(size_t)r] = shard_nnz[r];
     ok = hipSetDevice(D->dev[r]) == hipSuccess;
+    fs::KeepCsrScope keep_plain_arrays;     // (option release_csr is not for shards: the exchange layer's own later work -- A' on the
+                                            //  devices, a k-column prepare -- reads them)
     if (ok) S.shard[(size_t)r] = fs_csr_create(shard_rows[r], ncol, shard_nnz[r], row_ptr[r], cols[r], valued ? vals[r] : nullptr, space, 0);
     ok = ok && S.shard[(size_t)r] != nullptr;
   }
@@ -1165,6 +1169,8 @@ int fs_dist_matrix_build_transpose(fs_dist_matrix_t M, const int *row_ptr, const
         }
       std::lock_guard<std::mutex> cg(create_lock);
       if (hipSetDevice(D->dev[r]) != hipSuccess) { rcs[(size_t)r] = FS_ERR_HIP; errs[(size_t)r] = "hipSetDevice failed"; return; }
+      fs::KeepCsrScope keep_plain_arrays;     // (option release_csr is not for shards: the exchange layer's own later work -- A' on the
+                                              //  devices, a k-column prepare -- reads them)
       T.shard[(size_t)r] = fs_csr_create(hi - lo, nrow, cnt, lrp.data(), lc.data(), vals ? lv.data() : nullptr, FS_HOST, 0);
       if (!T.shard[(size_t)r]) { rcs[(size_t)r] = FS_ERR_HIP; errs[(size_t)r] = fs_last_error(); }
     });
@@ -1284,6 +1290,8 @@ int fs_dist_matrix_build_transpose_device(fs_dist_matrix_t M)
     FS_HIP(hipSetDevice(D->dev[d]));
     for (void **p : {(void **)&W.trow[(size_t)d], (void **)&W.tcol[(size_t)d], (void **)&W.tval[(size_t)d]})
       if (*p) { (void)hipFree(*p); *p = nullptr; }
+    fs::KeepCsrScope keep_plain_arrays;     // (option release_csr is not for shards: the exchange layer's own later work -- A' on the
+                                            //  devices, a k-column prepare -- reads them)
     T.shard[(size_t)d] = fs_coo_create(T.bounds[(size_t)d + 1] - T.bounds[(size_t)d], nrow, T.shard_nnz[(size_t)d], W.rrow[(size_t)d], W.rcol[(size_t)d],
                                        valued ? W.rval[(size_t)d] : nullptr, FS_DEVICE);
     if (!T.shard[(size_t)d]) { free_side(D, T); return FS_ERR_HIP; }

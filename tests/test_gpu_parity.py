@@ -2094,6 +2094,18 @@ def test_release_and_restore_of_the_plain_csr(hip):
             B.spmv(y, xd, st)
             assert np.all(np.abs(y.cpu().numpy() - ref) <= TOL * scale)
             B.close()
+            # the option is not for the shards of the multi-GPU layer: its own later work (A' on the devices, a k-column prepare)
+            # reads their plain arrays
+            import ctypes as C
+            L = capi.lib()
+            D = L.fs_dist_create(2, (C.c_int * 2)(0, 0))
+            M = L.fs_dist_csr_create(D, n, n, len(hcc), hrp.ctypes.data, hcc.ctypes.data, hvv.ctypes.data)
+            assert M, L.fs_last_error()
+            assert L.fs_dist_matrix_build_transpose_device(M) == 0, L.fs_last_error()
+            Yh = np.full((n, 2), -1.0)
+            assert L.fs_dist_spmm(M, Yh.ctypes.data, X2.ctypes.data, 2) == 0, L.fs_last_error()
+            assert np.all(np.abs(Yh[:, 0] - ref) <= TOL * scale)
+            L.fs_dist_matrix_destroy(M); L.fs_dist_destroy(D)
         finally:
             capi.set_option("release_csr", 0)
     finally:
