@@ -1703,6 +1703,42 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
     return recs
 
 
+def native_path_records(world, args):
+    """The ONE-PROCESS path of the C-ABI (fs_dist_*: one host thread, N devices, ncclCommInitAll -- what FASTSPARSE_NGPU gives an
+    unmodified C caller, the north_star's "host C dispatching through a thin C-ABI ... y gathered via RCCL") on the same GPUs, as a
+    CHILD of rank 0 (libfastsparse_amd/native_dist_bench.py) after this process' own workloads, twice: the exchange inside the
+    product (FS_DIST_PARTS=4) and the conservative one (FS_DIST_PARTS=1).  A crash, a hang (time-out) or a launcher that shows
+    every rank one device only costs this sub-record, never the line."""
+    out = {}
+    for tag, parts in (("overlapped_4_parts", "4"), ("conservative_1_part", "1")):
+        env = dict(os.environ, FS_DIST_PARTS=parts)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "FS_BENCH_SPAWNED"):
+            env.pop(k, None)
+        if world == 1:
+            env["FS_DIST_FORCE_RCCL"] = "1"       # (the one-rank rehearsal: RCCL on one device)
+        cmd = [sys.executable, "-m", "libfastsparse_amd.native_dist_bench", "--ndev", str(world), "--rows", str(args.rows), "--cols", str(args.rows),
+               "--per-row", str(args.per_row), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=float(os.environ.get("FS_BENCH_NATIVE_TIMEOUT_S", "150")))
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            out[tag] = json.loads(lines[-1]) if lines else {"error": "no record (exit %d): %s" % (p.returncode, (p.stderr or p.stdout)[-600:])}
+            if p.returncode != 0 and "error" not in out[tag]:
+                out[tag]["exit_code"] = p.returncode
+        except subprocess.TimeoutExpired:
+            out[tag] = {"error": "timed out (a hung collective?)", "after_s": time.perf_counter() - t0}
+            break                                  # do not start the second run behind a hang
+        except Exception as ex:
+            out[tag] = {"error": repr(ex)}
+    a, b = out.get("overlapped_4_parts", {}), out.get("conservative_1_part", {})
+    if a.get("self_check") and b.get("self_check"):
+        ca, cb = a["self_check"]["y_checksum"], b["self_check"]["y_checksum"]
+        out["both_exchanges_agree"] = bool(abs(ca - cb) <= 1e-9 * max(abs(ca), 1.0))
+    out["what"] = ("fs_dist_spmv_resident + fs_dist_spmv_t_resident on config-2 shards made on the devices; one host thread issues for every "
+                   "rank (profiles/r05_dist_host_overhead.txt); the number to compare with is this line's `value`")
+    return out
+
+
 _STDOUT_FD = None       # N > 1: the real stdout, kept aside while fd 1 points at stderr (see quiet_stdout)
 
 
@@ -1850,6 +1886,16 @@ def main():
             budget = float(os.environ.get("FS_BENCH_BUDGET_S", "480")) - (time.perf_counter() - t_start)
             dog = budget_watchdog(max(budget, 5.0), rank, rec, also, state)
             run_also(args, prov, world, rank, nccl, recs=also, state=state)
+            if _multi(world) and nccl and not os.environ.get("FS_BENCH_NO_NATIVE"):
+                # the same GPUs once more, through the one-process C path (a child of rank 0; the other ranks wait at the barrier)
+                state["current"] = "native one-process path"
+                prov.release()
+                dist.barrier()
+                native = native_path_records(world, args) if rank == 0 else None
+                dist.barrier()
+                if rank == 0:
+                    also.append({"workload": "native one-process path (fs_dist_*)", "native_one_process_path": native})
+                state["current"] = None
             dog.cancel()
             if rank == 0 and rec is not None:
                 rec["also"] = also

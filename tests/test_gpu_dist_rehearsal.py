@@ -173,6 +173,20 @@ def test_bench_runs_its_multi_rank_plan_on_one_rccl_rank():
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     recs = [rec] + rec["also"]
     assert len(recs) >= 4, [r["config"]["workload"][:40] for r in recs]
+    native = [r for r in recs if "native_one_process_path" in r]
     for r in recs:
-        assert r["config"]["self_check"]["ok"], r["config"]
+        if "native_one_process_path" not in r:
+            assert r["config"]["self_check"]["ok"], r["config"]
     assert "all-gather" in rec["config"]["exchange"]["y"]
+    # the line proves its world -- the rank count from an all-reduce of ones, every rank's device
+    rc = rec["rccl"]
+    assert rc["ranks_counted_by_all_reduce_of_ones"] == 1 and rc["world_size"] == 1 and rc["backend"].startswith("nccl") \
+        and rc["ranks"][0]["rank"] == 0 and "pci_bus_id" in rc["ranks"][0] and rc["rccl_version"], rc
+    assert len(rec["per_rank"]) == 1 and rec["aggregate_frac_of_hbm_peak"] > 0 and rec["config"]["exchange"]["parts"] == 4
+    # and the same GPU through the ONE-PROCESS C path (fs_dist_*, ncclCommInitAll on a one-device group here), both exchanges
+    assert len(native) == 1, [r.get("workload") for r in recs]
+    nat = native[0]["native_one_process_path"]
+    for tag in ("overlapped_4_parts", "conservative_1_part"):
+        assert "error" not in nat[tag] and nat[tag]["uses_rccl"] and nat[tag]["self_check"]["ok"] and nat[tag]["value"] > 0, nat[tag]
+    assert nat["conservative_1_part"]["conservative_exchange"] and not nat["overlapped_4_parts"]["conservative_exchange"]
+    assert nat["both_exchanges_agree"]
