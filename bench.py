@@ -1706,12 +1706,13 @@ def run_also(args, prov, world, rank, nccl, recs=None, state=None):
 def native_path_records(world, args):
     """The ONE-PROCESS path of the C-ABI (fs_dist_*: one host thread, N devices, ncclCommInitAll -- what FASTSPARSE_NGPU gives an
     unmodified C caller, the north_star's "host C dispatching through a thin C-ABI ... y gathered via RCCL") on the same GPUs, as a
-    CHILD of rank 0 (libfastsparse_amd/native_dist_bench.py) after this process' own workloads, twice: the exchange inside the
-    product (FS_DIST_PARTS=4) and the conservative one (FS_DIST_PARTS=1).  A crash, a hang (time-out) or a launcher that shows
+    CHILD of rank 0 (libfastsparse_amd/native_dist_bench.py) after this process' own workloads, three times: the exchange inside the
+    product (FS_DIST_PARTS=4), the conservative one (FS_DIST_PARTS=1), and the first again with one ISSUING THREAD per rank
+    (FS_DIST_THREADS=1, experimental: the remedy for this path's ~50 us of serial issue work per rank and product).  A crash, a hang (time-out) or a launcher that shows
     every rank one device only costs this sub-record, never the line."""
     out = {}
-    for tag, parts in (("overlapped_4_parts", "4"), ("conservative_1_part", "1")):
-        env = dict(os.environ, FS_DIST_PARTS=parts)
+    for tag, parts, threads in (("overlapped_4_parts", "4", "0"), ("conservative_1_part", "1", "0"), ("overlapped_4_parts_issue_threads", "4", "1")):
+        env = dict(os.environ, FS_DIST_PARTS=parts, FS_DIST_THREADS=threads)
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "FS_BENCH_SPAWNED"):
             env.pop(k, None)
         if world == 1:

@@ -40,6 +40,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -125,6 +127,77 @@ bool take_injection(int p)
 
 }  // namespace
 
+// One ISSUING thread per rank (FS_DIST_THREADS=1; experimental, off by default).  One host thread pays about 50 us per rank and
+// product for the launches, events and exchange calls of the ranks one after the other (profiles/r05_dist_host_overhead.txt): at
+// N = 8 the one-process path is issue-bound for products below ~0.5 ms.  With this switch every rank's calls come from a thread of
+// its own -- its device current once and for all -- and a product is a few rounds of "every rank does its piece, then all meet".
+// With RCCL each thread issues ITS communicator's ncclAllGather (no group: the many-threads-one-device-each form of the API).
+// UNVERIFIED on more than one GPU, like the rest of this file; libfastsparse_amd/native_dist_bench.py times it beside the default.
+struct RankWorkers {
+  int n = 0;
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable go, done;
+  std::function<int(int)> job;
+  unsigned long gen = 0;
+  int pending = 0, fixed_order = 0;
+  bool stop = false;
+  std::vector<int> rc;
+  std::vector<std::string> err;
+
+  void start(const std::vector<int> &dev)
+  {
+    n = (int)dev.size();
+    rc.assign((size_t)n, 0);
+    err.assign((size_t)n, std::string());
+    for (int r = 0; r < n; ++r)
+      th.emplace_back([this, r, d = dev[(size_t)r]] {
+        (void)hipSetDevice(d);
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          go.wait(lk, [&] { return stop || gen != seen; });
+          if (stop) return;
+          seen = gen;
+          const std::function<int(int)> f = job;
+          const int fo = fixed_order;
+          lk.unlock();
+          fs::tl_fixed_order = fo;              // the caller's solver scope (thread-local there) holds for its ranks' launches too
+          const int code = f(r);
+          const std::string why = code ? fs_last_error() : "";
+          fs::tl_fixed_order = 0;
+          lk.lock();
+          rc[(size_t)r] = code;
+          err[(size_t)r] = why;
+          if (--pending == 0) done.notify_one();
+        }
+      });
+  }
+  // f(r) on every rank's thread; returns when all are back: the first error (its message becomes the caller's), or FS_OK
+  int run(const std::function<int(int)> &f)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    job = f;
+    fixed_order = fs::tl_fixed_order;
+    pending = n;
+    ++gen;
+    go.notify_all();
+    done.wait(lk, [&] { return pending == 0; });
+    for (int r = 0; r < n; ++r)
+      if (rc[(size_t)r]) { fs::set_error(err[(size_t)r]); return rc[(size_t)r]; }
+    return FS_OK;
+  }
+  ~RankWorkers()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    go.notify_all();
+    for (std::thread &t : th) t.join();
+  }
+};
+
 struct fs_dist_s {
   int n = 0;
   std::vector<int> dev;               // device of every rank
@@ -133,6 +206,7 @@ struct fs_dist_s {
   bool use_rccl = false;
   bool conservative = false;          // one whole-shard all-gather behind the product (FS_DIST_PARTS=1, or after an error)
   bool broken = false;                // an RCCL call failed: the communicators were aborted, every later product is an error return
+  std::unique_ptr<RankWorkers> workers;   // FS_DIST_THREADS=1: one issuing thread per rank (else null: the calling thread issues)
   std::vector<ncclComm_t> comm;
   std::mutex lock;                    // the streams and communicators serve one product at a time (a communicator must not be
                                       // used from two host threads at once): taken behind the matrix's own lock
@@ -265,6 +339,7 @@ void nnz_cut(std::vector<int> &bounds, int n, int nrow, const RP *row_ptr)
 }
 
 int dist_sync(fs_dist_t D);
+int dist_product_threaded(fs_dist_t D, DistSide &S, const std::vector<double *> &in, const std::vector<double *> &out);
 
 void free_plan(fs_dist_t D, DistSide &S)
 {
@@ -457,6 +532,7 @@ int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, cons
   if (D->broken) { fs::set_error("fs_dist: this context is unusable after an RCCL error (its communicators were aborted)"); return FS_ERR_HIP; }
   ++g_products;
   if (int rc = replan_if_moved(D, S)) return rc;
+  if (D->workers) return dist_product_threaded(D, S, in, out);
   const int np = S.nparts;
   if (D->conservative || np == 1) {
     // one whole-shard all-gather behind the finished local product: no window reaches into rows still being written
@@ -514,8 +590,71 @@ int dist_product(fs_dist_t D, DistSide &S, const std::vector<double *> &in, cons
   return FS_OK;
 }
 
+// dist_product with one issuing thread per rank (RankWorkers): the same launches, events and exchange calls, every rank's from its
+// own thread.  The rounds end in a meeting of all threads, so a rank's event is recorded before another rank's stream is told to
+// wait for it (virtual ranks), and every thread reaches its all-gather of a part (RCCL).  No failure injection on this path.
+int dist_product_threaded(fs_dist_t D, DistSide &S, const std::vector<double *> &in, const std::vector<double *> &out)
+{
+  RankWorkers &W = *D->workers;
+  const int n = D->n, np = S.nparts;
+  const bool whole = D->conservative || np == 1;
+  auto exchange = [&](const std::function<const double *(int)> &send, const std::function<double *(int)> &recv, size_t count, int evp) -> int {
+    if (!count) return FS_OK;
+    if (D->use_rccl) {
+      std::vector<ncclResult_t> res((size_t)n, ncclSuccess);
+      (void)W.run([&](int r) -> int { res[(size_t)r] = rccl().AllGather(send(r), recv(r), count, ncclDouble, D->comm[(size_t)r], D->comm_stream[r]); return FS_OK; });
+      for (int r = 0; r < n; ++r)
+        if (res[(size_t)r] != ncclSuccess) {           // as in exchange_equal: no second collective on communicators in doubt
+          const int rc = nccl_fail(res[(size_t)r], "ncclAllGather (issuing threads)");
+          const std::string why = fs_last_error();
+          for (ncclComm_t &c : D->comm)
+            if (c) { if (rccl().CommAbort) (void)rccl().CommAbort(c); c = nullptr; }
+          D->broken = true;
+          fs::set_error(why + "; the RCCL communicators were aborted: create a new context");
+          return rc;
+        }
+      return FS_OK;
+    }
+    return W.run([&](int d) -> int {
+      for (int r = 0; r < n; ++r) {
+        FS_HIP(hipStreamWaitEvent(D->comm_stream[d], S.ev[(size_t)r][(size_t)evp], 0));
+        FS_HIP(hipMemcpyAsync(recv(d) + (int64_t)r * (int64_t)count, send(r), sizeof(double) * count, hipMemcpyDeviceToDevice, D->comm_stream[d]));
+      }
+      return FS_OK;
+    });
+  };
+  for (int p = 0; p < (whole ? 1 : np); ++p) {
+    if (int rc = W.run([&](int r) -> int {
+          const int nl = S.bounds[(size_t)r + 1] - S.bounds[(size_t)r];
+          for (int q = whole ? 0 : p; q < (whole ? np : p + 1); ++q)
+            if (nl > 0)
+              if (int rc2 = fs_spmv_part(S.shard[(size_t)r], 0, S.local[(size_t)r], in[(size_t)r], q, np, D->stream[r])) return rc2;
+          FS_HIP(hipEventRecord(S.ev[(size_t)r][(size_t)p], D->stream[r]));
+          FS_HIP(hipStreamWaitEvent(D->comm_stream[r], S.ev[(size_t)r][(size_t)p], 0));
+          return FS_OK;
+        })) return rc;
+    const int rc = whole ? exchange([&](int r) { return (const double *)S.local[(size_t)r]; }, [&](int r) { return S.pad[(size_t)r]; }, (size_t)S.max_rows, 0)
+                         : exchange([&](int r) { return (const double *)(S.local[(size_t)r] + S.cut[(size_t)r][(size_t)p]); },
+                                    [&](int r) { return S.pad[(size_t)r] + S.off[(size_t)p]; }, (size_t)S.maxc[(size_t)p], p);
+    if (rc) return rc;
+  }
+  return W.run([&](int r) -> int {
+    if (int rc = whole ? fs_copy_segments(S.nseg1, S.table[(size_t)r] + 3 * (size_t)S.nseg, S.max_rows, S.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])
+                       : fs_copy_segments(S.nseg, S.table[(size_t)r], S.max_seg, S.pad[(size_t)r], out[(size_t)r], D->comm_stream[r])) return rc;
+    FS_HIP(hipEventRecord(S.done[(size_t)r], D->comm_stream[r]));
+    FS_HIP(hipStreamWaitEvent(D->stream[r], S.done[(size_t)r], 0));
+    return FS_OK;
+  });
+}
+
 int dist_sync(fs_dist_t D)
 {
+  if (D->workers)
+    return D->workers->run([D](int r) -> int {
+      FS_HIP(hipStreamSynchronize(D->stream[r]));
+      FS_HIP(hipStreamSynchronize(D->comm_stream[r]));
+      return FS_OK;
+    });
   for (int r = 0; r < D->n; ++r) {
     FS_HIP(hipSetDevice(D->dev[r]));
     FS_HIP(hipStreamSynchronize(D->stream[r]));
@@ -946,6 +1085,11 @@ fs_dist_t fs_dist_create(int ndev, const int *devices)
     if (e != ncclSuccess) { nccl_fail(e, "ncclCommInitAll"); D->comm.clear(); fs_dist_destroy(D); return nullptr; }
     D->use_rccl = true;
   }
+  if (const char *t = getenv("FS_DIST_THREADS"))
+    if (*t == '1' && ndev > 1) {
+      D->workers.reset(new RankWorkers());
+      D->workers->start(D->dev);
+    }
   return D;
 }
 
@@ -982,6 +1126,7 @@ int fs_debug_dist_k_parts(fs_dist_matrix_t M, int transposed)
 
 int fs_dist_ndev(fs_dist_t D) { return D ? D->n : FS_ERR_ARG; }
 int fs_dist_uses_rccl(fs_dist_t D) { return D ? (int)D->use_rccl : FS_ERR_ARG; }
+int fs_debug_dist_issue_threads(fs_dist_t D) { return D && D->workers ? D->workers->n : 0; }   // diagnostics
 int fs_dist_is_conservative(fs_dist_t D) { return D ? (int)D->conservative : FS_ERR_ARG; }
 
 void fs_dist_matrix_destroy(fs_dist_matrix_t M)

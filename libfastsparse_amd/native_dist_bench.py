@@ -69,6 +69,8 @@ def main():
     if not D:
         raise SystemExit("fs_dist_create: " + L.fs_last_error().decode())
     rec["uses_rccl"] = bool(L.fs_dist_uses_rccl(D))
+    L.fs_debug_dist_issue_threads.argtypes = [vp]
+    rec["issue_threads"] = int(L.fs_debug_dist_issue_threads(D))      # FS_DIST_THREADS=1: one issuing thread per rank (0: the caller issues)
     rec["context_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     M = L.fs_dist_csr_create_from_shards(D, N * n, ncol, (C.c_int * N)(*([n] * N)), (C.c_int64 * N)(*([nnz] * N)),

@@ -2172,18 +2172,22 @@ def pysynth_uniform(nrow, ncol, per):
 _NGPU3 = {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}
 
 
-@pytest.mark.parametrize("mode", ["golden", "resident", "edges"])
+@pytest.mark.parametrize("mode", ["golden", "resident", "edges", "golden+threads", "resident+threads"])
 def test_every_dropin_entry_point_across_three_ranks(hip, mode):
     """FASTSPARSE_NGPU=3 FASTSPARSE_DEVICES=0,0,0 routes EVERY product entry point of sparse.h / dsparse.h /
     csr.h / cbcsr.h / cg.h through the row-sharded path (fs_dropin.hip "several GPUs" -> fs_dist.hip).  `golden`: all golden cases
     through HipDropinBackend with host vectors, the single-GPU bars (bit-exact for pattern matrices with integer x, 1e-12 row-scaled
     otherwise, y pre-poisoned), every output proven to come from sharded products (fs_debug_dist_products).  `resident`: x / y in
     HBM -- read in place and written by the unpack launch, never staged through the host.  `edges`: no entries, no rows, fewer rows
-    than ranks, one column, one long row, a struct edited in place.  tests/_dropin_ngpu.py is the child."""
+    than ranks, one column, one long row, a struct edited in place.  `+threads`: the same with FS_DIST_THREADS=1, one issuing thread per
+    rank (the experimental remedy for the one-process path's issue overhead).  tests/_dropin_ngpu.py is the child."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dropin_ngpu.py")
-    p = subprocess.run([sys.executable, child, mode], env=dict(os.environ, **_NGPU3), capture_output=True, text=True, timeout=1500)
+    env = dict(os.environ, **_NGPU3)
+    if mode.endswith("+threads"):
+        env["FS_DIST_THREADS"] = "1"
+    p = subprocess.run([sys.executable, child, mode], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and p.stdout.rstrip().endswith("OK"), (mode, p.stdout[-3000:] + p.stderr[-3000:])
 
 
