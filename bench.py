@@ -1891,8 +1891,25 @@ def main():
                 # the same GPUs once more, through the one-process C path (a child of rank 0; the other ranks wait at the barrier)
                 state["current"] = "native one-process path"
                 prov.release()
+                prov.synchronize()
                 dist.barrier()
-                native = native_path_records(world, args) if rank == 0 else None
+                # the other ranks wait on the HOST (the rendezvous store), not in a collective: a barrier kernel spinning on their GPUs
+                # would sit on CUs and links the child is being timed on
+                native, store = None, None
+                try:
+                    store = dist.distributed_c10d._get_default_store()
+                except Exception:
+                    store = None
+                if rank == 0:
+                    native = native_path_records(world, args)
+                    if store is not None:
+                        store.set("fs_native_path_done", "1")
+                elif store is not None:
+                    import datetime
+                    try:
+                        store.wait(["fs_native_path_done"], datetime.timedelta(seconds=900))
+                    except Exception:
+                        pass
                 dist.barrier()
                 if rank == 0:
                     also.append({"workload": "native one-process path (fs_dist_*)", "native_one_process_path": native})
