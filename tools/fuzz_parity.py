@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Randomised differential run: random shapes, densities, row-length profiles, forced kernel families, k and options through the
+device-resident layer AND the reference-named entry points, every result against the oracle (pattern-only with integer x: bit for
+bit; otherwise the row-scaled 1e-12 bound).  Not part of the test suite (open-ended); run on the GPU box:
+    python tools/fuzz_parity.py [seconds] [seed]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import _hipbackend as H  # noqa: E402
+from libfastsparse_amd import capi  # noqa: E402
+from oracle import pyoracle as O  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+TOL = 1e-12
+L = capi.lib()
+st = capi.current_stream()
+FORCE = [None, ("binning", 2), ("ldsx", 2), ("tiling", 2), ("spmv_kernel", 1), ("spmv_kernel", 2), ("reproducible", 1), ("strict_order", 1)]
+
+
+def make():
+    nrow = int(rng.choice([1, 7, 300, 5_000, 60_000, 400_000]))
+    ncol = int(rng.choice([1, 3, 64, 2_049, 40_000, 300_001]))
+    mean = float(rng.choice([0.3, 2, 9, 40]))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        lens = rng.poisson(mean, nrow)
+    elif kind == 1:
+        lens = np.minimum((mean / np.maximum(rng.uniform(size=nrow), 1e-6)).astype(np.int64), 50_000)     # heavy tail
+    elif kind == 2:
+        lens = np.where(rng.uniform(size=nrow) < 0.7, 0, rng.poisson(3 * mean, nrow))                        # mostly empty
+    else:
+        lens = np.full(nrow, int(mean) + 1)
+    lens = lens.astype(np.int64)
+    while lens.sum() > 6_000_000:
+        lens //= 2
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    nnz = int(rp[-1])
+    band = rng.integers(0, 3)
+    if band == 0 or ncol < 16:
+        cc = rng.integers(0, ncol, nnz)
+    elif band == 1:                                                # banded: columns near the diagonal
+        rows = np.repeat(np.arange(nrow), lens)
+        cc = (rows * ncol // max(nrow, 1) + rng.integers(-8, 9, nnz)) % ncol
+    else:                                                          # few hot columns (duplicates galore)
+        cc = rng.integers(0, min(ncol, 5), nnz)
+    return nrow, ncol, rp.astype(np.int32), cc.astype(np.int32), rng.uniform(-1, 1, nnz)
+
+
+def check(got, ref, scale, exact, what, terms=None):
+    """terms: number of addends of every output element.  1e-12 * sum |a||x| is the bar -- up to ~4 500 terms: beyond,
+    two different orders of the same sum may differ by 2 n 2^-53 sum |a||x| (the a-priori bound of each, reached when all terms
+    have one sign -- ncol = 1 makes such rows), and only strict_order (the reference's own order) can promise more."""
+    if exact:
+        assert np.array_equal(got, ref), what
+    else:
+        tol = TOL if terms is None else np.maximum(TOL, 2.0 * terms.reshape(terms.shape + (1,) * (scale.ndim - 1)) * 2.0 ** -53)
+        bad = np.abs(got - ref) - tol * scale
+        assert np.all(bad <= 0), (what, float(bad.max()), None if terms is None else int(terms.reshape(-1)[int(np.argmax(bad.reshape(bad.shape[0], -1).max(1)))]))
+
+
+t_end = time.time() + budget
+cases = 0
+while time.time() < t_end:
+    nrow, ncol, rp, cc, vv = make()
+    valued = bool(rng.integers(0, 2))
+    vals = vv if valued else None
+    force = FORCE[rng.integers(0, len(FORCE))]
+    integer = bool(rng.integers(0, 2))
+    x = rng.integers(-1000, 1001, ncol).astype(np.float64) if integer else np.sin(7.0 * np.arange(ncol) + 0.3)
+    u = rng.integers(-1000, 1001, nrow).astype(np.float64) if integer else np.sin(11.0 * np.arange(nrow) - 0.2)
+    k = int(rng.choice([1, 2, 3, 4, 5, 8, 17]))
+    what = dict(nrow=nrow, ncol=ncol, nnz=int(rp[-1]), valued=valued, force=force, integer=integer, k=k, seed=seed, case=cases)
+    if force:
+        capi.set_option(*force)
+    try:
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        A = capi.Matrix.from_csr(nrow, ncol, d(rp), d(cc), None if vals is None else d(vals))
+        exact = (not valued and integer) or (force == ("strict_order", 1))
+        ref = O.csr_mul(nrow, rp, cc, vals, x)
+        scale = O.csr_abs_scale(nrow, rp, cc, vals, x)
+        y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        A.spmv(y, d(x), st)
+        lens = np.diff(rp).astype(np.float64)
+        clen = np.bincount(cc, minlength=ncol).astype(np.float64)
+        check(y.cpu().numpy(), ref, scale, exact, ("spmv", what), lens)
+        # transposed
+        A.build_transpose(st)
+        rows = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+        zref = O.coo_tmul(ncol, rows, cc, vals, u)
+        zsc = O.coo_tmul(ncol, rows, cc, None if vals is None else np.abs(vals), np.abs(u))
+        z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
+        A.spmv(z, d(u), st, transposed=True)
+        check(z.cpu().numpy(), zref, zsc, exact, ("spmv_t", what), clen)
+        # k columns
+        if k > 1:
+            X = rng.integers(-50, 51, (ncol, k)).astype(np.float64) if integer else np.sin(np.arange(ncol * k, dtype=np.float64)).reshape(ncol, k)
+            A.prepare(k, st)
+            Y = torch.full((nrow, k), -1.0, dtype=torch.float64, device="cuda")
+            A.spmm(Y, d(X), k, st)
+            Yr = O.csr_mul_n(nrow, rp, cc, vals, X, k)
+            Ys = O.csr_mul_n(nrow, rp, cc, None if vals is None else np.abs(vals), np.abs(X), k)
+            check(Y.cpu().numpy(), Yr, Ys, exact, ("spmm", what), lens)
+        A.close()
+        # the reference-named entry point with host struct + host vectors
+        if valued:
+            S = H.CSR(nrow, ncol, int(rp[-1]), H._ip(rp), H._ip(cc), H._dp(vv))
+            f = L.csr_A_mul_B
+        else:
+            S = H.BCSR(nrow, ncol, int(rp[-1]), H._ip(rp), H._ip(cc))
+            f = L.bcsr_A_mul_B
+        f.restype = None
+        yh = np.full(max(nrow, 1), -1.0)
+        f(H._dp(yh), C.byref(S), H._dp(x.copy()))
+        L.fs_invalidate(C.byref(S))
+        check(yh[:nrow], ref, scale, exact, ("dropin", what), lens)
+    finally:
+        if force:
+            capi.set_option(force[0], 0 if force[0] in ("spmv_kernel", "reproducible", "strict_order") else 1)
+    cases += 1
+    if cases % 25 == 0:
+        print("%d cases ok" % cases, flush=True)
+print("fuzz: %d cases, all within the bars (seed %d)" % (cases, seed))
