@@ -1124,6 +1124,21 @@ int fs_debug_dist_k_parts(fs_dist_matrix_t M, int transposed)
   return most;
 }
 
+// the same for the single-vector product of one side (0: no product made on that side yet)
+int fs_debug_dist_parts(fs_dist_matrix_t M, int transposed)
+{
+  if (!M) return 0;
+  const DistSide &S = transposed ? M->t : M->a;
+  if (!S.built) return 0;
+  int most = 0;
+  for (const std::vector<int> &c : S.cut) {
+    int busy = 0;
+    for (size_t p = 0; p + 1 < c.size(); ++p) busy += c[p + 1] > c[p];
+    most = std::max(most, busy);
+  }
+  return most;
+}
+
 int fs_dist_ndev(fs_dist_t D) { return D ? D->n : FS_ERR_ARG; }
 int fs_dist_uses_rccl(fs_dist_t D) { return D ? (int)D->use_rccl : FS_ERR_ARG; }
 int fs_debug_dist_issue_threads(fs_dist_t D) { return D && D->workers ? D->workers->n : 0; }   // diagnostics
