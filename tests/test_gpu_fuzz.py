@@ -1,0 +1,21 @@
+"""A short, seeded stretch of the three randomised differential runs (tools/fuzz_parity.py: device layer; tools/fuzz_dist.py: the
+multi-GPU layer on virtual ranks; tools/fuzz_dropin.py: the reference-named entry points) -- the open-ended runs are recorded in
+profiles/r05_fuzz_parity.txt; here a few hundred cases each keep them from rotting.  Every result is compared with the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,env", [("fuzz_parity.py", {}), ("fuzz_dist.py", {}), ("fuzz_dist.py", {"FS_DIST_PARTS": "7", "FS_DIST_THREADS": "1"}),
+                                      ("fuzz_dropin.py", {}), ("fuzz_dropin.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"})])
+def test_randomised_differential_stretch(tool, env):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "6", "20251005"], cwd=ROOT, env=e, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "all within the bars" in out.stdout, out.stdout[-2000:]
