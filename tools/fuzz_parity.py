@@ -26,11 +26,19 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 L = capi.lib()
 st = capi.current_stream()
-FORCE = [None, ("binning", 2), ("ldsx", 2), ("tiling", 2), ("spmv_kernel", 1), ("spmv_kernel", 2), ("reproducible", 1), ("strict_order", 1)]
+# option sets: small panels / tiles (bin_rows, tile_rows, tile_cols) take small matrices through the many-panel paths of the big ones
+FORCE = [{}, {"binning": 2}, {"binning": 2, "bin_rows": 64}, {"binning": 2, "bin_rows": 64, "reproducible": 1}, {"binning": 2, "long_rows": 2, "bin_rows": 128},
+         {"binning": 2, "long_rows": 2, "long_min_len": 40, "reproducible": 1}, {"binning": 2, "bin_rows": 256, "spmm_kernel": 2}, {"ldsx": 2},
+         {"ldsx": 2, "tile_rows": 64}, {"ldsx": 2, "reproducible": 1}, {"ldsx": 2, "tiled_flags": 4}, {"tiling": 2}, {"tiling": 2, "tile_rows": 64, "tile_cols": 512},
+         {"tiling": 2, "tile_split": 8}, {"spmv_kernel": 1}, {"spmv_kernel": 2}, {"spmv_kernel": 3}, {"reproducible": 1}, {"strict_order": 1},
+         {"spmm_kernel": 1}, {"spmm_kernel": 3}, {"spmm_wide": 1}, {"release_csr": 1}, {"release_csr": 1, "binning": 2},
+         {"release_csr": 1, "ldsx": 2}, {"release_csr": 1, "tiling": 2, "tile_rows": 64}]
+RESET = {"binning": 1, "ldsx": 1, "tiling": 1, "long_rows": 1}          # every other option: 0
 
 
 t_end = time.time() + budget
 cases = 0
+released = 0
 while time.time() < t_end:
     nrow, ncol, rp, cc, vv = make(rng)
     valued = bool(rng.integers(0, 2))
@@ -41,12 +49,12 @@ while time.time() < t_end:
     u = rng.integers(-1000, 1001, nrow).astype(np.float64) if integer else np.sin(11.0 * np.arange(nrow) - 0.2)
     k = int(rng.choice([1, 2, 3, 4, 5, 8, 17]))
     what = dict(nrow=nrow, ncol=ncol, nnz=int(rp[-1]), valued=valued, force=force, integer=integer, k=k, seed=seed, case=cases)
-    if force:
-        capi.set_option(*force)
+    for name, value in force.items():
+        capi.set_option(name, value)
     try:
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
         A = capi.Matrix.from_csr(nrow, ncol, d(rp), d(cc), None if vals is None else d(vals))
-        exact = (not valued and integer) or (force == ("strict_order", 1))
+        exact = (not valued and integer) or "strict_order" in force
         ref = O.csr_mul(nrow, rp, cc, vals, x)
         scale = O.csr_abs_scale(nrow, rp, cc, vals, x)
         y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
@@ -54,8 +62,14 @@ while time.time() < t_end:
         lens = np.diff(rp).astype(np.float64)
         clen = np.bincount(cc, minlength=ncol).astype(np.float64)
         check(y.cpu().numpy(), ref, scale, exact, ("spmv", what), lens)
-        # transposed
-        A.build_transpose(st)
+        # transposed (a handle that gave its plain arrays back under release_csr says so, takes them back and goes on)
+        try:
+            A.build_transpose(st)
+        except Exception as e:  # noqa: BLE001
+            assert "release_csr" in force and "(-5)" in str(e), (what, str(e))      # FS_ERR_RELEASED
+            A.restore_csr(d(rp), d(cc), None if vals is None else d(vals))
+            A.build_transpose(st)
+            released += 1
         rows = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
         zref = O.coo_tmul(ncol, rows, cc, vals, u)
         zsc = O.coo_tmul(ncol, rows, cc, None if vals is None else np.abs(vals), np.abs(u))
@@ -85,9 +99,9 @@ while time.time() < t_end:
         L.fs_invalidate(C.byref(S))
         check(yh[:nrow], ref, scale, exact, ("dropin", what), lens)
     finally:
-        if force:
-            capi.set_option(force[0], 0 if force[0] in ("spmv_kernel", "reproducible", "strict_order") else 1)
+        for name in force:
+            capi.set_option(name, RESET.get(name, 0))
     cases += 1
     if cases % 25 == 0:
         print("%d cases ok" % cases, flush=True)
-print("fuzz: %d cases, all within the bars (seed %d)" % (cases, seed))
+print("fuzz: %d cases, all within the bars (seed %d; %d handles took their released arrays back)" % (cases, seed, released))
