@@ -512,6 +512,96 @@ def _traffic(kernels, workload, rows, per):
 _TRAFFIC_SOURCE = None
 
 
+_LIVE_PMC_BROKEN = None      # the first failure of a live PMC pass: later workloads do not try again (the run must stay within minutes)
+
+
+def live_pmc_traffic(args, workload="c2", kernels=("fs::spmv_expand_kernel", "fs::spmv_reduce_kernel")):
+    """roofline.traffic MEASURED BY THIS RUN (N = 1): two short children of this process -- `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
+    and `--pmc WRITE_SIZE`, separate passes as MI355X_MICROARCH.md's HBM section prescribes, the program itself behind `--` -- run
+    this file's `workload` for a few steps (`--lean`: device vectors only, no probes, no CPU baseline), and the per-dispatch sums of
+    the product's kernels give HBM bytes per product = sum over its kernels of (2 x FETCH_SIZE + WRITE_SIZE) KB (the x 2 is the
+    guide's gfx950 correction: FETCH_SIZE counts a 128-byte request as 64).  Outside the timed region, after it.  Any failure (no
+    rocprofv3, a time-out, an unexpected CSV) returns (None, reason): the line then keeps the value of profiles/."""
+    global _LIVE_PMC_BROKEN
+    if _LIVE_PMC_BROKEN:
+        return None, {"error": "not tried: an earlier live PMC pass of this run failed (%s)" % _LIVE_PMC_BROKEN}
+    total, how = _live_pmc_traffic(args, workload, kernels)
+    if not total:
+        _LIVE_PMC_BROKEN = how.get("error", "?")[:200]
+    return total, how
+
+
+def _live_pmc_traffic(args, workload, kernels):
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    per_counter, t0 = {}, time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="fs_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--", "python3",
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1", "--rows", str(args.rows), "--per-row", str(args.per_row),
+                   "--c5-rows", str(args.c5_rows), "--lean", "--no-cpu-baseline", "--no-reproducible-cost"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+                env.pop(k, None)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=float(os.environ.get("FS_BENCH_PMC_TIMEOUT_S", "90")))
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, {"error": "the %s pass failed (exit %d): %s" % (counter, p.returncode, (p.stderr or p.stdout)[-300:])}
+            sums = {}                                   # kernel -> dispatch -> value (a dispatch has one row per counter instance)
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for kn in kernels:
+                        if kn in row["Kernel_Name"]:
+                            d = sums.setdefault(kn, {})
+                            d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if set(sums) != set(kernels):
+                return None, {"error": "the %s pass saw %s, not the product's kernels %s" % (counter, sorted(sums), list(kernels))}
+            per_counter[counter] = {kn: (sum(v.values()) / len(v), len(v)) for kn, v in sums.items()}
+        except subprocess.TimeoutExpired:
+            return None, {"error": "the %s pass timed out" % counter}
+        except Exception as ex:
+            return None, {"error": repr(ex)}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    parts = {kn: (2.0 * per_counter["FETCH_SIZE"][kn][0] + per_counter["WRITE_SIZE"][kn][0]) * 1024.0 for kn in kernels}
+    return sum(parts.values()), {
+        "measured_by_this_run": True, "bytes_per_kernel": parts,
+        "mean_FETCH_SIZE_KB": {kn: per_counter["FETCH_SIZE"][kn][0] for kn in kernels},
+        "mean_WRITE_SIZE_KB": {kn: per_counter["WRITE_SIZE"][kn][0] for kn in kernels},
+        "dispatches_averaged": {kn: per_counter["FETCH_SIZE"][kn][1] for kn in kernels},
+        "how": "two children after the timed region: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
+               "--workload %s --steps 3 --warmup 1 --lean; per product: sum over its kernels of the mean per dispatch of 2 x FETCH_SIZE + WRITE_SIZE (KB; "
+               "the x 2 is the gfx950 correction of MI355X_MICROARCH.md); the dispatches include the builder's own timing runs of the same kernels" % workload,
+        "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def apply_live_traffic(rec, args, workload, kernels, alg_bytes):
+    """replace roofline.traffic (and the ceiling derived from it) by what two rocprofv3 --pmc children of THIS run measure; the value
+    of profiles/ stays beside it for comparison; a failure leaves the record as it was and says why"""
+    if getattr(args, "lean", False) or getattr(args, "no_live_traffic", False):
+        return
+    live, how = live_pmc_traffic(args, workload, kernels)
+    r = rec["roofline"]
+    if not live:
+        r["traffic_live_measurement_failed"] = how
+        return
+    r["traffic_from_profiles_for_comparison"] = {"traffic": r.get("traffic"), "files": (r.pop("traffic_from_profiles", None) or {}).get("files")}
+    r["traffic"] = live
+    r["traffic_measured"] = how
+    r["design_ceiling_frac"] = alg_bytes / live * HBM_COPY_GBS / HBM_PEAK_GBS
+    r["frac_of_design_ceiling"] = r["frac"] / r["design_ceiling_frac"]
+    r["design_ceiling_source"] = "algorithmic bytes / the PMC traffic this run measured x 6.29 TB/s copy rate (MI355X_MICROARCH.md) / 8 TB/s"
+
+
 def _roofline(kernel, achieved, traffic, alg_bytes, avg_ms, launches, traffic_file=None):
     """the `roofline` object; design_ceiling_frac: algorithmic bytes / the bytes the kept kernel really moves (PMC) x what a copy
     reaches on this chip: the fraction of peak THIS algorithm could reach if both its streams ran at the copy rate"""
@@ -1014,6 +1104,8 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
             "one step = A x + A' u")
     if not _multi(world) and not strong and n_global == 10_000_000 and per == 16 and not getattr(args, "lean", False):
         rec["roofline"].update(config2_bound(bytes_per_launch, prov))
+    if not _multi(world) and not strong and kname == "two-pass" and kname_t == "two-pass" and hasattr(prov, "capi"):
+        apply_live_traffic(rec, args, "c2", ("fs::spmv_expand_kernel", "fs::spmv_reduce_kernel"), bytes_per_launch)
     if _multi(world):
         rec["config"].update({
             "exchange_check": exchange_check,
@@ -1154,6 +1246,8 @@ def run_c3(args, prov, world, rank, nccl):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    if ka_name == "lds-staged" and kt_name == "lds-staged":      # (mean over the dispatches of A and A': the two products of a step)
+        apply_live_traffic(rec, args, "c3", ("fs::spmv_ldsx_dma_kernel",), bpl)
     rec["config"]["one_time"] = one_time_costs(
         [("A", A, False), ("At", At, False)],
         "COO arrays already in HBM -> fs_coo_create twice (A from (rows, cols), A' from (cols, rows)): validation, stable device sort by "
@@ -1251,6 +1345,8 @@ def run_c4(args, prov, world, rank, nccl):
                               "fs::spmm_mfma_kernel<valued>", achieved, _traffic(("spmm_k32",), "c4", n, per), nbytes, avg_ms,
                               args.steps, "profiles/traffic_c4_spmm_k32.json"),
     }
+    if args.spmm_kernel != 4:
+        apply_live_traffic(rec, args, "c4", ("fs::spmm_kernel<true, 5>",), nbytes)
     rec["config"]["hbm_held_by_the_handle_bytes"] = dict(zip(("csr_and_schedule", "kept_single_vector_copy", "k_column_copies_and_scratch"),
                                                              A.device_bytes()))
     rec["config"]["one_time"] = one_time_costs(
@@ -1514,6 +1610,9 @@ def run_c5(args, prov, world, rank, nccl, out=None):
     if repro is not None:
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
+    if not _multi(world) and kname == "two-pass" and hasattr(prov, "capi"):
+        apply_live_traffic(rec, args, "c5", ("fs::spmv_expand_kernel", "fs::spmv_longrows_kernel", "fs::spmv_reduce_kernel", "fs::tiled_combine_kernel"),
+                           bytes_local)
     if hasattr(A, "build_ms"):
         rec["config"]["one_time"] = one_time_costs([("A", A, False)], "this rank's shard: device arrays in (borrowed), candidates built and timed")
     if release is not None:
@@ -1810,6 +1909,8 @@ def main():
                     help="profiling runs (tools/profile.sh): the timed products and the self-check only -- no per-launch events, no "
                          "host-pointer call, no probes, so that the per-kernel means of a PMC pass are the full products'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="config 2, N = 1: skip the two rocprofv3 --pmc children that measure roofline.traffic (then the value of profiles/ is reported)")
     ap.add_argument("--no-reproducible-cost", action="store_true", help="c2: skip timing the products with fixed-order sums")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baselines' samples (0: the workload's default)")
     ap.add_argument("--spmm-kernel", type=int, default=0,

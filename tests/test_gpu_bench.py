@@ -1,0 +1,36 @@
+"""`bench.py` on one GPU, as the driver runs it (a short config-2 run): the line's contract keys, and roofline.traffic MEASURED by the
+run itself -- two rocprofv3 --pmc children after the timed region (bench.live_pmc_traffic) -- next to the value of profiles/."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_measures_its_own_hbm_traffic():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-reproducible-cost"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 5 and rec["dtype"] == "f64" and rec["vs_baseline"] is None
+    r = rec["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "traffic_live_measurement_failed" not in r, r.get("traffic_live_measurement_failed")
+    m = r["traffic_measured"]
+    assert m["measured_by_this_run"] is True and set(m["bytes_per_kernel"]) == {"fs::spmv_expand_kernel", "fs::spmv_reduce_kernel"}
+    assert abs(sum(m["bytes_per_kernel"].values()) - r["traffic"]) < 1.0
+    alg = r["algorithmic_bytes_per_launch"]
+    # the two-pass pair moves 28.25 B per entry for 12 algorithmic ones: between 2 x and 2.6 x, and close to what profiles/ holds
+    assert 2.0 * alg < r["traffic"] < 2.6 * alg, (r["traffic"], alg)
+    old = r["traffic_from_profiles_for_comparison"]["traffic"]
+    assert old and abs(r["traffic"] - old) < 0.03 * old, (r["traffic"], old)
+    assert 0.2 < r["frac"] < r["design_ceiling_frac"] < 0.45
