@@ -589,6 +589,9 @@ def apply_live_traffic(rec, args, workload, kernels, alg_bytes):
     of profiles/ stays beside it for comparison; a failure leaves the record as it was and says why"""
     if getattr(args, "lean", False) or getattr(args, "no_live_traffic", False):
         return
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        rec["roofline"]["traffic_live_measurement_failed"] = {"error": "not tried: this run is itself under a profiler"}
+        return
     live, how = live_pmc_traffic(args, workload, kernels)
     r = rec["roofline"]
     if not live:
