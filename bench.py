@@ -572,12 +572,40 @@ def _live_pmc_traffic(args, workload, kernels):
             return None, {"error": repr(ex)}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    durations = None
+    if workload == "c2":          # the headline: the same child once more with the kernel trace alone -- rocprofv3's own clock on the kernels
+        tmp = tempfile.mkdtemp(prefix="fs_trace_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py"), "--workload", workload,
+                   "--steps", "10", "--warmup", "2", "--rows", str(args.rows), "--per-row", str(args.per_row), "--lean", "--no-cpu-baseline", "--no-reproducible-cost"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+                env.pop(k, None)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=float(os.environ.get("FS_BENCH_PMC_TIMEOUT_S", "90")))
+            ns = {}
+            for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    for kn in kernels:
+                        if kn in row["Kernel_Name"]:
+                            ns.setdefault(kn, []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+            if p.returncode == 0 and set(ns) == set(kernels):
+                durations = {kn: {"mean_ms": sum(v) / len(v) * 1e-6, "dispatches": len(v)} for kn, v in ns.items()}
+                try:          # the traced child's own HIP-event figure: the two clocks on the SAME launches
+                    child = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+                    durations["hip_events_ms_per_launch_in_the_traced_child"] = child["roofline"]["avg_launch_ms"]
+                except Exception:
+                    pass
+        except Exception:
+            durations = None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     parts = {kn: (2.0 * per_counter["FETCH_SIZE"][kn][0] + per_counter["WRITE_SIZE"][kn][0]) * 1024.0 for kn in kernels}
     return sum(parts.values()), {
         "measured_by_this_run": True, "bytes_per_kernel": parts,
         "mean_FETCH_SIZE_KB": {kn: per_counter["FETCH_SIZE"][kn][0] for kn in kernels},
         "mean_WRITE_SIZE_KB": {kn: per_counter["WRITE_SIZE"][kn][0] for kn in kernels},
         "dispatches_averaged": {kn: per_counter["FETCH_SIZE"][kn][1] for kn in kernels},
+        "kernel_trace_ms": durations,
         "how": "two children after the timed region: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
                "--workload %s --steps 3 --warmup 1 --lean; per product: sum over its kernels of the mean per dispatch of 2 x FETCH_SIZE + WRITE_SIZE (KB; "
                "the x 2 is the gfx950 correction of MI355X_MICROARCH.md); the dispatches include the builder's own timing runs of the same kernels" % workload,
@@ -600,6 +628,12 @@ def apply_live_traffic(rec, args, workload, kernels, alg_bytes):
     r["traffic_from_profiles_for_comparison"] = {"traffic": r.get("traffic"), "files": (r.pop("traffic_from_profiles", None) or {}).get("files")}
     r["traffic"] = live
     r["traffic_measured"] = how
+    if how.get("kernel_trace_ms"):
+        tr = sum(v["mean_ms"] for v in how["kernel_trace_ms"].values() if isinstance(v, dict))
+        r["rocprofv3_kernel_trace_ms_per_launch"] = tr      # a third child: `rocprofv3 --kernel-trace` alone, the product's kernels added up
+        r["hip_events_over_kernel_trace"] = r["avg_launch_ms"] / tr if tr else None
+        inchild = how["kernel_trace_ms"].get("hip_events_ms_per_launch_in_the_traced_child")
+        r["hip_events_over_kernel_trace_same_process"] = inchild / tr if (tr and inchild) else None
     r["design_ceiling_frac"] = alg_bytes / live * HBM_COPY_GBS / HBM_PEAK_GBS
     r["frac_of_design_ceiling"] = r["frac"] / r["design_ceiling_frac"]
     r["design_ceiling_source"] = "algorithmic bytes / the PMC traffic this run measured x 6.29 TB/s copy rate (MI355X_MICROARCH.md) / 8 TB/s"

@@ -34,3 +34,7 @@ def test_bench_line_measures_its_own_hbm_traffic():
     old = r["traffic_from_profiles_for_comparison"]["traffic"]
     assert old and abs(r["traffic"] - old) < 0.03 * old, (r["traffic"], old)
     assert 0.2 < r["frac"] < r["design_ceiling_frac"] < 0.45
+    # a third child under `rocprofv3 --kernel-trace` alone: the tracer's clock on the product's kernels against the HIP-event pair of
+    # the SAME process (kernels run a few percent slower under the tracer than in the untraced parent, hence two ratios)
+    assert 0.97 < r["hip_events_over_kernel_trace_same_process"] < 1.05, r
+    assert 0.85 < r["hip_events_over_kernel_trace"] < 1.10, r
