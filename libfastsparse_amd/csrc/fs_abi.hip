@@ -33,6 +33,7 @@ Options &options()
     Options q;
     if (const char *v = getenv("FS_TILED_FLAGS")) q.tiled_flags = atoi(v);
     if (const char *v = getenv("FS_BIN_ROWS")) q.bin_rows = atoi(v);
+    if (const char *v = getenv("FS_BIN_FLAGS")) q.bin_flags = atoi(v);          // (A/B runs: 64 keeps two-byte row ids in the two-pass copy)
     if (const char *v = getenv("FS_TILE_COLS")) q.tile_cols = atoi(v);
     if (const char *v = getenv("FS_LONG_ROWS")) q.long_rows = atoi(v);
     if (const char *v = getenv("FS_LONG_GEOMETRY")) q.long_geometry = atoi(v);
@@ -465,10 +466,20 @@ int fs_debug_two_pass_layout(fs_matrix_t A, int transposed, unsigned long long *
   if (!a.binned || !a.binned->built) { set_error("no two-pass copy"); return FS_ERR_ARG; }
   const fs::BinnedCsr &N = *a.binned;
   out8[0] = (unsigned long long)(uintptr_t)N.lcol; out8[1] = (unsigned long long)(uintptr_t)N.vals;
-  out8[2] = (unsigned long long)(uintptr_t)N.gdst; out8[3] = (unsigned long long)(uintptr_t)N.lrow;
+  out8[2] = (unsigned long long)(uintptr_t)N.gdst; out8[3] = (unsigned long long)(uintptr_t)(N.lrow ? (const void *)N.lrow : (const void *)N.lrow8);
   out8[4] = (unsigned long long)(uintptr_t)N.prod; out8[5] = (unsigned long long)N.n; out8[6] = (unsigned long long)N.B;
   out8[7] = (unsigned long long)N.P;
   return FS_OK;
+}
+
+// the row ids of the two-pass copy: -1 two bytes per entry (or no such copy); >= 0 one byte per entry (BinnedCsr::lrow8), the value
+// = the dummy entries that walk steps above 255 (diagnostics, not in include/fastsparse_hip.h)
+long long fs_debug_two_pass_rows8(fs_matrix_t A, int transposed)
+{
+  if (!A || (transposed && !A->has_t)) return -1;
+  const fs::DeviceCsr &a = transposed ? A->at : A->a;
+  if (!a.binned || !a.binned->built || !a.binned->lrow8) return -1;
+  return (long long)a.binned->dummies;
 }
 
 // one pass of the two-pass pair alone (which = 1: pass 1, x -> the product stream; 2: pass 2, the product stream -> y)
@@ -493,7 +504,7 @@ int fs_debug_two_pass_realloc(fs_matrix_t A, int transposed, int which_and_flags
     if (!a0.binned || !a0.binned->built) return FS_ERR_ARG;
     fs::BinnedCsr &N0 = *a0.binned;
     void **slots[5] = {(void **)&N0.lcol, (void **)&N0.vals, (void **)&N0.gdst, (void **)&N0.lrow, (void **)&N0.prod};
-    const size_t sizes[5] = {(size_t)N0.n * 2, N0.vals ? (size_t)N0.n * 8 : 0, ((size_t)N0.n >> fs::kBinGroupLog) * 4, (size_t)N0.n * 2,
+    const size_t sizes[5] = {(size_t)N0.n * 2, N0.vals ? (size_t)N0.n * 8 : 0, ((size_t)N0.n >> fs::kBinGroupLog) * 4, N0.lrow ? (size_t)N0.n * 2 : 0,
                              (size_t)N0.n * 8 * (size_t)N0.kw};
     const int order_a[5] = {4, 1, 0, 3, 2}, order_b[5] = {1, 4, 3, 0, 2};
     const int *order = (which_and_flags & 64) ? order_b : order_a;

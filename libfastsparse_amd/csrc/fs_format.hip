@@ -151,7 +151,7 @@ static void free_binned_slot(BinnedCsr *&N)
 {
   if (!N) return;
   free_long_rows(N->lr);
-  void *owned[] = {N->lcol, N->vals, N->gdst, N->lrow, N->prod, N->band_ptr, N->bin_ptr, N->panel_row, N->vfirst, N->yv};
+  void *owned[] = {N->lcol, N->vals, N->gdst, N->lrow, N->lrow8, N->gbase, N->prod, N->band_ptr, N->bin_ptr, N->panel_row, N->vfirst, N->yv};
   for (void *q : owned)
     if (q) (void)traced_free(q);
   free(N->h_band_ptr);
@@ -241,7 +241,8 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
   };
   auto binned_bytes = [&](const BinnedCsr *N) -> int64_t {
     if (!N) return 0;
-    int64_t b = N->n * (2 + 2 + 8ll * N->kw + (N->vals ? 8 : 0)) + 4 * (N->n / (kBinGroup / N->kw)) + 4ll * (N->B + 1) + 8ll * (N->P + 1);
+    int64_t b = N->n * (2 + (N->lrow8 ? 1 : 2) + 8ll * N->kw + (N->vals ? 8 : 0)) + (N->lrow8 ? 6 : 4) * (N->n / (kBinGroup / N->kw)) + 4ll * (N->B + 1) +
+                8ll * (N->P + 1);
     if (N->vfirst) b += 4ll * (A.nrow + 1);
     if (N->yv) b += 8ll * N->nvrow * N->kw;
     if (N->lr) b += N->lr->n * (4 + (N->lr->vals ? 8 : 0)) + 12ll * N->lr->nlong + (8ll + 4ll * (kLongOwners + 1)) * (N->lr->B + 1) +
@@ -1723,14 +1724,15 @@ __global__ void bin_key_kernel(int nvrow, int64_t nnz, int P, int bcols, const i
 // group counts of the padded runs in pass-1 order (g1[band*P + panel]) and pass-2 order (g2[panel*B + band]);
 // slot nruns of both is the zero that turns the exclusive scans into B*P + 1 offsets
 __global__ void bin_groups_kernel(int B, int P, int ge, const int *__restrict__ run_ptr, unsigned *__restrict__ g1,
-                                  unsigned *__restrict__ g2)
+                                  unsigned *__restrict__ g2, const unsigned *__restrict__ xs = nullptr)
 {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nruns = (int64_t)B * P;
   if (k > nruns) return;
   if (k == nruns) { g1[k] = 0; g2[k] = 0; return; }
   const int b = (int)(k / P), p = (int)(k % P);
-  const unsigned g = (unsigned)(run_ptr[k + 1] - run_ptr[k] + ge - 1) / (unsigned)ge;   // ge entries per group
+  const unsigned dum = xs ? xs[run_ptr[k + 1]] - xs[run_ptr[k]] : 0u;                   // (one-byte row steps: the run's dummy entries)
+  const unsigned g = ((unsigned)(run_ptr[k + 1] - run_ptr[k]) + dum + (unsigned)ge - 1u) / (unsigned)ge;   // ge entries per group
   g1[k] = g;
   g2[(int64_t)p * B + b] = g;
 }
@@ -1752,6 +1754,56 @@ __global__ void bin_scatter_kernel(int64_t nnz, int B, int P, int bcols, int ge,
   lcol[pos1] = (uint16_t)(cols[src] - b * bcols);
   if (vals) vals1[pos1] = vals[src];
   lrow[pos2] = (uint16_t)(vrows[src] - panel_row[p]);
+}
+
+// ---- one-byte row steps (BinnedCsr::lrow8) ----
+// extra[i] = dummy entries in front of sorted entry i: its step from the entry before it in the same run, walked 255 rows at a time
+// (the first entry of a run starts from its own row: no step).  extra[nnz] = 0 closes the scan.
+__global__ void bin_gap_kernel(int64_t nnz, int P, const unsigned *__restrict__ skeys, const unsigned *__restrict__ perm,
+                               const int *__restrict__ vrows, const int *__restrict__ run_ptr, unsigned *__restrict__ extra)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nnz) return;
+  if (i == nnz) { extra[i] = 0; return; }
+  const unsigned key = skeys[i];
+  unsigned e = 0;
+  if (i > run_ptr[key]) {
+    const int gap = vrows[perm[i]] - vrows[perm[i - 1]];       // same panel: the difference of the local rows
+    if (gap > 255) e = (unsigned)(gap - 1) / 255u;
+  }
+  extra[i] = e;
+}
+
+// the scatter of both orders with the dummies in place: slot = rank in the run + the dummies in front of it
+__global__ void bin_scatter8_kernel(int64_t nnz, int B, int P, int bcols, int ge, const unsigned *__restrict__ skeys,
+                                    const unsigned *__restrict__ perm, const int *__restrict__ vrows,
+                                    const int *__restrict__ panel_row, const int *__restrict__ cols,
+                                    const double *__restrict__ vals, const int *__restrict__ run_ptr,
+                                    const unsigned *__restrict__ xs, const unsigned *__restrict__ start1,
+                                    const unsigned *__restrict__ start2, uint16_t *__restrict__ lcol, double *__restrict__ vals1,
+                                    uint8_t *__restrict__ lrow8, uint16_t *__restrict__ gbase)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const unsigned key = skeys[i], src = perm[i];
+  const int b = (int)(key / (unsigned)P), p = (int)(key % (unsigned)P);
+  const int64_t first = run_ptr[key];
+  const unsigned dum = xs[i + 1] - xs[i];                       // dummies in front of this entry
+  const int64_t slot = (i - first) + (int64_t)(xs[i] - xs[first]) + dum;
+  const int64_t base1 = (int64_t)start1[key] * ge, base2 = (int64_t)start2[(int64_t)p * B + b] * ge;
+  const int row = vrows[src] - panel_row[p];
+  const int prev = i > first ? vrows[perm[i - 1]] - panel_row[p] : row;    // the row in front of the first slot of a run: its own
+  // the dummies: zero slot of the band (lcol = bcols and vals = 0 are the arrays' fill), step 255 each
+  for (unsigned m = 0; m < dum; ++m) {
+    const int64_t sl = slot - dum + m;
+    lrow8[base2 + sl] = 255;
+    if ((sl & (ge - 1)) == 0) gbase[(base2 + sl) / ge] = (uint16_t)(prev + 255 * (int)m);
+  }
+  const int before = prev + 255 * (int)dum;
+  lcol[base1 + slot] = (uint16_t)(cols[src] - b * bcols);
+  if (vals) vals1[base1 + slot] = vals[src];
+  lrow8[base2 + slot] = (uint8_t)(row - before);
+  if ((slot & (ge - 1)) == 0) gbase[(base2 + slot) / ge] = (uint16_t)before;
 }
 
 // gdst[g] = pass-2 group of pass-1 group g (one thread per run walks the run's groups)
@@ -2195,7 +2247,28 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   FS_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, dk, dv, n, 0, bits, s));
   const unsigned *sorted_keys = dk.current(), *perm = dv.current();
   hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, nruns, A.nnz, sorted_keys, run_ptr.p);
-  hipLaunchKernelGGL(bin_groups_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, B, P, ge, run_ptr.p, g1.p, g2.p);
+  // ---- one byte per row id where the cells are dense (BinnedCsr::lrow8): the dummies that walk steps above 255, counted first ----
+  Scratch<unsigned> extra, xs;
+  Scratch<char> tmp3;
+  bool rows8 = false;
+  int64_t dummies = 0;
+  if (kw == 1 && bcols == kBinCols && !(o.bin_flags & 64) && A.nnz > 0) {
+    FS_HIP(extra.alloc(n + 1));
+    FS_HIP(xs.alloc(n + 1));
+    hipLaunchKernelGGL(bin_gap_kernel, dim3(grid_for(A.nnz + 1)), dim3(256), 0, s, A.nnz, P, sorted_keys, perm, vrows.p, run_ptr.p, extra.p);
+    FS_HIP(hipGetLastError());
+    size_t b3 = 0;
+    FS_HIP(rocprim::exclusive_scan(nullptr, b3, extra.p, xs.p, 0u, n + 1, rocprim::plus<unsigned>(), s));
+    FS_HIP(tmp3.alloc(b3));
+    FS_HIP(rocprim::exclusive_scan((void *)tmp3.p, b3, extra.p, xs.p, 0u, n + 1, rocprim::plus<unsigned>(), s));
+    unsigned total = 0;
+    FS_HIP(hipMemcpyAsync(&total, xs.p + n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    dummies = total;
+    rows8 = (o.bin_flags & 128) || (double)total <= 0.01 * (double)A.nnz;
+  }
+  hipLaunchKernelGGL(bin_groups_kernel, dim3(grid_for(nruns + 1)), dim3(256), 0, s, B, P, ge, run_ptr.p, g1.p, g2.p,
+                     rows8 ? (const unsigned *)xs.p : (const unsigned *)nullptr);
   FS_HIP(hipGetLastError());
   tmp_bytes = 0;
   FS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, g1.p, start1.p, 0u, (size_t)nruns + 1, rocprim::plus<unsigned>(), s));
@@ -2224,7 +2297,13 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
   // ---- lay out both orders ------------------------------------------------------------------------------------
   const size_t np = (size_t)N->n;
   FS_HIP(traced_malloc(&N->lcol, sizeof(uint16_t) * np));
-  FS_HIP(traced_malloc(&N->lrow, sizeof(uint16_t) * np));
+  if (rows8) {
+    FS_HIP(traced_malloc(&N->lrow8, np));
+    FS_HIP(traced_malloc(&N->gbase, sizeof(uint16_t) * (size_t)(groups ? groups : 1)));
+    N->dummies = dummies;
+  } else {
+    FS_HIP(traced_malloc(&N->lrow, sizeof(uint16_t) * np));
+  }
   FS_HIP(traced_malloc(&N->gdst, sizeof(unsigned) * (size_t)groups));
   FS_HIP(traced_malloc(&N->prod, sizeof(double) * np * (size_t)kw));
   if (A.vals) {
@@ -2232,9 +2311,16 @@ static int build_binned_impl(DeviceCsr &A, hipStream_t s, BinnedCsr *&slot, int 
     FS_HIP(hipMemsetAsync(N->vals, 0, sizeof(double) * np, s));
   }
   FS_HIP(hipMemsetD16Async((hipDeviceptr_t)N->lcol, (unsigned short)bcols, np, s));   // padding: the zero row behind the band
-  FS_HIP(hipMemsetAsync(N->lrow, 0, sizeof(uint16_t) * np, s));
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, bcols, ge, sorted_keys, perm, vrows.p,
-                     N->panel_row, A.cols, A.vals, run_ptr.p, start1.p, start2.p, N->lcol, N->vals, N->lrow);
+  if (rows8) {
+    FS_HIP(hipMemsetAsync(N->lrow8, 0, np, s));
+    FS_HIP(hipMemsetAsync(N->gbase, 0, sizeof(uint16_t) * (size_t)(groups ? groups : 1), s));
+    hipLaunchKernelGGL(bin_scatter8_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, bcols, ge, sorted_keys, perm, vrows.p,
+                       N->panel_row, A.cols, A.vals, run_ptr.p, xs.p, start1.p, start2.p, N->lcol, N->vals, N->lrow8, N->gbase);
+  } else {
+    FS_HIP(hipMemsetAsync(N->lrow, 0, sizeof(uint16_t) * np, s));
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, s, A.nnz, B, P, bcols, ge, sorted_keys, perm, vrows.p,
+                       N->panel_row, A.cols, A.vals, run_ptr.p, start1.p, start2.p, N->lcol, N->vals, N->lrow);
+  }
   hipLaunchKernelGGL(bin_gdst_kernel, dim3(grid_for(nruns)), dim3(256), 0, s, B, P, start1.p, start2.p, N->gdst);
   FS_HIP(hipGetLastError());
 

@@ -120,11 +120,32 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
   expand_share<VALUED, U, NTLD, NTST, BC>(xband, ncol, B, band_ptr, lcol, vals, gdst, x, xs, prod, g0, g1);
 }
 
+// the local rows of the 8 entries e .. e + 7 (e a multiple of 8) as four pairs of 16-bit ids.  L8 (BinnedCsr::lrow8): one byte per
+// entry, the step from the slot before it; gbase[g] = the row in front of group g's first slot.  A lane sums its 8 steps; the lane
+// with the second half of a group (e = 8 mod 16: an ODD lane, since a panel's entries start on a group boundary and lane t takes
+// e0 + 8 t + whole rounds) adds the first half's total, fetched from the lane below it (DPP row_shr:1 -- every lane of the wave
+// executes this, and an odd lane that is inside the range has its even neighbour inside too).
+template <bool NTLD, bool L8>
+__device__ __forceinline__ v4u row_ids(const uint16_t *__restrict__ lrow, const uint8_t *__restrict__ lrow8,
+                                       const uint16_t *__restrict__ gbase, int64_t e)
+{
+  if (!L8) return stream_load<NTLD>((const v4u *)(lrow + e));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const v2u d = stream_load<NTLD>((const v2u *)(lrow8 + e));
+  const unsigned base = gbase[e >> kBinGroupLog];
+  const unsigned s0 = d.x & 0xffu, s1 = s0 + ((d.x >> 8) & 0xffu), s2 = s1 + ((d.x >> 16) & 0xffu), s3 = s2 + (d.x >> 24);
+  const unsigned s4 = s3 + (d.y & 0xffu), s5 = s4 + ((d.y >> 8) & 0xffu), s6 = s5 + ((d.y >> 16) & 0xffu), s7 = s6 + (d.y >> 24);
+  const unsigned below = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s7, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+  const unsigned off = base + (((unsigned)(e >> 3) & 1u) ? below : 0u);
+  return v4u{(off + s0) | ((off + s1) << 16), (off + s2) | ((off + s3) << 16), (off + s4) | ((off + s5) << 16), (off + s6) | ((off + s7) << 16)};
+}
+
 // pass 2: workgroup = one row panel; its products are contiguous.  ytile: the panel's slice of y in LDS.
-template <bool NTLD>
+template <bool NTLD, bool L8 = false>
 __device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int panel, const unsigned *__restrict__ bin_ptr,
                                              const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-                                             const double *__restrict__ prod, double *__restrict__ y, int ys)
+                                             const double *__restrict__ prod, double *__restrict__ y, int ys,
+                                             const uint8_t *__restrict__ lrow8 = nullptr, const uint16_t *__restrict__ gbase = nullptr)
 {
   const int t = threadIdx.x;
   const int r0 = panel_row[panel], nr = panel_row[panel + 1] - r0;
@@ -147,7 +168,7 @@ __device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int pan
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int64_t ek = e + (int64_t)k * 8 * kBinBlock;
-      a[k] = stream_load<NTLD>((const v4u *)(lrow + ek));
+      a[k] = row_ids<NTLD, L8>(lrow, lrow8, gbase, ek);
 #pragma unroll
       for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ek + 2 * j));
     }
@@ -155,12 +176,15 @@ __device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int pan
     FS_ADD8(a[0], p[0])
     FS_ADD8(a[1], p[1])
   }
-  for (; e < e1; e += 8 * kBinBlock) {
-    const v4u a = stream_load<NTLD>((const v4u *)(lrow + e));
+  // the last, partial round: whole waves stay together (the one-byte row ids shift a value between neighbouring lanes), the lanes
+  // past the end read the panel's last eight entries and skip their adds
+  for (; e - 8 * (t & 63) < e1; e += 8 * kBinBlock) {
+    const int64_t ec = e < e1 ? e : e1 - 8;
+    const v4u a = row_ids<NTLD, L8>(lrow, lrow8, gbase, ec);
     v2d p[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = stream_load<NTLD>((const v2d *)(prod + e + 2 * j));
-    FS_ADD8(a, p)
+    for (int j = 0; j < 4; ++j) p[j] = stream_load<NTLD>((const v2d *)(prod + ec + 2 * j));
+    if (e < e1) { FS_ADD8(a, p) }
   }
 #undef FS_ADD8
 #undef FS_ADD
@@ -168,13 +192,14 @@ __device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int pan
   for (int i = t; i < nr; i += kBinBlock) y[(int64_t)(r0 + i) * ys] = ytile[i];
 }
 
-template <bool NTLD, int RM = kBinRowsMax>
+template <bool NTLD, int RM = kBinRowsMax, bool L8 = false>
 __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
     const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
+    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase, const uint8_t *__restrict__ lrow8 = nullptr,
+    const uint16_t *__restrict__ gbase = nullptr)
 {
   __shared__ double ytile[RM];
-  reduce_panel<NTLD>(ytile, pbase + blockIdx.x, bin_ptr, panel_row, lrow, prod, y, ys);
+  reduce_panel<NTLD, L8>(ytile, pbase + blockIdx.x, bin_ptr, panel_row, lrow, prod, y, ys, lrow8, gbase);
 }
 
 // pass 2 with a FIXED order of additions: ONE wave per panel walks the panel's products in stream order, 512 entries per step
@@ -187,10 +212,11 @@ __global__ __launch_bounds__(kBinBlock) void spmv_reduce_kernel(
 #ifndef FS_ORDERED_DEPTH
 #define FS_ORDERED_DEPTH 16   // steps of loads in flight (config 2: 4 / 6 / 8 / 12 / 16 / 20 -> +13 / +7 / +6 / +4.3 / +3.5 / +3 % over the 16-wave pass)
 #endif
-template <bool NTLD, int RM, int DEPTH>
+template <bool NTLD, int RM, int DEPTH, bool L8 = false>
 __global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
     const unsigned *__restrict__ bin_ptr, const int *__restrict__ panel_row, const uint16_t *__restrict__ lrow,
-    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase)
+    const double *__restrict__ prod, double *__restrict__ y, int ys, int pbase, const uint8_t *__restrict__ lrow8 = nullptr,
+    const uint16_t *__restrict__ gbase = nullptr)
 {
   __shared__ __attribute__((aligned(16))) double ytile[RM];
   const int t = threadIdx.x;
@@ -210,7 +236,7 @@ __global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
   // steps past the end re-read the segment's last eight entries (their adds are skipped): every load is unconditional
   auto fetch = [&](int k, int64_t e) {
     const int64_t ec = (e + 8 <= e1) ? e : (e1 - e0 >= 8 ? e1 - 8 : e0);
-    a[k] = stream_load<NTLD>((const v4u *)(lrow + ec));
+    a[k] = row_ids<NTLD, L8>(lrow, lrow8, gbase, ec);
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ec + 2 * j));
   };
@@ -675,9 +701,15 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
     else if (N.bcols == kBinColsBig)
       hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row,
                          N.lrow, N.prod, out, os, p0);
+    else if (ordered && N.lrow8)
+      hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsMax, FS_ORDERED_DEPTH, true>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
+                         N.panel_row, N.lrow, N.prod, out, os, p0, N.lrow8, N.gbase);
     else if (ordered)
       hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsMax, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
                          N.panel_row, N.lrow, N.prod, out, os, p0);
+    else if (N.lrow8)       // one byte per row id (BinnedCsr::lrow8): default loads only
+      hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsMax, true>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow,
+                         N.prod, out, os, p0, N.lrow8, N.gbase);
     else if (options().bin_flags & 4)
       hipLaunchKernelGGL(spmv_reduce_kernel<true>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
                          out, os, p0);
@@ -720,6 +752,9 @@ int launch_reduce_panels(const DeviceCsr &A, double *y, int p0, int p1, hipStrea
   if (N.bcols == kBinColsBig)
     hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
                        y, 1, p0);
+  else if (N.lrow8)
+    hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsMax, true>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod,
+                       y, 1, p0, N.lrow8, N.gbase);
   else
     hipLaunchKernelGGL(spmv_reduce_kernel<false>, dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row, N.lrow, N.prod, y, 1, p0);
   FS_HIP(hipGetLastError());

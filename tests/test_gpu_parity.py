@@ -2033,6 +2033,105 @@ def test_non_finite_x_reaches_exactly_the_rows_that_reference_it(hip, kind):
         capi.set_option("long_rows", 1)
 
 
+@pytest.mark.parametrize("shape", ["uniform", "uniform_pattern", "holes", "heavy_tail", "small_panels"])
+def test_two_pass_copy_with_one_byte_row_ids(hip, shape):
+    """where the (band, panel) cells of the two-pass copy are dense -- config 2: 430 entries per cell, in ascending
+    row order -- pass 2 reads ONE byte per entry (the step from the entry before it, the row in front of every group of 16 beside it)
+    instead of a two-byte row id; a step above 255 is walked by dummy entries of value 0.  Same sums: against the oracle (csr.h:425-438);
+    against the two-byte form of the SAME matrix bit for bit where sums are exact (pattern-only, integer x) and within the bar otherwise;
+    bit-identical from run to run under `reproducible` (a dummy adds + 0.0); in parts; through the host-vector path."""
+    import ctypes as C
+    import torch
+    from libfastsparse_amd import capi
+    L = capi.lib()
+    L.fs_debug_two_pass_rows8.restype = C.c_longlong
+    L.fs_debug_two_pass_rows8.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(20251005)
+    opts = {"binning": 2, "ldsx": 0, "tiling": 0}
+    if shape in ("uniform", "uniform_pattern"):
+        nrow = ncol = 1_000_000
+        lens = np.full(nrow, 16)
+    elif shape == "holes":                       # one 16 384-row panel with long empty stretches: steps far above 255
+        nrow, ncol = 40_000, 5_000
+        lens = np.zeros(nrow, np.int64)
+        lens[:10_000], lens[16_000], lens[30_000:30_010], lens[39_999] = 3, 2, 5, 1
+    elif shape == "heavy_tail":
+        nrow, ncol = 60_000, 40_000
+        lens = np.minimum((9 / np.maximum(rng.uniform(size=nrow), 1e-6)).astype(np.int64), 50_000) // 8
+        opts["long_rows"] = 2
+    else:
+        nrow, ncol = 5_000, 2_049
+        lens = rng.poisson(40, nrow)
+        opts["bin_rows"] = 64
+    rp = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rp = rp.astype(np.int32)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    vv = None if shape == "uniform_pattern" else rng.uniform(-1, 1, nnz)
+    st = capi.current_stream()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()       # noqa: E731
+    xi = rng.integers(-9, 10, ncol).astype(np.float64)
+    xs = np.sin(7.0 * np.arange(ncol) + 0.3)
+    out = {}
+    # arrival-order sums: the same bits only where every sum is exact (pattern-only, integer x); the bar otherwise
+    sci = O.csr_abs_scale(nrow, rp, cc, vv, xi)
+    same = np.array_equal if vv is None else (lambda a, b: bool(np.all(np.abs(a - b) <= np.maximum(TOL, 2.0 * np.diff(rp) * 2.0 ** -53) * sci)))
+    for k, v in opts.items():
+        capi.set_option(k, v)
+    try:
+        for form, flags in (("two_bytes", 64), ("one_byte", 128)):
+            capi.set_option("bin_flags", flags)
+            A = capi.Matrix.from_csr(nrow, ncol, d(rp), d(cc), None if vv is None else d(vv))
+            capi.set_option("bin_flags", 0)
+            assert A.kernel_name() == "two-pass"
+            dummies = L.fs_debug_two_pass_rows8(A.h, 0)
+            assert (dummies == -1) if form == "two_bytes" else (dummies >= 0), (form, dummies)
+            if form == "one_byte" and shape == "holes":
+                assert dummies >= 20, dummies
+            y = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+            res = {}
+            for name, x in (("int", xi), ("sin", xs)):
+                y.fill_(-1.0)
+                A.spmv(y, d(x), st)
+                res[name] = y.cpu().numpy()
+                ref, sc = O.csr_mul(nrow, rp, cc, vv, x), O.csr_abs_scale(nrow, rp, cc, vv, x)
+                assert np.all(np.abs(res[name] - ref) <= np.maximum(TOL, 2.0 * np.diff(rp) * 2.0 ** -53) * sc), (form, name)
+            capi.set_option("reproducible", 1)
+            try:
+                y.fill_(-1.0)
+                A.spmv(y, d(xs), st)
+                res["sin_fixed_order"] = y.cpu().numpy()
+                y.fill_(-1.0)
+                A.spmv(y, d(xs), st)
+                assert np.array_equal(res["sin_fixed_order"], y.cpu().numpy())
+            finally:
+                capi.set_option("reproducible", 0)
+            # in three parts, rows range by range (fs_spmv_part: what the multi-GPU layer ships part by part)
+            y.fill_(-1.0)
+            for part in range(3):
+                A.spmv_part(y, d(xi), part, 3, st)
+            assert same(y.cpu().numpy(), res["int"]), form
+            # host vectors through the pipelined path
+            yh = np.full(nrow, -1.0)
+            A.spmv_host(yh, xi)
+            assert same(yh, res["int"]), form
+            out[form] = res
+            A.close()
+        assert same(out["one_byte"]["int"], out["two_bytes"]["int"])
+        # (each form's fixed order is its own: a dummy shifts the entries behind it to other lanes of the one-wave pass 2)
+        scs = O.csr_abs_scale(nrow, rp, cc, vv, xs)
+        assert np.all(np.abs(out["one_byte"]["sin_fixed_order"] - out["two_bytes"]["sin_fixed_order"]) <= np.maximum(TOL, 2.0 * np.diff(rp) * 2.0 ** -53) * scs)
+        if shape == "uniform":                   # and the builder takes the one-byte form by itself where the cells are dense
+            A = capi.Matrix.from_csr(nrow, ncol, d(rp), d(cc), d(vv))
+            assert 0 <= L.fs_debug_two_pass_rows8(A.h, 0) <= 0.01 * nnz
+            A.close()
+    finally:
+        capi.set_option("bin_flags", 0)
+        for k in opts:
+            capi.set_option(k, 1 if k in ("binning", "ldsx", "tiling", "long_rows") else 0)
+
+
 def test_release_and_restore_of_the_plain_csr(hip):
     """once the builder has kept a re-ordered copy the plain arrays are dead weight.  fs_matrix_release_csr gives
     them back (A and A'): the default products are unchanged, the handle holds its copy alone, everything that reads the plain arrays

@@ -27,7 +27,8 @@ rng = np.random.default_rng(seed)
 L = capi.lib()
 st = capi.current_stream()
 # option sets: small panels / tiles (bin_rows, tile_rows, tile_cols) take small matrices through the many-panel paths of the big ones
-FORCE = [{}, {"binning": 2}, {"binning": 2, "bin_rows": 64}, {"binning": 2, "bin_rows": 64, "reproducible": 1}, {"binning": 2, "long_rows": 2, "bin_rows": 128},
+FORCE = [{}, {"binning": 2}, {"binning": 2, "bin_flags": 64}, {"binning": 2, "bin_flags": 128}, {"binning": 2, "bin_flags": 128, "reproducible": 1},
+         {"binning": 2, "bin_rows": 64}, {"binning": 2, "bin_rows": 64, "reproducible": 1}, {"binning": 2, "long_rows": 2, "bin_rows": 128},
          {"binning": 2, "long_rows": 2, "long_min_len": 40, "reproducible": 1}, {"binning": 2, "bin_rows": 256, "spmm_kernel": 2}, {"ldsx": 2},
          {"ldsx": 2, "tile_rows": 64}, {"ldsx": 2, "reproducible": 1}, {"ldsx": 2, "tiled_flags": 4}, {"tiling": 2}, {"tiling": 2, "tile_rows": 64, "tile_cols": 512},
          {"tiling": 2, "tile_split": 8}, {"spmv_kernel": 1}, {"spmv_kernel": 2}, {"spmv_kernel": 3}, {"reproducible": 1}, {"strict_order": 1},
