@@ -192,10 +192,12 @@ struct BinnedCsr {
   // from the entry before it, with the row in front of every group of 16 in gbase -- 1.125 bytes per entry instead of 2.  A step
   // above 255 is walked by dummy entries (zero slot of the band, value 0, step 255) in front of the entry, in BOTH orders (a group
   // holds the same entries in pass 1 and pass 2); the builder takes this form when the dummies stay below 1 % of the entries
-  // (bin_flags bit 6: never, bit 7: always).  lrow is then nullptr.
+  // (bin_flags bit 6: never, bit 7: always).  lrow is then nullptr until a fixed-order product asks for it.
   uint8_t *lrow8 = nullptr;    // n, pass-2 order: row - row of the slot before (first slot of a cell: 0); padding = 0
   uint16_t *gbase = nullptr;   // n / kBinGroup: the row in front of the group's first slot (first group of a cell: its first row)
   int64_t dummies = 0;         // entries added to walk steps above 255
+  bool lrow_tried = false;     // the first fixed-order product writes the two-byte ids out once (lrow beside lrow8: the one-wave pass 2
+                               // reads those; fs_kernels_twopass.hip, ensure_two_byte_ids)
   double *prod = nullptr;      // n * kw, pass-2 order: written by pass 1, read by pass 2
   unsigned *band_ptr = nullptr;  // B + 1: first pass-1 group of every band
   int nwg1 = 0;                // pass-1 workgroups (persistent, one per CU)

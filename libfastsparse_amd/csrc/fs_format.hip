@@ -241,8 +241,8 @@ void device_bytes(const DeviceCsr &A, int64_t out[3])
   };
   auto binned_bytes = [&](const BinnedCsr *N) -> int64_t {
     if (!N) return 0;
-    int64_t b = N->n * (2 + (N->lrow8 ? 1 : 2) + 8ll * N->kw + (N->vals ? 8 : 0)) + (N->lrow8 ? 6 : 4) * (N->n / (kBinGroup / N->kw)) + 4ll * (N->B + 1) +
-                8ll * (N->P + 1);
+    int64_t b = N->n * (2 + (N->lrow8 ? 1 : 0) + (N->lrow ? 2 : 0) + 8ll * N->kw + (N->vals ? 8 : 0)) + (N->lrow8 ? 6 : 4) * (N->n / (kBinGroup / N->kw)) +
+                4ll * (N->B + 1) + 8ll * (N->P + 1);
     if (N->vfirst) b += 4ll * (A.nrow + 1);
     if (N->yv) b += 8ll * N->nvrow * N->kw;
     if (N->lr) b += N->lr->n * (4 + (N->lr->vals ? 8 : 0)) + 12ll * N->lr->nlong + (8ll + 4ll * (kLongOwners + 1)) * (N->lr->B + 1) +

@@ -120,23 +120,31 @@ __global__ __launch_bounds__(kBinBlock) void spmv_expand_kernel(
   expand_share<VALUED, U, NTLD, NTST, BC>(xband, ncol, B, band_ptr, lcol, vals, gdst, x, xs, prod, g0, g1);
 }
 
-// the local rows of the 8 entries e .. e + 7 (e a multiple of 8) as four pairs of 16-bit ids.  L8 (BinnedCsr::lrow8): one byte per
-// entry, the step from the slot before it; gbase[g] = the row in front of group g's first slot.  A lane sums its 8 steps; the lane
-// with the second half of a group (e = 8 mod 16: an ODD lane, since a panel's entries start on a group boundary and lane t takes
-// e0 + 8 t + whole rounds) adds the first half's total, fetched from the lane below it (DPP row_shr:1 -- every lane of the wave
-// executes this, and an odd lane that is inside the range has its even neighbour inside too).
+// the local rows of the 8 entries e .. e + 7 (e a multiple of 8) as four pairs of 16-bit ids, in two steps so that the loads of
+// several steps can be in flight before the first is used: row_ids_load issues the loads, row_ids decodes what they brought.
+// L8 (BinnedCsr::lrow8): one byte per entry, the step from the slot before it; gbase[g] = the row in front of group g's first slot.
+// A lane sums its 8 steps; the lane with the second half of a group (e = 8 mod 16: an ODD lane, since a panel's entries start on a
+// group boundary and lane t takes e0 + 8 t + whole rounds) adds the first half's total, fetched from the lane below it (DPP
+// row_shr:1 -- every lane of the wave executes the decode, and an odd lane inside the range has its even neighbour inside too).
 template <bool NTLD, bool L8>
-__device__ __forceinline__ v4u row_ids(const uint16_t *__restrict__ lrow, const uint8_t *__restrict__ lrow8,
-                                       const uint16_t *__restrict__ gbase, int64_t e)
+__device__ __forceinline__ v4u row_ids_load(const uint16_t *__restrict__ lrow, const uint8_t *__restrict__ lrow8,
+                                            const uint16_t *__restrict__ gbase, int64_t e)
 {
   if (!L8) return stream_load<NTLD>((const v4u *)(lrow + e));
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   const v2u d = stream_load<NTLD>((const v2u *)(lrow8 + e));
-  const unsigned base = gbase[e >> kBinGroupLog];
-  const unsigned s0 = d.x & 0xffu, s1 = s0 + ((d.x >> 8) & 0xffu), s2 = s1 + ((d.x >> 16) & 0xffu), s3 = s2 + (d.x >> 24);
-  const unsigned s4 = s3 + (d.y & 0xffu), s5 = s4 + ((d.y >> 8) & 0xffu), s6 = s5 + ((d.y >> 16) & 0xffu), s7 = s6 + (d.y >> 24);
+  return v4u{d.x, d.y, (unsigned)gbase[e >> kBinGroupLog], (unsigned)(e >> 3) & 1u};
+}
+
+template <bool L8>
+__device__ __forceinline__ v4u row_ids(v4u raw)
+{
+  if (!L8) return raw;
+  const unsigned dx = raw.x, dy = raw.y;
+  const unsigned s0 = dx & 0xffu, s1 = s0 + ((dx >> 8) & 0xffu), s2 = s1 + ((dx >> 16) & 0xffu), s3 = s2 + (dx >> 24);
+  const unsigned s4 = s3 + (dy & 0xffu), s5 = s4 + ((dy >> 8) & 0xffu), s6 = s5 + ((dy >> 16) & 0xffu), s7 = s6 + (dy >> 24);
   const unsigned below = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s7, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-  const unsigned off = base + (((unsigned)(e >> 3) & 1u) ? below : 0u);
+  const unsigned off = raw.z + (raw.w ? below : 0u);
   return v4u{(off + s0) | ((off + s1) << 16), (off + s2) | ((off + s3) << 16), (off + s4) | ((off + s5) << 16), (off + s6) | ((off + s7) << 16)};
 }
 
@@ -168,11 +176,13 @@ __device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int pan
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int64_t ek = e + (int64_t)k * 8 * kBinBlock;
-      a[k] = row_ids<NTLD, L8>(lrow, lrow8, gbase, ek);
+      a[k] = row_ids_load<NTLD, L8>(lrow, lrow8, gbase, ek);
 #pragma unroll
       for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ek + 2 * j));
     }
     __builtin_amdgcn_sched_barrier(0);
+    a[0] = row_ids<L8>(a[0]);
+    a[1] = row_ids<L8>(a[1]);
     FS_ADD8(a[0], p[0])
     FS_ADD8(a[1], p[1])
   }
@@ -180,10 +190,11 @@ __device__ __forceinline__ void reduce_panel(double *__restrict__ ytile, int pan
   // past the end read the panel's last eight entries and skip their adds
   for (; e - 8 * (t & 63) < e1; e += 8 * kBinBlock) {
     const int64_t ec = e < e1 ? e : e1 - 8;
-    const v4u a = row_ids<NTLD, L8>(lrow, lrow8, gbase, ec);
+    const v4u raw = row_ids_load<NTLD, L8>(lrow, lrow8, gbase, ec);
     v2d p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = stream_load<NTLD>((const v2d *)(prod + ec + 2 * j));
+    const v4u a = row_ids<L8>(raw);
     if (e < e1) { FS_ADD8(a, p) }
   }
 #undef FS_ADD8
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
   // steps past the end re-read the segment's last eight entries (their adds are skipped): every load is unconditional
   auto fetch = [&](int k, int64_t e) {
     const int64_t ec = (e + 8 <= e1) ? e : (e1 - e0 >= 8 ? e1 - 8 : e0);
-    a[k] = row_ids<NTLD, L8>(lrow, lrow8, gbase, ec);
+    a[k] = row_ids_load<NTLD, L8>(lrow, lrow8, gbase, ec);      // (decoded where it is used: the loads of DEPTH steps stay in flight)
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[k][j] = stream_load<NTLD>((const v2d *)(prod + ec + 2 * j));
   };
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(64) void spmv_reduce_ordered_kernel(
 #pragma unroll
       for (int k = 0; k < DEPTH; ++k) {
         const int64_t ek = e + (int64_t)k * kStep;
-        const v4u ak = a[k];
+        const v4u ak = row_ids<L8>(a[k]);
         v2d pk[4] = {p[k][0], p[k][1], p[k][2], p[k][3]};
         fetch(k, ek + (int64_t)DEPTH * kStep);
         if (ek + 8 <= e1) { FS_ADD8(ak, pk) }
@@ -653,6 +664,43 @@ __global__ __launch_bounds__(kBlock) void tiled_combine_k_kernel(int nrow, const
 
 // p0 .. p1: the panels pass 2 covers in this launch (p1 < 0: all of them); pass 1 runs when p0 == 0.  With cut rows the
 // combine pass covers rows row0 .. row1 (the rows whose last piece lies in a panel below p1: see spmv_part_bounds).
+// The one-wave pass 2 of fixed-order sums is bound by what ONE wave can issue per step, so the decode of one-byte row ids costs it
+// what it saves the sixteen-wave pass (config 2: + 11.5 % instead of + 3.6 % over the arrival-order product).  The first fixed-order
+// product on such a copy therefore writes the two-byte ids out once (0.1 ms for 160 M entries + one allocation of 2 bytes per entry)
+// and the ordered kernel keeps reading those; the default product never touches them.  If the allocation fails the ordered kernel
+// decodes on the fly (spmv_reduce_ordered_kernel<..., true>).
+__global__ void rows8_decode_kernel(int64_t groups, const uint8_t *__restrict__ lrow8, const uint16_t *__restrict__ gbase,
+                                    uint16_t *__restrict__ lrow)
+{
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  const v4u d = *(const v4u *)(lrow8 + g * kBinGroup);
+  unsigned r = gbase[g];
+  unsigned out[kBinGroup / 2];
+#pragma unroll
+  for (int j = 0; j < kBinGroup; j += 2) {
+    const unsigned w = j < 4 ? d.x : j < 8 ? d.y : j < 12 ? d.z : d.w;
+    const unsigned a = r + ((w >> (8 * (j & 3))) & 0xffu), b = a + ((w >> (8 * ((j + 1) & 3))) & 0xffu);
+    out[j / 2] = a | (b << 16);
+    r = b;
+  }
+#pragma unroll
+  for (int j = 0; j < kBinGroup / 8; ++j)
+    *(v4u *)(lrow + g * kBinGroup + 8 * j) = v4u{out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]};
+}
+
+static void ensure_two_byte_ids(BinnedCsr &N, hipStream_t s)
+{
+  if (N.lrow || !N.lrow8 || N.lrow_tried) return;
+  N.lrow_tried = true;
+  uint16_t *p = nullptr;
+  if (hipMalloc(&p, sizeof(uint16_t) * (size_t)N.n) != hipSuccess) { (void)hipGetLastError(); return; }
+  const int64_t groups = N.n >> kBinGroupLog;
+  if (groups > 0) hipLaunchKernelGGL(rows8_decode_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, groups, N.lrow8, N.gbase, p);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return; }
+  N.lrow = p;       // (behind the synchronize: a later product on another stream finds the ids complete)
+}
+
 int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream_t s, int xs, int ys, int p0, int p1, int row0,
                        int row1)
 {
@@ -695,13 +743,14 @@ int launch_spmv_binned(const DeviceCsr &A, double *y, const double *x, hipStream
   if (p1 > p0) {
     // "reproducible" (or bit 5 of bin_flags): one wave per panel, additions in stream order, bit-identical run to run
     const bool ordered = reproducible_now() || (options().bin_flags & 32);
+    if (ordered && N.lrow8 && !N.lrow) ensure_two_byte_ids(*A.binned, s);
     if (N.bcols == kBinColsBig && ordered)
       hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsBig, FS_ORDERED_DEPTH>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
                          N.panel_row, N.lrow, N.prod, out, os, p0);
     else if (N.bcols == kBinColsBig)
       hipLaunchKernelGGL((spmv_reduce_kernel<false, kBinRowsBig>), dim3(p1 - p0), dim3(kBinBlock), 0, s, N.bin_ptr, N.panel_row,
                          N.lrow, N.prod, out, os, p0);
-    else if (ordered && N.lrow8)
+    else if (ordered && N.lrow8 && !N.lrow)
       hipLaunchKernelGGL((spmv_reduce_ordered_kernel<false, kBinRowsMax, FS_ORDERED_DEPTH, true>), dim3(p1 - p0), dim3(64), 0, s, N.bin_ptr,
                          N.panel_row, N.lrow, N.prod, out, os, p0, N.lrow8, N.gbase);
     else if (ordered)
