@@ -29,7 +29,8 @@ vp = C.c_void_p
 L.fs_debug_dist_k_parts.argtypes = [vp, C.c_int]
 L.fs_debug_dist_parts.argtypes = [vp, C.c_int]
 # option sets: small panels (bin_rows / tile_rows) are what lets a small matrix be cut into parts at all
-FORCE = [{}, {}, {"binning": 2}, {"binning": 2, "bin_rows": 64}, {"binning": 2, "bin_rows": 64, "reproducible": 1},
+FORCE = [{}, {}, {"binning": 2}, {"binning": 2, "bin_flags": 128}, {"binning": 2, "bin_flags": 128, "bin_rows": 256, "reproducible": 1}, {"binning": 2, "bin_flags": 64},
+         {"binning": 2, "bin_rows": 64}, {"binning": 2, "bin_rows": 64, "reproducible": 1},
          {"binning": 2, "bin_rows": 256, "spmm_kernel": 2}, {"binning": 2, "long_rows": 2, "bin_rows": 128}, {"ldsx": 2}, {"ldsx": 2, "tile_rows": 64},
          {"tiling": 2, "tile_rows": 64}, {"tiling": 2, "tile_rows": 64, "reproducible": 1}, {"spmv_kernel": 1}, {"reproducible": 1},
          {"strict_order": 1}, {"release_csr": 1}]
