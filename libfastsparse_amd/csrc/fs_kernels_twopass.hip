@@ -692,6 +692,9 @@ __global__ void rows8_decode_kernel(int64_t groups, const uint8_t *__restrict__ 
 static void ensure_two_byte_ids(BinnedCsr &N, hipStream_t s)
 {
   if (N.lrow || !N.lrow8 || N.lrow_tried) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (cap != hipStreamCaptureStatusNone) return;      // a product being captured into a graph: no allocation, no wait -- decode on the fly
   N.lrow_tried = true;
   uint16_t *p = nullptr;
   if (hipMalloc(&p, sizeof(uint16_t) * (size_t)N.n) != hipSuccess) { (void)hipGetLastError(); return; }

@@ -2118,6 +2118,26 @@ def test_two_pass_copy_with_one_byte_row_ids(hip, shape):
             assert same(yh, res["int"]), form
             out[form] = res
             A.close()
+            if form == "one_byte" and shape == "uniform_pattern":
+                # the FIRST fixed-order product of a handle captured into a graph: no allocation and no wait may happen there, so the
+                # one-wave pass 2 decodes the one-byte ids on the fly -- the same ids, the same order, the same bits
+                capi.set_option("bin_flags", 128)
+                B = capi.Matrix.from_csr(nrow, ncol, d(rp), d(cc), None)
+                capi.set_option("bin_flags", 0)
+                xd, yg = d(xs), torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+                torch.cuda.synchronize()
+                capi.set_option("reproducible", 1)
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        B.spmv(yg, xd, capi.current_stream())
+                    g.replay()
+                    torch.cuda.synchronize()
+                finally:
+                    capi.set_option("reproducible", 0)
+                assert np.array_equal(yg.cpu().numpy(), res["sin_fixed_order"])
+                del g
+                B.close()
         assert same(out["one_byte"]["int"], out["two_bytes"]["int"])
         # (each form's fixed order is its own: a dummy shifts the entries behind it to other lanes of the one-wave pass 2)
         scs = O.csr_abs_scale(nrow, rp, cc, vv, xs)
