@@ -733,9 +733,12 @@ void cbcsr_A_mul_B(double *y, struct ColBinaryCSR *A, double *x)
   uint64_t h = mix(mix(mix(4, (uint64_t)A->nrow), (uint64_t)A->ncol), (uint64_t)A->nnz);
   h = mix(mix(mix(h, (uint64_t)A->colblocksize), (uint64_t)(uintptr_t)A->row_ptr), (uint64_t)(uintptr_t)A->cols);
   h = print_ints(print_ints(h, A->row_ptr, ncell + 1, full), A->cols, A->nnz, full);
-  if (dist_on()) {
+  if (dist_on() && !fs::options().strict_order) {
     // across the GPUs: the same entries as a plain pattern-only CSR whose rows hold their cells' entries block by block (the order the
-    // single-GPU kernels add large column-blocked matrices in; cbcsr.h:88-103 itself adds per-thread partial vectors in schedule order)
+    // single-GPU kernels add large column-blocked matrices in; cbcsr.h:88-103 itself adds per-thread partial vectors in schedule order).
+    // A row's terms are then ONE running sum, where the serial reference adds a partial sum per column block to y: the same bits for
+    // integer data, within the bar otherwise -- so under strict_order (the reference's bits for arbitrary x) the call stays on ONE GPU,
+    // whose kernels keep the per-block association (tools/fuzz_dropin.py under FS_STRICT_ORDER=1 FASTSPARSE_NGPU=3 found the difference).
     fs_dist_t D = dist_context("cbcsr_A_mul_B");
     EntryP e = lookup(A, kDist, mix(5, h), [&](Entry &n) {
       std::vector<int> rp((size_t)A->nrow + 1, 0), cc((size_t)A->nnz);

@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tool,env", [("fuzz_parity.py", {}), ("fuzz_dist.py", {}), ("fuzz_dist.py", {"FS_DIST_PARTS": "7", "FS_DIST_THREADS": "1"}),
-                                      ("fuzz_dropin.py", {}), ("fuzz_dropin.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"})])
+                                      ("fuzz_dropin.py", {}), ("fuzz_dropin.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}),
+                                      # storage-order sums: every family BIT FOR BIT against the oracle for arbitrary x and values, one GPU and three ranks
+                                      ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1"}),
+                                      ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1", "FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"})])
 def test_randomised_differential_stretch(tool, env):
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "6", "20251005"], cwd=ROOT, env=e, capture_output=True, text=True,

@@ -27,6 +27,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
 rng = np.random.default_rng(seed)
 ORA = _cases.OracleBackend()
+STRICT = os.environ.get("FS_STRICT_ORDER") == "1"      # storage-order sums: the oracle's bits for ARBITRARY x and values, every family
 
 FAMILIES = ["coo", "coo_t", "csr", "csr_t", "csr_n", "bin_n", "aa", "aa_parallel", "blocked", "blocked_n", "blocked_valued", "cbcsr"]
 BIN_N = [("bcsr_A_mul_B2", 2), ("bcsr_A_mul_B4", 4), ("bcsr_A_mul_B8", 8), ("bcsr_A_mul_B8_auto", 8), ("bcsr_A_mul_Bn", 3), ("bcsr_A_mul_Bn", 8),
@@ -63,7 +64,7 @@ while time.time() < t_end:
             if isinstance(v, np.ndarray) and v.dtype == np.float64:
                 a[i] = np.abs(v)
         scale = getattr(ORA, method)(*a)
-        exact = integer and not valued
+        exact = (integer and not valued) or STRICT
         check(np.asarray(got), np.asarray(ref), np.asarray(scale), exact, what, out_terms)
 
     lens = np.bincount(rows, minlength=nrow).astype(np.float64)
@@ -82,7 +83,7 @@ while time.time() < t_end:
         o2 = np.argsort(rows, kind="stable")
         ref = ORA.coo_tmul(nrow, ncol, rows[o2], cols[o2], None if v is None else v[o2], u)
         sc = ORA.coo_tmul(nrow, ncol, rows[o2], cols[o2], None if v is None else np.abs(v[o2]), np.abs(u))
-        check(got, ref, sc, integer and not valued, what, clen)
+        check(got, ref, sc, (integer and not valued) or STRICT, what, clen)
     elif fam == "csr_n":
         k = int(rng.choice([2, 3, 4, 8, 17, 32]))
         both("csr_mul_n", nrow, ncol, rows, cols, vals, vec(ncol, k), k, "csr_A_mul_Bn", valued=True, out_terms=lens)
@@ -95,7 +96,7 @@ while time.time() < t_end:
         got = be.aa_mul(nrow, ncol, rows, cols, x, fam == "aa_parallel")
         ref = ORA.aa_mul(nrow, ncol, rows, cols, x, False)
         sc = ORA.aa_mul(nrow, ncol, rows, cols, np.abs(x), False)
-        if integer:
+        if integer or STRICT:
             assert np.array_equal(got, ref), what
         else:
             tol = np.maximum(1e-12, 2.0 * (clen + lens.max(initial=0.0)) * 2.0 ** -53) * 2.0
