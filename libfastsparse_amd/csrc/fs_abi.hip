@@ -141,6 +141,16 @@ int fs_device_synchronize(void)
   return FS_OK;
 }
 
+// option "release_csr": the plain arrays go once a copy is kept -- unless the products the options select NOW would read them (strict_order,
+// spmv_kernel 1-3, or `reproducible` with a kept LDS-staged copy that cannot be ordered): releasing then would turn every product of the
+// handle into an FS_ERR_RELEASED (tools/fuzz_parity.py under FS_REPRODUCIBLE=1 found exactly that); fs_matrix_release_csr stays unconditional
+static void auto_release(fs::DeviceCsr &A)
+{
+  if (!fs::options().release_csr || fs::tl_keep_csr != 0) return;
+  if (fs::spmv_choice(A, fs::options()) < 6) return;
+  (void)fs::release_plain_csr(A);
+}
+
 int fs_set_option(const char *name, int value)
 {
   if (!name) { set_error("fs_set_option: NULL name"); return FS_ERR_ARG; }
@@ -225,7 +235,7 @@ fs_matrix_t fs_csr_create(int nrow, int ncol, int64_t nnz, const int *row_ptr, c
   A.build_ms[0] = up_ms;
   fs::pool_trim();
   if (rc) { fs::free_csr(A); delete M; return nullptr; }
-  if (fs::options().release_csr && fs::tl_keep_csr == 0) (void)fs::release_plain_csr(A);
+  auto_release(A);
   return M;
 }
 
@@ -261,7 +271,7 @@ fs_matrix_t fs_coo_create(int nrow, int ncol, int64_t nnz, const int *rows, cons
   }
   fs::pool_trim();
   if (rc) { fs::free_csr(M->a); delete M; return nullptr; }
-  if (fs::options().release_csr && fs::tl_keep_csr == 0) (void)fs::release_plain_csr(M->a);
+  auto_release(M->a);
   return M;
 }
 
@@ -284,7 +294,7 @@ int fs_matrix_build_transpose(fs_matrix_t A, fs_stream_t stream)
   fs::pool_trim();
   if (rc) { fs::free_csr(A->at); return rc; }
   A->has_t = true;
-  if (fs::options().release_csr && fs::tl_keep_csr == 0) (void)fs::release_plain_csr(A->at);
+  auto_release(A->at);
   return FS_OK;
 }
 

@@ -2276,8 +2276,26 @@ def test_solvers_keep_a_lds_staged_copy_that_cannot_be_ordered(hip):
             A.spmv(y, d(x), st); y1 = y.clone()
             A.spmv(y, d(x), st)
             assert torch.equal(y, y1) and np.all(np.abs(y.cpu().numpy() - ref) <= TOL * scale)
+            # option release_csr (plain arrays back once a copy is kept) must not release what the options' products read: created under
+            # `reproducible` this handle's products run on the streaming kernel, so its arrays stay (tools/fuzz_parity.py, FS_REPRODUCIBLE=1)
+            capi.set_option("release_csr", 1)
+            try:
+                B = capi.Matrix.from_csr(nrow, ncol, d(hrp), d(hcc), None)
+                assert B.kernel_name() == "stream" and B.device_bytes()[0] > 0
+                B.spmv(y, d(x), st)
+                assert torch.equal(y, y1)
+                B.close()
+            finally:
+                capi.set_option("release_csr", 0)
         finally:
             capi.set_option("reproducible", 0)
+        capi.set_option("release_csr", 1)       # and created WITHOUT the requirement the same matrix does give its arrays back
+        try:
+            B = capi.Matrix.from_csr(nrow, ncol, d(hrp), d(hcc), None)
+            assert B.kernel_name() == "lds-staged" and B.device_bytes()[0] == 0
+            B.close()
+        finally:
+            capi.set_option("release_csr", 0)
     finally:
         capi.set_option("ldsx", 1)
         capi.set_option("cg_fixed_order", 1)

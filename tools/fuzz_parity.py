@@ -35,6 +35,7 @@ FORCE = [{}, {"binning": 2}, {"binning": 2, "bin_flags": 64}, {"binning": 2, "bi
          {"spmm_kernel": 1}, {"spmm_kernel": 3}, {"spmm_wide": 1}, {"release_csr": 1}, {"release_csr": 1, "binning": 2},
          {"release_csr": 1, "ldsx": 2}, {"release_csr": 1, "tiling": 2, "tile_rows": 64}]
 RESET = {"binning": 1, "ldsx": 1, "tiling": 1, "long_rows": 1}          # every other option: 0
+PRESET = {k: 1 for k, e in (("reproducible", "FS_REPRODUCIBLE"), ("strict_order", "FS_STRICT_ORDER")) if os.environ.get(e) == "1"}   # env presets stay
 
 
 t_end = time.time() + budget
@@ -63,6 +64,11 @@ while time.time() < t_end:
         lens = np.diff(rp).astype(np.float64)
         clen = np.bincount(cc, minlength=ncol).astype(np.float64)
         check(y.cpu().numpy(), ref, scale, exact, ("spmv", what), lens)
+        fixed = L.fs_get_option(b"reproducible") == 1 or L.fs_get_option(b"strict_order") == 1
+        if fixed:                                   # fixed-order sums: a second product gives the same bits
+            y2 = torch.full((nrow,), -2.0, dtype=torch.float64, device="cuda")
+            A.spmv(y2, d(x), st)
+            assert torch.equal(y, y2), ("spmv twice", what)
         # transposed (a handle that gave its plain arrays back under release_csr says so, takes them back and goes on)
         try:
             A.build_transpose(st)
@@ -77,6 +83,10 @@ while time.time() < t_end:
         z = torch.full((ncol,), -1.0, dtype=torch.float64, device="cuda")
         A.spmv(z, d(u), st, transposed=True)
         check(z.cpu().numpy(), zref, zsc, exact, ("spmv_t", what), clen)
+        if fixed:
+            z2 = torch.full((ncol,), -2.0, dtype=torch.float64, device="cuda")
+            A.spmv(z2, d(u), st, transposed=True)
+            assert torch.equal(z, z2), ("spmv_t twice", what)
         # k columns
         if k > 1:
             X = rng.integers(-50, 51, (ncol, k)).astype(np.float64) if integer else np.sin(np.arange(ncol * k, dtype=np.float64)).reshape(ncol, k)
@@ -86,6 +96,10 @@ while time.time() < t_end:
             Yr = O.csr_mul_n(nrow, rp, cc, vals, X, k)
             Ys = O.csr_mul_n(nrow, rp, cc, None if vals is None else np.abs(vals), np.abs(X), k)
             check(Y.cpu().numpy(), Yr, Ys, exact, ("spmm", what), lens)
+            if fixed:
+                Y2 = torch.full((nrow, k), -2.0, dtype=torch.float64, device="cuda")
+                A.spmm(Y2, d(X), k, st)
+                assert torch.equal(Y, Y2), ("spmm twice", what)
         A.close()
         # the reference-named entry point with host struct + host vectors
         if valued:
@@ -101,7 +115,7 @@ while time.time() < t_end:
         check(yh[:nrow], ref, scale, exact, ("dropin", what), lens)
     finally:
         for name in force:
-            capi.set_option(name, RESET.get(name, 0))
+            capi.set_option(name, PRESET.get(name, RESET.get(name, 0)))
     cases += 1
     if cases % 25 == 0:
         print("%d cases ok" % cases, flush=True)
