@@ -1,5 +1,5 @@
-"""A short, seeded stretch of the three randomised differential runs (tools/fuzz_parity.py: device layer; tools/fuzz_dist.py: the
-multi-GPU layer on virtual ranks; tools/fuzz_dropin.py: the reference-named entry points) -- the open-ended runs are recorded in
+"""A short, seeded stretch of the randomised differential runs (tools/fuzz_parity.py: device layer; tools/fuzz_dist.py: the
+multi-GPU layer on virtual ranks; tools/fuzz_dropin.py: the reference-named entry points; tools/fuzz_cg.py: the solvers) -- the open-ended runs are recorded in
 profiles/r05_fuzz_parity.txt; here a few hundred cases each keep them from rotting.  Every result is compared with the oracle."""
 import os
 import subprocess
@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                       ("fuzz_dropin.py", {}), ("fuzz_dropin.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}),
                                       # storage-order sums: every family BIT FOR BIT against the oracle for arbitrary x and values, one GPU and three ranks
                                       ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1"}),
-                                      ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1", "FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"})])
+                                      ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1", "FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}),
+                                      # the solvers (bsbm_cg / bsbm_cg2 and fs_cg / fs_cg2): true residuals, iteration counts, two solves bit for bit
+                                      ("fuzz_cg.py", {}), ("fuzz_cg.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"})])
 def test_randomised_differential_stretch(tool, env):
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "6", "20251005"], cwd=ROOT, env=e, capture_output=True, text=True,

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised run of the solvers (bsbm_cg / bsbm_cg2, cg.h:25-187: (A'A + lambda I) x = b on a binary matrix) through the
+reference-named entry points (host structs and vectors) AND the device-resident fs_cg / fs_cg2, against the oracle's restatement
+of the same loops: the TRUE residual of the returned x with the oracle's products (<= 2 tol ||b||: what a solve really left behind),
+the solution against the oracle's, the iteration count within one of the oracle's on these well-conditioned systems (lambda at
+least the mean column weight), and under FS_STRICT_ORDER=1 / FS_CG_FIXED_ORDER two solves bit for bit.  FASTSPARSE_NGPU=3
+FASTSPARSE_DEVICES=0,0,0 runs the entry points across three virtual ranks.     python tools/fuzz_cg.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402,F401
+
+import _hipbackend as H  # noqa: E402
+from oracle import pyoracle as O  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 99
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+cases = 0
+breakdowns = 0
+fragile = 0
+its = []
+while time.time() < t_end:
+    nrow = int(rng.choice([50, 3_000, 40_000, 300_000]))
+    ncol = int(rng.choice([10, 500, 5_000, 60_000]))
+    per = float(rng.choice([1.5, 6, 25]))
+    lens = rng.poisson(per, nrow)
+    while lens.sum() > 3_000_000:
+        lens //= 2
+    rows = np.repeat(np.arange(nrow, dtype=np.int32), lens)
+    nnz = len(rows)
+    cols = rng.integers(0, ncol, nnz).astype(np.int32)
+    order = rng.permutation(nnz)
+    rows, cols = np.ascontiguousarray(rows[order]), np.ascontiguousarray(cols[order])
+    two = bool(rng.integers(0, 2))
+    lam = float(max(1.0, nnz / max(ncol, 1)) * rng.choice([1.0, 4.0]))      # >= the mean column weight: a handful to a few dozen iterations
+    tol = float(rng.choice([1e-6, 1e-9]))
+    i = np.arange(ncol, dtype=np.float64)
+    b1 = np.sin(i * 19 + 0.4) + np.cos(i * i * 3)
+    b = np.ascontiguousarray(np.stack([b1, np.cos(i * 23 + 0.7) + np.sin(i * i * 7)], 1)) if two else b1
+    device = bool(rng.integers(0, 2))
+    what = dict(nrow=nrow, ncol=ncol, nnz=nnz, two=two, lam=lam, tol=tol, device_layer=device, seed=seed, case=cases, ngpu=os.environ.get("FASTSPARSE_NGPU", "1"))
+    be = H.HipDeviceBackend() if device else H.HipDropinBackend()
+    x, it = be.cg(nrow, ncol, rows, cols, b, lam, tol, two)
+    xr, itr = O.cg_normal(nrow, ncol, rows, cols, b, lam, tol, two)
+    if two and np.all(np.isfinite(xr)) and not np.all(np.isfinite(O.cg_normal(nrow, ncol, rows, cols, b, lam, tol * 1e-3, two)[0])):
+        # the reference's block solver is about to break down on this system (NaN at a slightly tighter tolerance: a 2 x 2 step that
+        # turns singular once one right-hand side has converged): where exactly it does depends on the last bits -- not a case to compare
+        fragile += 1
+        cases += 1
+        continue
+    if not np.all(np.isfinite(xr)):          # the reference's own block solver breaks down (a singular 2 x 2 step on a nearly empty matrix): same here
+        assert not np.all(np.isfinite(x)) and it == itr, (what, "the reference breaks down, this solve did not", it, itr)
+        breakdowns += 1
+        cases += 1
+        continue
+    assert np.all(np.isfinite(x)), what
+    rp, cc, _ = O.coo_to_csr(nrow, rows, cols, None)
+    rows_sorted = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
+    for j in range(2 if two else 1):
+        xj = np.ascontiguousarray(x[:, j]) if two else x
+        bj = np.ascontiguousarray(b[:, j]) if two else b
+        xrj = np.ascontiguousarray(xr[:, j]) if two else xr
+
+        def residual(v):
+            return np.linalg.norm(bj - (O.coo_tmul(ncol, rows_sorted, cc, None, O.csr_mul(nrow, rp, cc, None, v)) + lam * v)) / np.linalg.norm(bj)
+        res, res_ref = residual(xj), residual(xrj)
+        # (the reference stops after F = ncol iterations whatever is left: what the oracle's own x leaves behind is then the bar)
+        bar = max(2.0 * tol, 10.0 * res_ref)
+        assert res <= bar, (what, "true residual", res, res_ref)
+        assert np.max(np.abs(xj - xrj)) <= 25.0 * bar * max(np.max(np.abs(xrj)), 1e-300) + 1e-13, (what, "solution", float(np.max(np.abs(xj - xrj))))
+    assert abs(it - itr) <= 1, (what, "iterations", it, itr)
+    x2, it2 = be.cg(nrow, ncol, rows, cols, b, lam, tol, two)          # the solvers' products add in a fixed order: the same solve again, bit for bit
+    assert it2 == it and np.array_equal(x, x2), (what, "two solves differ")
+    its.append(it)
+    cases += 1
+    if cases % 10 == 0:
+        print("%d solves ok" % cases, flush=True)
+    if cases % 100 == 0:
+        be.L.fs_release_all()
+print("fuzz_cg: %d systems (each solved twice), all within the bars (seed %d, FASTSPARSE_NGPU=%s; iterations %d .. %d; %d where the reference's block "
+      "solver itself breaks down to NaN and so does this one, after the same number of iterations; %d skipped where it breaks down at a 1000 x tighter tolerance)"
+      % (cases, seed, os.environ.get("FASTSPARSE_NGPU", "1"), min(its) if its else 0, max(its) if its else 0, breakdowns, fragile))

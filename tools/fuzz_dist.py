@@ -35,6 +35,7 @@ FORCE = [{}, {}, {"binning": 2}, {"binning": 2, "bin_flags": 128}, {"binning": 2
          {"tiling": 2, "tile_rows": 64}, {"tiling": 2, "tile_rows": 64, "reproducible": 1}, {"spmv_kernel": 1}, {"reproducible": 1},
          {"strict_order": 1}, {"release_csr": 1}]
 RESET = {"binning": 1, "ldsx": 1, "tiling": 1, "long_rows": 1}          # every other option: 0
+PRESET = {k: 1 for k, e in (("reproducible", "FS_REPRODUCIBLE"), ("strict_order", "FS_STRICT_ORDER")) if os.environ.get(e) == "1"}   # env presets stay
 
 
 def ok(rc, what):
@@ -107,7 +108,7 @@ while time.time() < t_end:
     u = rng.integers(-1000, 1001, nrow).astype(np.float64) if integer else np.sin(11.0 * np.arange(nrow) - 0.2)
     what = dict(nrow=nrow, ncol=ncol, nnz=len(cc), valued=valued, ranks=ranks, how=how, force=force, integer=integer, hbm=in_hbm, k=k,
                 seed=seed, case=cases)
-    exact = (not valued and integer) or "strict_order" in force
+    exact = (not valued and integer) or "strict_order" in force or os.environ.get("FS_STRICT_ORDER") == "1"
     lens = np.diff(rp).astype(np.float64)
     clen = np.bincount(cc, minlength=ncol).astype(np.float64)
     rows = np.repeat(np.arange(nrow, dtype=np.int32), np.diff(rp))
@@ -196,7 +197,7 @@ while time.time() < t_end:
         if D:
             L.fs_dist_destroy(D)
         for name in force:
-            capi.set_option(name, RESET.get(name, 0))
+            capi.set_option(name, PRESET.get(name, RESET.get(name, 0)))
     cases += 1
     if cases % 20 == 0:
         print("%d cases ok" % cases, flush=True)

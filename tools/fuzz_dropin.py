@@ -34,6 +34,21 @@ BIN_N = [("bcsr_A_mul_B2", 2), ("bcsr_A_mul_B4", 4), ("bcsr_A_mul_B8", 8), ("bcs
          ("bcsr_A_mul_B32n", 5), ("bcsr_A_mul_B32n", 32)]
 BLK_N = [("bsbm_A_mul_B2", 2), ("bsbm_A_mul_B4", 4), ("bsbm_A_mul_Bn", 3), ("bsbm_A_mul_Bn", 7)]
 
+class DeviceVectors(H.HipDropinBackend):
+    """the same calls with x and y in HBM: the entry points take device pointers in place (hipPointerGetAttributes decides per vector)"""
+
+    def _call(self, name, nout, A, x, *extra):
+        import ctypes as C
+        xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64).reshape(-1)).cuda()
+        yd = torch.full((max(nout, 1),), -1.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        f = getattr(self.L, name)
+        f.restype = None
+        f(C.c_void_p(yd.data_ptr()), A if isinstance(A, C._Pointer) else C.byref(A), C.c_void_p(xd.data_ptr()), *extra)
+        self.L.fs_invalidate(A if isinstance(A, C._Pointer) else C.byref(A))
+        return yd.cpu().numpy()[:nout]
+
+
 t_end = time.time() + budget
 cases = 0
 seen = {}
@@ -46,8 +61,9 @@ while time.time() < t_end:
     order = rng.permutation(nnz)                                      # COO entry order is the caller's: any
     rows, cols, vals = np.ascontiguousarray(rows[order]), np.ascontiguousarray(cc[order]), np.ascontiguousarray(vv[order])
     integer = bool(rng.integers(0, 2))
-    be = H.HipDropinBackend()
-    what = dict(family=fam, nrow=nrow, ncol=ncol, nnz=nnz, integer=integer, seed=seed, case=cases, ngpu=os.environ.get("FASTSPARSE_NGPU", "1"))
+    in_hbm = bool(rng.integers(0, 3) == 0)
+    be = DeviceVectors() if in_hbm else H.HipDropinBackend()
+    what = dict(hbm=in_hbm, family=fam, nrow=nrow, ncol=ncol, nnz=nnz, integer=integer, seed=seed, case=cases, ngpu=os.environ.get("FASTSPARSE_NGPU", "1"))
 
     def vec(n, k=1):
         if integer:
