@@ -17,8 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                       ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1"}),
                                       ("fuzz_dropin.py", {"FS_STRICT_ORDER": "1", "FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}),
                                       # the solvers (bsbm_cg / bsbm_cg2 and fs_cg / fs_cg2): true residuals, iteration counts, two solves bit for bit
-                                      ("fuzz_cg.py", {}), ("fuzz_cg.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"})])
+                                      ("fuzz_cg.py", {}), ("fuzz_cg.py", {"FASTSPARSE_NGPU": "3", "FASTSPARSE_DEVICES": "0,0,0"}),
+                                      # expected results from the REAL reference library instead of the oracle's restatement
+                                      ("fuzz_dropin.py", {"FS_FUZZ_REF": "1", "FS_STRICT_ORDER": "1"}), ("fuzz_cg.py", {"FS_FUZZ_REF": "1"})])
 def test_randomised_differential_stretch(tool, env):
+    if env.get("FS_FUZZ_REF") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libfsref.so")):
+        pytest.skip("oracle/_ref/libfsref.so (the real reference, built where /root/reference exists) did not travel")
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "6", "20251005"], cwd=ROOT, env=e, capture_output=True, text=True,
                          timeout=300)

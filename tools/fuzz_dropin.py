@@ -27,6 +27,14 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
 rng = np.random.default_rng(seed)
 ORA = _cases.OracleBackend()
+# FS_FUZZ_REF=1: the expected results come from the REAL reference library (oracle/_ref/libfsref.so: travels to the GPU box as a built file)
+# instead of the oracle's restatement (the CPU suite pins the two to each other bit for bit)
+REF = None
+if os.environ.get("FS_FUZZ_REF") == "1":
+    import _refbind
+    if not _refbind.available():
+        raise SystemExit("FS_FUZZ_REF=1 but oracle/_ref/libfsref.so is missing")
+    REF = _cases.RefBackend()
 STRICT = os.environ.get("FS_STRICT_ORDER") == "1"      # storage-order sums: the oracle's bits for ARBITRARY x and values, every family
 
 FAMILIES = ["coo", "coo_t", "csr", "csr_t", "csr_n", "bin_n", "aa", "aa_parallel", "blocked", "blocked_n", "blocked_valued", "cbcsr"]
@@ -73,7 +81,7 @@ while time.time() < t_end:
 
     def both(method, *args, valued, out_terms):
         got = getattr(be, method)(*args)
-        ref = getattr(ORA, method)(*args)
+        ref = getattr(REF or ORA, method)(*args)
         # the scale: the same call on |values|, |x| through the oracle
         a = list(args)
         for i, v in enumerate(a):
@@ -110,7 +118,7 @@ while time.time() < t_end:
     elif fam in ("aa", "aa_parallel"):
         x = vec(ncol)
         got = be.aa_mul(nrow, ncol, rows, cols, x, fam == "aa_parallel")
-        ref = ORA.aa_mul(nrow, ncol, rows, cols, x, False)
+        ref = (REF or ORA).aa_mul(nrow, ncol, rows, cols, x, False)
         sc = ORA.aa_mul(nrow, ncol, rows, cols, np.abs(x), False)
         if integer or STRICT:
             assert np.array_equal(got, ref), what
@@ -142,7 +150,9 @@ while time.time() < t_end:
         print("%d cases ok" % cases, flush=True)
     if cases % 200 == 0:
         be.L.fs_release_all()
+    if REF:
+        REF.R._keep.clear()
     if psutil.Process().memory_info().rss > 64 << 30:                 # (never near the box's cap again)
         raise SystemExit("fuzz_dropin: more than 64 GiB resident after %r: stopping" % (what,))
-print("fuzz_dropin: %d cases, all within the bars (seed %d, FASTSPARSE_NGPU=%s): %s"
-      % (cases, seed, os.environ.get("FASTSPARSE_NGPU", "1"), ", ".join("%s %d" % kv for kv in sorted(seen.items()))))
+print("fuzz_dropin: %d cases, all within the bars (seed %d, FASTSPARSE_NGPU=%s, expected results from %s): %s"
+      % (cases, seed, os.environ.get("FASTSPARSE_NGPU", "1"), "the REAL reference library" if REF else "the oracle", ", ".join("%s %d" % kv for kv in sorted(seen.items()))))
