@@ -303,6 +303,14 @@ struct BuildClock {
 };
 }  // namespace
 
+// The L2-tiled kernel gathers from an L2-resident band of x: it has never run faster than 152 G entries per second on a matrix whose x
+// does not fit L2 (config 2: 1.05 ms for 160 M entries; its gathers alone are bound at 205 G/s, profiles/r04_probe_gather.jsonl), where the
+// two-pass pair streams 200 G valued / 280 G pattern entries per second.  So on a large matrix whose two-pass copy, just built, already
+// beats that rate, the L2-tiled copy is not built at all (config 2: 34 + 6 of 115 ms per matrix, and its transient HBM), and the
+// streaming kernel -- three to four times slower there -- is timed once instead of five times.  Auto mode only.
+constexpr double kTiledBestEntriesPerMs = 152e6;
+static int two_pass_clear_win(DeviceCsr &A, hipStream_t s, bool *win);
+
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
 {
   BuildClock clock(s);
@@ -340,8 +348,12 @@ int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
                                                                               // fixed-order sums asked for needs its rivals)
   if (!ldsx_clear_win)
     if (int rc = build_binned(A, s)) return rc;
-  A.build_ms[3] = clock.lap();
+  bool binned_clear_win = false;
   if (!ldsx_clear_win)
+    if (int rc = two_pass_clear_win(A, s, &binned_clear_win)) return rc;
+  A.two_pass_clear_win = binned_clear_win;
+  A.build_ms[3] = clock.lap();
+  if (!ldsx_clear_win && !binned_clear_win)
     if (int rc = build_tiled(A, s)) return rc;
   A.build_ms[4] = clock.lap();
   const int rc = choose_copy(A, s);        // fills build_ms[6] (timing) and starts [7] (freeing the losers)
@@ -2358,6 +2370,26 @@ static int time_product(F launch, hipStream_t s, hipEvent_t e0, hipEvent_t e1, f
   return FS_OK;
 }
 
+static int two_pass_clear_win(DeviceCsr &A, hipStream_t s, bool *win)
+{
+  *win = false;
+  const Options &o = options();
+  if (!(A.binned && A.binned->built) || o.binning != 1 || o.tiling != 1 || A.nnz < (32ll << 20) || 8.0 * (double)A.ncol <= (double)(4 << 20)) return FS_OK;
+  Scratch<double> x, y;
+  if (x.alloc((size_t)A.ncol) != hipSuccess || y.alloc((size_t)A.nrow) != hipSuccess) { (void)hipGetLastError(); return FS_OK; }
+  FS_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)A.ncol, s));
+  hipEvent_t e0, e1;
+  FS_HIP(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return FS_OK; }
+  float t = 1e30f;
+  const int rc = time_product([&] { return launch_spmv_binned(A, y, x, s); }, s, e0, e1, &t, 2);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != FS_OK) return rc;
+  *win = (double)t <= (double)A.nnz / kTiledBestEntriesPerMs;
+  return FS_OK;
+}
+
 int choose_copy(DeviceCsr &A, hipStream_t s)
 {
   BuildClock clock(s);
@@ -2383,7 +2415,7 @@ int choose_copy(DeviceCsr &A, hipStream_t s)
   // (a lone LDS-staged copy with dense tiles -- build_schedule did not build its rivals -- is 8 to 15 times faster than the
   // streaming kernel: one timed run of that one is enough to say so, five cost 25-50 ms of a 230 ms build on config 3)
   const bool lone_ldsx = hx && !hb && !ht && A.tiledx->entries_per_tile >= kLdsxClearWin;
-  int rc = time_product([&] { return launch_spmv(A, y, x, s, true); }, s, e0, e1, &t_stream, lone_ldsx ? 1 : 5);
+  int rc = time_product([&] { return launch_spmv(A, y, x, s, true); }, s, e0, e1, &t_stream, (lone_ldsx || A.two_pass_clear_win) ? 1 : 5);
   if (rc == FS_OK && ht) rc = time_product([&] { return launch_spmv_tiled(A, *A.tiled, y, x, s); }, s, e0, e1, &t_tiled);
   if (rc == FS_OK && hx) rc = time_product([&] { return launch_spmv_tiled(A, *A.tiledx, y, x, s); }, s, e0, e1, &t_ldsx);
   if (rc == FS_OK && hb) rc = time_product([&] { return launch_spmv_binned(A, y, x, s); }, s, e0, e1, &t_bin);
