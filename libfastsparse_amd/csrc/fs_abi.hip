@@ -720,6 +720,7 @@ int fs_matrix_restore_csr(fs_matrix_t A, int transposed, const int *row_ptr, con
     if (!rc && vals) rc = fs::to_device(&a.vals, vals, (size_t)a.nnz, space);
   }
   a.released = false;
+  a.max_row_len = -1;
   if (!rc) rc = fs::build_schedule(a, nullptr, /*allow_tiled=*/false);     // the chunk schedule of the streaming kernel only: the kept copy stays
   if (rc) { (void)fs::release_plain_csr(a); return rc; }
   return FS_OK;

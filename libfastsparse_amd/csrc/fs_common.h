@@ -54,6 +54,7 @@ struct DeviceCsr {
   // what the format builder measured when it chose (ms per product, median of 5; 0 = candidate not built / not timed):
   // [0] chunk-streaming, [1] L2-tiled, [2] LDS-staged tiled, [3] two-pass
   float candidate_ms[4] = {0.f, 0.f, 0.f, 0.f};
+  mutable int max_row_len = -1;      // longest row, once a builder has asked (-1: not yet); the arrays of a handle never change
   bool two_pass_clear_win = false;   // the builder did not build the L2-tiled copy: the two-pass pair already ran faster than that kernel ever has
   // where the one-time work of this matrix went, in ms of host wall time (fs_matrix_build_ms): [0] the arrays into HBM (upload or
   // device copy) + validation, [1] ordering (COO -> CSR, or the transpose), [2] chunk schedule, [3] two-pass copy built, [4] L2-tiled
