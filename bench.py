@@ -515,7 +515,7 @@ _TRAFFIC_SOURCE = None
 _LIVE_PMC_BROKEN = None      # the first failure of a live PMC pass: later workloads do not try again (the run must stay within minutes)
 
 
-def live_pmc_traffic(args, workload="c2", kernels=("fs::spmv_expand_kernel", "fs::spmv_reduce_kernel")):
+def live_pmc_traffic(args, workload="c2", kernels=("fs::spmv_expand_kernel", "fs::spmv_reduce_")):
     """roofline.traffic MEASURED BY THIS RUN (N = 1): two short children of this process -- `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
     and `--pmc WRITE_SIZE`, separate passes as MI355X_MICROARCH.md's HBM section prescribes, the program itself behind `--` -- run
     this file's `workload` for a few steps (`--lean`: device vectors only, no probes, no CPU baseline), and the per-dispatch sums of
@@ -1142,7 +1142,7 @@ def run_c2(args, prov, world, rank, nccl, strong=False, out=None):
     if not _multi(world) and not strong and n_global == 10_000_000 and per == 16 and not getattr(args, "lean", False):
         rec["roofline"].update(config2_bound(bytes_per_launch, prov))
     if not _multi(world) and not strong and kname == "two-pass" and kname_t == "two-pass" and hasattr(prov, "capi"):
-        apply_live_traffic(rec, args, "c2", ("fs::spmv_expand_kernel", "fs::spmv_reduce_kernel"), bytes_per_launch)
+        apply_live_traffic(rec, args, "c2", ("fs::spmv_expand_kernel", "fs::spmv_reduce_"), bytes_per_launch)
     if _multi(world):
         rec["config"].update({
             "exchange_check": exchange_check,
@@ -1648,7 +1648,7 @@ def run_c5(args, prov, world, rank, nccl, out=None):
         rec["config"]["fixed_order_sums"] = repro
         rec["config"]["reproducible_cost_pct"] = repro.get("reproducible_cost_pct")
     if not _multi(world) and kname == "two-pass" and hasattr(prov, "capi"):
-        apply_live_traffic(rec, args, "c5", ("fs::spmv_expand_kernel", "fs::spmv_longrows_kernel", "fs::spmv_reduce_kernel", "fs::tiled_combine_kernel"),
+        apply_live_traffic(rec, args, "c5", ("fs::spmv_expand_kernel", "fs::spmv_longrows_kernel", "fs::spmv_reduce_", "fs::tiled_combine_kernel"),
                            bytes_local)
     if hasattr(A, "build_ms"):
         rec["config"]["one_time"] = one_time_costs([("A", A, False)], "this rank's shard: device arrays in (borrowed), candidates built and timed")

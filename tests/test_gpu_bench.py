@@ -26,7 +26,7 @@ def test_bench_line_measures_its_own_hbm_traffic():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "traffic_live_measurement_failed" not in r, r.get("traffic_live_measurement_failed")
     m = r["traffic_measured"]
-    assert m["measured_by_this_run"] is True and set(m["bytes_per_kernel"]) == {"fs::spmv_expand_kernel", "fs::spmv_reduce_kernel"}
+    assert m["measured_by_this_run"] is True and set(m["bytes_per_kernel"]) == {"fs::spmv_expand_kernel", "fs::spmv_reduce_"}
     assert abs(sum(m["bytes_per_kernel"].values()) - r["traffic"]) < 1.0
     alg = r["algorithmic_bytes_per_launch"]
     # the two-pass pair moves 28.25 B per entry for 12 algorithmic ones: between 2 x and 2.6 x, and close to what profiles/ holds
