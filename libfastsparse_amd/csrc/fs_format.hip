@@ -308,7 +308,7 @@ struct BuildClock {
 // two-pass pair streams 200 G valued / 280 G pattern entries per second.  So on a large matrix whose two-pass copy, just built, already
 // beats that rate, the L2-tiled copy is not built at all (config 2: 34 + 6 of 115 ms per matrix, and its transient HBM), and the
 // streaming kernel -- three to four times slower there -- is timed once instead of five times.  Auto mode only.
-constexpr double kTiledBestEntriesPerMs = 152e6;
+constexpr double kTiledBestEntriesPerMs = 152e6;          // valued; pattern-only: 200e6 (config 2's pattern: 0.817 ms = 196 G/s, profiles/r03_cg_kernel_stats.csv)
 static int two_pass_clear_win(DeviceCsr &A, hipStream_t s, bool *win);
 
 int build_schedule(DeviceCsr &A, hipStream_t s, bool allow_tiled)
@@ -2390,7 +2390,7 @@ static int two_pass_clear_win(DeviceCsr &A, hipStream_t s, bool *win)
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc != FS_OK) return rc;
-  *win = (double)t <= (double)A.nnz / kTiledBestEntriesPerMs;
+  *win = (double)t <= (double)A.nnz / (A.vals ? kTiledBestEntriesPerMs : 200e6);
   return FS_OK;
 }
 
